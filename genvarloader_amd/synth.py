@@ -1,0 +1,253 @@
+"""Seeded synthetic inputs for the haplotype hot path (host side, numpy only).
+
+Shapes and dtypes are exactly what the reference's FFI consumes
+(``/root/reference/src/ffi/mod.rs:724-743``; layout conventions in
+``python/genvarloader/_dataset/_haps.py:844-866``): ``regions`` i32 ``(B, 4)``
+``[contig, start, end, strand]``, ``shifts`` i32 ``(B, P)``, ``geno_offset_idx``
+i64 ``(B, P)``, ``geno_offsets`` i64 ``(2, n)`` starts/stops, ``geno_v_idxs`` i32,
+variant table ``v_starts``/``ilens`` i32 + ``alt_alleles`` u8 / ``alt_offsets`` i64,
+``ref`` u8 / ``ref_offsets`` i64.  The role is the one ``_dummy.py:23-213`` plays
+in the reference: an in-memory dataset with no files behind it.
+
+The recipe follows SURVEY.md section 8(d): uniform ACGT reference with 1 % N,
+Poisson variant density 1/300 bp, SNP-only or 85 % SNP / 15 % atomised indel
+(|ilen| ~ Geometric(0.35) clipped to [1, 30]; an insertion's ALT is the anchor
+base followed by ilen random bases, a deletion's ALT is the anchor base), each
+haplotype carrying each overlapping variant with a per-variant allele frequency
+AF ~ Beta(a, b).  With the default Beta(0.6, 0.9) a 2048 bp window sees about 3
+variants per haplotype.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+ACGT = np.frombuffer(b"ACGT", np.uint8)
+
+
+@dataclass
+class SynthStatic:
+    """Per-dataset arrays (uploaded once; mirror of ``_HapsFfiStatic``,
+    ``_haps.py:233-247`` plus ``Reference``, ``_reference.py:31-50``)."""
+
+    ref: np.ndarray
+    ref_offsets: np.ndarray
+    v_starts: np.ndarray
+    ilens: np.ndarray
+    alt_alleles: np.ndarray
+    alt_offsets: np.ndarray
+    v_contig: np.ndarray  # i32 contig of each variant (generator bookkeeping only)
+    af: np.ndarray
+    pad_char: int = ord("N")
+
+
+@dataclass
+class SynthBatch:
+    """Per-batch arrays (``ReconstructionRequest``, ``_haps.py:58-93``) plus the
+    sparse-genotype CSR the batch indexes."""
+
+    regions: np.ndarray
+    shifts: np.ndarray
+    geno_offset_idx: np.ndarray
+    geno_offsets: np.ndarray
+    geno_v_idxs: np.ndarray
+    to_rc: np.ndarray | None
+    output_length: int
+    keep: np.ndarray | None = None
+    keep_offsets: np.ndarray | None = None
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def n_windows(self) -> int:
+        return int(self.geno_offset_idx.size)
+
+    @property
+    def mean_variants(self) -> float:
+        go = self.geno_offsets
+        idx = self.geno_offset_idx.ravel()
+        return float((go[1, idx] - go[0, idx]).mean()) if idx.size else 0.0
+
+
+def make_static(
+    rng: np.random.Generator,
+    contig_lens=(1 << 20,),
+    density: float = 1.0 / 300.0,
+    indel_frac: float = 0.0,
+    n_frac: float = 0.01,
+    af_beta=(0.6, 0.9),
+    max_indel: int = 30,
+) -> SynthStatic:
+    contig_lens = [int(x) for x in contig_lens]
+    ref_offsets = np.zeros(len(contig_lens) + 1, np.int64)
+    ref_offsets[1:] = np.cumsum(contig_lens)
+    total = int(ref_offsets[-1])
+    ref = ACGT[rng.integers(0, 4, total, dtype=np.uint8)]
+    if n_frac > 0:
+        ref[rng.random(total) < n_frac] = ord("N")
+
+    v_starts_l, ilens_l, alts_l, alt_len_l, contig_l = [], [], [], [], []
+    for c, clen in enumerate(contig_lens):
+        n = int(rng.poisson(clen * density))
+        if n == 0:
+            continue
+        pos = np.unique(rng.integers(0, clen, n, dtype=np.int64))
+        n = len(pos)
+        is_indel = rng.random(n) < indel_frac
+        mag = np.clip(rng.geometric(0.35, n), 1, max_indel).astype(np.int64)
+        sign = np.where(rng.random(n) < 0.5, -1, 1)
+        il = np.where(is_indel, mag * sign, 0).astype(np.int64)
+        # a deletion may not run past the contig end (pos - ilen + 1 <= clen)
+        room = clen - 1 - pos
+        il = np.where(il < 0, -np.minimum(-il, room), il)
+        alt_len = 1 + np.maximum(il, 0)
+        off = np.zeros(n + 1, np.int64)
+        off[1:] = np.cumsum(alt_len)
+        alt = ACGT[rng.integers(0, 4, int(off[-1]), dtype=np.uint8)]
+        base = ref[ref_offsets[c] + pos]
+        first = off[:-1]
+        snp = il == 0
+        # SNP: a base different from the reference base
+        code = np.searchsorted(ACGT, base)  # N (78) -> 4? searchsorted on sorted ACGT
+        code = np.where(code > 3, 0, code)
+        alt_snp = ACGT[(code + rng.integers(1, 4, n)) % 4]
+        alt[first] = np.where(snp, alt_snp, base)  # indels keep the anchor base
+        v_starts_l.append(pos.astype(np.int32))
+        ilens_l.append(il.astype(np.int32))
+        alts_l.append(alt)
+        alt_len_l.append(alt_len)
+        contig_l.append(np.full(n, c, np.int32))
+
+    if v_starts_l:
+        v_starts = np.concatenate(v_starts_l)
+        ilens = np.concatenate(ilens_l)
+        alt_alleles = np.concatenate(alts_l)
+        alt_len = np.concatenate(alt_len_l)
+        v_contig = np.concatenate(contig_l)
+    else:
+        v_starts = np.zeros(0, np.int32)
+        ilens = np.zeros(0, np.int32)
+        alt_alleles = np.zeros(0, np.uint8)
+        alt_len = np.zeros(0, np.int64)
+        v_contig = np.zeros(0, np.int32)
+    alt_offsets = np.zeros(len(v_starts) + 1, np.int64)
+    alt_offsets[1:] = np.cumsum(alt_len)
+    af = rng.beta(af_beta[0], af_beta[1], len(v_starts))
+    return SynthStatic(ref, ref_offsets, v_starts, ilens, alt_alleles, alt_offsets, v_contig, af)
+
+
+def make_batch(
+    rng: np.random.Generator,
+    st: SynthStatic,
+    n_queries: int,
+    ploidy: int = 2,
+    length: int = 2048,
+    slack: int = 32,
+    rc_frac: float = 0.0,
+    random_shifts: bool = False,
+    output_length: int | None = None,
+    lookback: int = 40,
+    edge_frac: float = 0.0,
+    permute_csr: bool = False,
+) -> SynthBatch:
+    """``n_queries`` regions of ``length + 2*slack`` bp, ``ploidy`` haplotypes each.
+
+    ``edge_frac`` of the regions are pushed over a contig edge (negative start /
+    end past the contig) to exercise the padding branches.  ``output_length``
+    defaults to ``length`` (fixed-length crop); pass ``-1`` for ragged."""
+    B, P = int(n_queries), int(ploidy)
+    n_contigs = len(st.ref_offsets) - 1
+    clens = np.diff(st.ref_offsets)
+    contig = rng.integers(0, n_contigs, B).astype(np.int64)
+    span = length + 2 * slack
+    hi = np.maximum(clens[contig] - span, 1)
+    start = (rng.random(B) * hi).astype(np.int64)
+    if edge_frac > 0:
+        edge = rng.random(B) < edge_frac
+        left = rng.random(B) < 0.5
+        off = rng.integers(1, max(2, span // 2), B)
+        start = np.where(edge & left, -off, start)
+        start = np.where(edge & ~left, clens[contig] - span + off, start)
+    end = start + span
+    strand = np.where(rng.random(B) < rc_frac, -1, 1)
+    regions = np.stack([contig, start, end, strand], axis=1).astype(np.int32)
+
+    # candidate variants per query: pos in [start - lookback, end) on its contig
+    # (variants are grouped by contig, sorted by position inside a contig)
+    c_first = np.searchsorted(st.v_contig, np.arange(n_contigs), "left")
+    c_last = np.searchsorted(st.v_contig, np.arange(n_contigs), "right")
+    lo = np.empty(B, np.int64)
+    hi_ = np.empty(B, np.int64)
+    for c in range(n_contigs):
+        m = contig == c
+        if not m.any():
+            continue
+        vs = st.v_starts[c_first[c] : c_last[c]]
+        lo[m] = c_first[c] + np.searchsorted(vs, start[m] - lookback, "left")
+        hi_[m] = c_first[c] + np.searchsorted(vs, end[m], "left")
+    n_cand = np.repeat(hi_ - lo, P)  # per row k
+    row_lo = np.repeat(lo, P)
+    K = B * P
+    cand_off = np.zeros(K + 1, np.int64)
+    cand_off[1:] = np.cumsum(n_cand)
+    tot = int(cand_off[-1])
+    row_of = np.repeat(np.arange(K), n_cand)
+    v_of = row_lo[row_of] + (np.arange(tot) - cand_off[row_of])
+    carried = rng.random(tot) < st.af[v_of]
+    geno_v_idxs = v_of[carried].astype(np.int32)
+    counts = np.bincount(row_of[carried], minlength=K).astype(np.int64)
+    offs = np.zeros(K + 1, np.int64)
+    offs[1:] = np.cumsum(counts)
+    geno_offsets = np.ascontiguousarray(np.stack([offs[:-1], offs[1:]]))
+    geno_offset_idx = np.arange(K, dtype=np.int64).reshape(B, P)
+    if permute_csr:
+        # shuffle which CSR slot each row uses (geno_offset_idx is then non-trivial)
+        perm = rng.permutation(K)
+        inv = np.empty(K, np.int64)
+        inv[perm] = np.arange(K)
+        geno_offsets = np.ascontiguousarray(geno_offsets[:, perm])
+        geno_offset_idx = inv.reshape(B, P)
+
+    out_len = length if output_length is None else int(output_length)
+    if random_shifts and out_len >= 0:
+        # _haps.py:728-730: max_shift = clip(diff, 0) + clip(region_len - output_length, 0)
+        il = st.ilens[geno_v_idxs].astype(np.int64)
+        csum = np.concatenate([[0], np.cumsum(np.maximum(il, 0))])
+        approx = csum[offs[1:]] - csum[offs[:-1]]
+        max_shift = approx.reshape(B, P) + np.clip((end - start) - out_len, 0, None)[:, None]
+        shifts = rng.integers(0, max_shift + 1).astype(np.int32)
+    else:
+        shifts = np.zeros((B, P), np.int32)
+    to_rc = np.repeat(strand == -1, P) if rc_frac > 0 else None
+    return SynthBatch(
+        regions=regions, shifts=shifts, geno_offset_idx=geno_offset_idx,
+        geno_offsets=geno_offsets, geno_v_idxs=geno_v_idxs, to_rc=to_rc,
+        output_length=out_len,
+        meta=dict(B=B, P=P, length=length, slack=slack, rc_frac=rc_frac),
+    )
+
+
+# --- BASELINE.json configs ---------------------------------
+CONFIGS = {
+    # name: (n_windows, length, indel_frac, rc_frac, contig_len)
+    "cfg1": dict(windows=1024, length=1024, indel_frac=0.0, rc_frac=0.0, contig=64 << 20),
+    "cfg2": dict(windows=4096, length=2048, indel_frac=0.0, rc_frac=0.0, contig=64 << 20),
+    "cfg3": dict(windows=4096, length=2048, indel_frac=0.15, rc_frac=0.5, contig=64 << 20),
+    "cfg4": dict(windows=256, length=131072, indel_frac=0.15, rc_frac=0.0, contig=256 << 20),
+}
+
+
+def make_config(name: str, seed: int | None = None, ploidy: int = 2, contig: int | None = None,
+                windows: int | None = None, random_shifts: bool = False):
+    """Build (static, batch) for a BASELINE.json config.  Seeds follow SURVEY 8(d):
+    ``default_rng(20260802 + cfg_index)``."""
+    cfg = CONFIGS[name]
+    idx = int(name[3:])
+    rng = np.random.default_rng(20260802 + idx if seed is None else seed)
+    st = make_static(rng, (contig or cfg["contig"],), indel_frac=cfg["indel_frac"])
+    k = windows or cfg["windows"]
+    bt = make_batch(rng, st, k // ploidy, ploidy, cfg["length"], rc_frac=cfg["rc_frac"],
+                    random_shifts=random_shifts)
+    bt.meta["config"] = name
+    return st, bt

@@ -1,0 +1,286 @@
+"""ctypes front-end of the CPU oracle (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module; nothing in ``genvarloader_amd/`` does.
+
+Function names, argument order and meaning follow the reference's PyO3 entry
+points (``/root/reference/src/ffi/mod.rs``) so a parity test reads like the
+reference's own ``tests/parity`` replays:
+
+* ``reconstruct_haplotypes_from_sparse``  ffi/mod.rs:634-655 (in place)
+* ``reconstruct_haplotypes_fused``        ffi/mod.rs:724-743
+* ``get_diffs_sparse``                    ffi/mod.rs:145-157
+* ``choose_exonic_variants``              genotypes/mod.rs:132-176
+* ``get_reference``                       ffi/mod.rs:2402-2411
+* ``rc_flat_rows_inplace``                reverse.rs:56-69
+* ``onehot``                              definition in gvl_oracle.c (unpinned)
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+
+def build(march: str | None = None, force: bool = False) -> Path:
+    """Compile gvl_oracle*.c into libgvl_oracle.so (gcc).  Building the checker
+    is not using it."""
+    so = _HERE / "libgvl_oracle.so"
+    srcs = sorted(_HERE.glob("gvl_oracle*.c"))
+    stale = (not so.exists()) or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs)
+    if stale or force or march:
+        cmd = ["make", "-C", str(_HERE), "-B"]
+        if march:
+            cmd.append(f"MARCH={march}")
+        subprocess.run(cmd, check=True, capture_output=True)
+    return so
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        so = _HERE / "libgvl_oracle.so"
+        if not so.exists():
+            build()
+        _LIB = C.CDLL(str(so))
+        _LIB.gvlo_choose_exonic_variants.restype = C.c_int64
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return None if a is None else np.ascontiguousarray(a, dtype=dt)
+
+
+def _starts_stops(geno_offsets):
+    """_dataset/_genotypes.py:13-21 (_as_starts_stops)."""
+    o = np.asarray(geno_offsets)
+    if o.ndim == 1:
+        return np.ascontiguousarray(np.stack([o[:-1], o[1:]]), dtype=np.int64)
+    return np.ascontiguousarray(o, dtype=np.int64)
+
+
+def default_threads() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        return os.cpu_count() or 1
+
+
+def reconstruct_haplotypes_from_sparse(
+    out, out_offsets, regions, shifts, geno_offset_idx, geno_offsets, geno_v_idxs,
+    v_starts, ilens, alt_alleles, alt_offsets, ref, ref_offsets, pad_char,
+    keep=None, keep_offsets=None, annot_v_idxs=None, annot_ref_pos=None,
+    parallel=False, *, to_rc=None, onehot_out=None, n_threads=None,
+):
+    """In-place batch reconstruct (ffi/mod.rs:634-700).  ``to_rc`` / ``onehot_out``
+    are the fused-entry extras (ffi/mod.rs:842-853 and the a10 definition)."""
+    assert out.dtype == np.uint8 and out.flags.c_contiguous
+    out_offsets = _c(out_offsets, np.int64)
+    regions = _c(regions, np.int32)
+    shifts = _c(shifts, np.int32)
+    goi = _c(geno_offset_idx, np.int64)
+    go = _starts_stops(geno_offsets)
+    batch, ploidy = goi.shape
+    assert regions.shape[0] == batch and shifts.shape == goi.shape
+    gv = _c(geno_v_idxs, np.int32)
+    vs, il = _c(v_starts, np.int32), _c(ilens, np.int32)
+    aa, ao = _c(alt_alleles, np.uint8), _c(alt_offsets, np.int64)
+    rf, ro = _c(ref, np.uint8), _c(ref_offsets, np.int64)
+    kp, ko = _c(keep, np.uint8 if keep is None else np.bool_), _c(keep_offsets, np.int64)
+    rc = _c(to_rc, np.bool_)
+    for a in (annot_v_idxs, annot_ref_pos):
+        assert a is None or (a.dtype == np.int32 and a.flags.c_contiguous)
+    nt = n_threads if n_threads is not None else (default_threads() if parallel else 1)
+    go0, go1 = np.ascontiguousarray(go[0]), np.ascontiguousarray(go[1])
+    lib().gvlo_reconstruct_batch(
+        _p(out), _p(out_offsets), _p(regions), C.c_int64(regions.shape[1]),
+        C.c_int64(batch), C.c_int64(ploidy), _p(shifts), _p(goi), _p(go0), _p(go1),
+        _p(gv), _p(vs), _p(il), _p(aa), _p(ao), _p(rf), _p(ro), C.c_uint8(int(pad_char)),
+        _p(kp), _p(ko), _p(annot_v_idxs), _p(annot_ref_pos), _p(rc), _p(onehot_out),
+        C.c_int(nt),
+    )
+
+
+def get_diffs_sparse(
+    geno_offset_idx, geno_v_idxs, geno_offsets, ilens, keep=None, keep_offsets=None,
+    q_starts=None, q_ends=None, v_starts=None, parallel=False, *, n_threads=None,
+):
+    """ffi/mod.rs:145-185 -> genotypes/mod.rs:15-125."""
+    goi = _c(geno_offset_idx, np.int64)
+    go = _starts_stops(geno_offsets)
+    batch, ploidy = goi.shape
+    diffs = np.zeros((batch, ploidy), np.int32)
+    go0, go1 = np.ascontiguousarray(go[0]), np.ascontiguousarray(go[1])
+    gv, il = _c(geno_v_idxs, np.int32), _c(ilens, np.int32)
+    kp, ko = _c(keep, np.bool_), _c(keep_offsets, np.int64)
+    qs, qe, vs = _c(q_starts, np.int32), _c(q_ends, np.int32), _c(v_starts, np.int32)
+    nt = n_threads if n_threads is not None else (default_threads() if parallel else 1)
+    lib().gvlo_get_diffs_sparse(
+        _p(goi), C.c_int64(batch), C.c_int64(ploidy), _p(gv), _p(go0), _p(go1), _p(il),
+        _p(kp), _p(ko), _p(qs), _p(qe), C.c_int64(1), _p(vs), _p(diffs), C.c_int(nt),
+    )
+    return diffs
+
+
+def choose_exonic_variants(starts, ends, geno_offset_idx, geno_v_idxs, geno_offsets,
+                           v_starts, ilens):
+    """genotypes/mod.rs:132-176 -> (keep bool[], keep_offsets i64[n+1])."""
+    goi = _c(geno_offset_idx, np.int64)
+    go = _starts_stops(geno_offsets)
+    batch, ploidy = goi.shape
+    go0, go1 = np.ascontiguousarray(go[0]), np.ascontiguousarray(go[1])
+    st, en = _c(starts, np.int32), _c(ends, np.int32)
+    gv, vs, il = _c(geno_v_idxs, np.int32), _c(v_starts, np.int32), _c(ilens, np.int32)
+    ko = np.zeros(batch * ploidy + 1, np.int64)
+    args = (_p(st), _p(en), _p(goi), C.c_int64(batch), C.c_int64(ploidy), _p(gv),
+            _p(go0), _p(go1), _p(vs), _p(il))
+    n = lib().gvlo_choose_exonic_variants(*args, None, _p(ko))
+    keep = np.zeros(n, np.bool_)
+    lib().gvlo_choose_exonic_variants(*args, _p(keep), _p(ko))
+    return keep, ko
+
+
+def fused_out_offsets(regions, diffs, output_length):
+    """ffi/mod.rs:794-811."""
+    regions = _c(regions, np.int32)
+    diffs = _c(diffs, np.int32)
+    batch, ploidy = diffs.shape
+    oo = np.zeros(batch * ploidy + 1, np.int64)
+    lib().gvlo_fused_out_offsets(_p(regions), C.c_int64(regions.shape[1]), C.c_int64(batch),
+                                 C.c_int64(ploidy), _p(diffs), C.c_int64(int(output_length)),
+                                 _p(oo))
+    return oo
+
+
+def reconstruct_haplotypes_fused(
+    regions, shifts, geno_offset_idx, geno_offsets, geno_v_idxs, v_starts, ilens,
+    alt_alleles, alt_offsets, ref_, ref_offsets, pad_char, output_length,
+    keep=None, keep_offsets=None, to_rc=None, parallel=False, *, onehot=False,
+    n_threads=None,
+):
+    """ffi/mod.rs:724-860: diffs (query mode) -> offsets -> reconstruct -> RC.
+    With ``onehot=True`` also returns the (total, 4) uint8 one-hot."""
+    regions = _c(regions, np.int32)
+    diffs = get_diffs_sparse(
+        geno_offset_idx, geno_v_idxs, geno_offsets, ilens, keep, keep_offsets,
+        np.ascontiguousarray(regions[:, 1]), np.ascontiguousarray(regions[:, 2]),
+        v_starts, parallel, n_threads=n_threads,
+    )
+    out_offsets = fused_out_offsets(regions, diffs, output_length)
+    total = int(out_offsets[-1])
+    out = np.empty(total, np.uint8)
+    oh = np.empty((total, 4), np.uint8) if onehot else None
+    reconstruct_haplotypes_from_sparse(
+        out, out_offsets, regions, shifts, geno_offset_idx, geno_offsets, geno_v_idxs,
+        v_starts, ilens, alt_alleles, alt_offsets, ref_, ref_offsets, pad_char,
+        keep, keep_offsets, None, None, parallel, to_rc=to_rc, onehot_out=oh,
+        n_threads=n_threads,
+    )
+    if onehot:
+        return out, out_offsets, oh
+    return out, out_offsets
+
+
+def reconstruct_annotated_haplotypes_fused(
+    regions, shifts, geno_offset_idx, geno_offsets, geno_v_idxs, v_starts, ilens,
+    alt_alleles, alt_offsets, ref_, ref_offsets, pad_char, output_length,
+    keep=None, keep_offsets=None, to_rc=None, parallel=False, *, n_threads=None,
+):
+    """ffi/mod.rs:2237-2397: fused + two i32 annotation buffers; RC rows have
+    their annotations reversed (reverse.rs:25-38)."""
+    regions = _c(regions, np.int32)
+    diffs = get_diffs_sparse(
+        geno_offset_idx, geno_v_idxs, geno_offsets, ilens, keep, keep_offsets,
+        np.ascontiguousarray(regions[:, 1]), np.ascontiguousarray(regions[:, 2]),
+        v_starts, parallel, n_threads=n_threads,
+    )
+    out_offsets = fused_out_offsets(regions, diffs, output_length)
+    total = int(out_offsets[-1])
+    out = np.empty(total, np.uint8)
+    av = np.empty(total, np.int32)
+    ap = np.empty(total, np.int32)
+    reconstruct_haplotypes_from_sparse(
+        out, out_offsets, regions, shifts, geno_offset_idx, geno_offsets, geno_v_idxs,
+        v_starts, ilens, alt_alleles, alt_offsets, ref_, ref_offsets, pad_char,
+        keep, keep_offsets, av, ap, parallel, to_rc=to_rc, n_threads=n_threads,
+    )
+    return out, av, ap, out_offsets
+
+
+def get_reference(regions, out_offsets, reference, ref_offsets, pad_char, parallel=False,
+                  to_rc=None, *, n_threads=None):
+    """ffi/mod.rs:2402-2429 -> reference/mod.rs:56-120."""
+    regions = _c(regions, np.int32)
+    oo = _c(out_offsets, np.int64)
+    rf, ro = _c(reference, np.uint8), _c(ref_offsets, np.int64)
+    out = np.zeros(int(oo[-1]), np.uint8)
+    rc = _c(to_rc, np.bool_)
+    nt = n_threads if n_threads is not None else (default_threads() if parallel else 1)
+    lib().gvlo_get_reference(_p(regions), C.c_int64(regions.shape[1]),
+                              C.c_int64(regions.shape[0]), _p(oo), _p(rf), _p(ro),
+                              C.c_uint8(int(pad_char)), _p(rc), _p(out), C.c_int(nt))
+    return out
+
+
+def rc_flat_rows_inplace(data, offsets, to_rc):
+    """reverse.rs:56-69."""
+    assert data.dtype == np.uint8 and data.flags.c_contiguous
+    oo, rc = _c(offsets, np.int64), _c(to_rc, np.bool_)
+    lib().gvlo_rc_rows(_p(data), _p(oo), _p(rc), C.c_int64(len(rc)))
+
+
+def reverse_flat_rows_inplace(data, offsets, to_rc):
+    """reverse.rs:25-38 for 4-byte elements (f32 / i32)."""
+    assert data.dtype.itemsize == 4 and data.flags.c_contiguous
+    oo, rc = _c(offsets, np.int64), _c(to_rc, np.bool_)
+    lib().gvlo_reverse_rows_4(_p(data), _p(oo), _p(rc), C.c_int64(len(rc)))
+
+
+def reconstruct_haplotype_from_sparse(
+    v_idxs, v_starts, ilens, shift, alt_alleles, alt_offsets, ref, ref_start, out,
+    pad_char, keep=None, annot_v_idxs=None, annot_ref_pos=None,
+):
+    """Single row, same signature as the reference's numpy fallback
+    (_dataset/_genotypes.py:125-139) / Rust reconstruct/mod.rs:280-319."""
+    assert out.dtype == np.uint8 and out.flags.c_contiguous
+    vi = _c(v_idxs, np.int32)
+    vs, il = _c(v_starts, np.int32), _c(ilens, np.int32)
+    aa, ao = _c(alt_alleles, np.uint8), _c(alt_offsets, np.int64)
+    rf = _c(ref, np.uint8)
+    kp = _c(keep, np.bool_)
+    lib().gvlo_reconstruct_row(
+        C.c_int64(len(vi)), _p(vi), _p(vs), _p(il), C.c_int64(int(shift)), _p(aa), _p(ao),
+        _p(rf), C.c_int64(len(rf)), C.c_int64(int(ref_start)), _p(out), C.c_int64(len(out)),
+        C.c_uint8(int(pad_char)), _p(kp), _p(annot_v_idxs), _p(annot_ref_pos),
+    )
+
+
+def onehot(x, layout: str = "lc"):
+    """a10 definition.  ``x`` uint8 (..., L); "lc" -> (..., L, 4); "cl" -> (..., 4, L)."""
+    x = np.ascontiguousarray(x, np.uint8)
+    L = x.shape[-1] if x.ndim else 0
+    rows = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
+    if layout == "lc":
+        out = np.empty(x.shape + (4,), np.uint8)
+        lib().gvlo_onehot(_p(x), C.c_int64(rows), C.c_int64(L), C.c_int(0), _p(out))
+    else:
+        out = np.empty(x.shape[:-1] + (4, L), np.uint8)
+        lib().gvlo_onehot(_p(x), C.c_int64(rows), C.c_int64(L), C.c_int(1), _p(out))
+    return out
+
+
+def onehot_numpy(x):
+    """The 3-line numpy statement of the same definition (cross-check)."""
+    x = np.asarray(x, np.uint8)
+    return (x[..., None] == np.frombuffer(b"ACGT", np.uint8)).astype(np.uint8)

@@ -1,0 +1,176 @@
+"""Regenerates tests/golden/*.npz.  Runs ONLY in the build container (it reads
+/root/reference); the committed .npz files are what travels.
+
+Two kinds of fixture, both plain data (inputs + expected outputs, no pickles):
+
+1. ``ref_<kernel>.npz`` -- the reference's own frozen goldens
+   (``/root/reference/tests/parity/golden/<kernel>.npz``: object arrays of
+   ``(inputs, expected)`` produced by the reference's Rust build, see
+   ``tests/parity/_golden.py:47-54``) re-packed as flat numeric arrays.
+2. ``pyref_<name>.npz`` -- seeded synthetic batches shaped like the BASELINE
+   configs (scaled down), with expected haplotype bytes / annotations produced
+   by the reference's pure-numpy single-row fallback
+   ``reconstruct_haplotype_from_sparse`` (``_dataset/_genotypes.py:125-248``).
+   The function body is AST-extracted from the reference at generation time and
+   exec'd here; it is never written into this repo.
+
+Usage:  python tests/golden/make_fixtures.py
+"""
+
+from __future__ import annotations
+
+import ast
+import sys
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+REF = Path("/root/reference")
+sys.path.insert(0, str(REPO))
+
+from genvarloader_amd import synth  # noqa: E402
+
+REF_GOLDENS = [
+    "reconstruct_haplotypes_from_sparse",
+    "get_diffs_sparse",
+    "get_reference",
+    "rc_alleles",
+    "choose_exonic_variants",
+    "shift_and_realign_tracks_sparse",
+    "intervals_to_tracks",
+    "prng_xorshift64",
+    "prng_hash4",
+]
+
+
+def pack_cases(cases) -> dict:
+    """[(inputs tuple, expected)] -> flat dict of arrays.  Key scheme:
+    ``n`` case count; ``{i}/n_in``; ``{i}/in{j}`` (absent => None);
+    ``{i}/exp`` or ``{i}/exp{j}`` for tuple outputs (``{i}/n_exp``)."""
+    d = {"n": np.int64(len(cases))}
+    for i, (inputs, exp) in enumerate(cases):
+        if not isinstance(inputs, (tuple, list)):
+            inputs = (inputs,)
+        d[f"{i}/n_in"] = np.int64(len(inputs))
+        for j, x in enumerate(inputs):
+            if x is None:
+                continue
+            d[f"{i}/in{j}"] = np.asarray(x)
+        if isinstance(exp, (tuple, list)):
+            d[f"{i}/n_exp"] = np.int64(len(exp))
+            for j, x in enumerate(exp):
+                d[f"{i}/exp{j}"] = np.asarray(x)
+        else:
+            d[f"{i}/exp"] = np.asarray(exp)
+    for k, v in d.items():
+        assert v.dtype != object, (k, v.dtype)
+    return d
+
+
+def convert_reference_goldens():
+    for name in REF_GOLDENS:
+        src = REF / "tests/parity/golden" / f"{name}.npz"
+        cases = list(np.load(src, allow_pickle=True)["cases"])
+        np.savez_compressed(HERE / f"ref_{name}.npz", **pack_cases(cases))
+        print(f"ref_{name}.npz: {len(cases)} cases")
+
+
+def extract_function(path: Path, name: str):
+    """exec one top-level FunctionDef of a reference module in a numpy-only namespace."""
+    tree = ast.parse(path.read_text())
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == name:
+            mod = ast.Module(body=[node], type_ignores=[])
+            ns = {"np": np}
+            exec(compile(mod, str(path), "exec"), ns)
+            return ns[name]
+    raise KeyError(name)
+
+
+def pyref_batch(fallback, st, bt, annotate=False):
+    """Drive the reference's single-row fallback over a batch the way the Rust
+    batch driver does (reconstruct/mod.rs:376-422), then RC like ffi/mod.rs:842-853."""
+    B, P = bt.geno_offset_idx.shape
+    K = B * P
+    L = bt.output_length
+    assert L >= 0
+    out = np.zeros(K * L, np.uint8)
+    av = np.zeros(K * L, np.int32) if annotate else None
+    ap = np.zeros(K * L, np.int32) if annotate else None
+    comp = np.arange(256, dtype=np.uint8)
+    comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    for k in range(K):
+        q = k // P
+        oi = bt.geno_offset_idx.ravel()[k]
+        o_s, o_e = bt.geno_offsets[0, oi], bt.geno_offsets[1, oi]
+        c = bt.regions[q, 0]
+        contig = st.ref[st.ref_offsets[c] : st.ref_offsets[c + 1]]
+        keep = None
+        if bt.keep is not None:
+            keep = bt.keep[bt.keep_offsets[k] : bt.keep_offsets[k + 1]]
+        sl = slice(k * L, (k + 1) * L)
+        fallback(
+            bt.geno_v_idxs[o_s:o_e], st.v_starts, st.ilens, int(bt.shifts.ravel()[k]),
+            st.alt_alleles, st.alt_offsets, contig, int(bt.regions[q, 1]), out[sl],
+            st.pad_char, keep, None if av is None else av[sl], None if ap is None else ap[sl],
+        )
+        if bt.to_rc is not None and bt.to_rc[k]:
+            out[sl] = comp[out[sl][::-1]]
+            if annotate:
+                av[sl] = av[sl][::-1]
+                ap[sl] = ap[sl][::-1]
+    return out, av, ap
+
+
+def save_pyref(name, st, bt, out, av=None, ap=None):
+    d = dict(
+        ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+        alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, pad_char=np.uint8(st.pad_char),
+        regions=bt.regions, shifts=bt.shifts, geno_offset_idx=bt.geno_offset_idx,
+        geno_offsets=bt.geno_offsets, geno_v_idxs=bt.geno_v_idxs,
+        output_length=np.int64(bt.output_length), expected=out,
+    )
+    if bt.to_rc is not None:
+        d["to_rc"] = bt.to_rc
+    if bt.keep is not None:
+        d["keep"] = bt.keep
+        d["keep_offsets"] = bt.keep_offsets
+    if av is not None:
+        d["expected_annot_v_idxs"] = av
+        d["expected_annot_ref_pos"] = ap
+    np.savez_compressed(HERE / f"pyref_{name}.npz", **d)
+    print(f"pyref_{name}.npz: K={bt.n_windows} L={bt.output_length} "
+          f"V/row={bt.mean_variants:.2f} bytes={out.size}")
+
+
+def generate_pyref():
+    fb = extract_function(REF / "python/genvarloader/_dataset/_genotypes.py",
+                          "reconstruct_haplotype_from_sparse")
+    # cfg2-like: SNP only
+    rng = np.random.default_rng(20260802 + 2)
+    st = synth.make_static(rng, (200_000,), indel_frac=0.0)
+    bt = synth.make_batch(rng, st, 48, 2, 512)
+    save_pyref("cfg2_small", st, bt, *pyref_batch(fb, st, bt)[:1])
+    # cfg3-like: SNP + indel, RC on half, random shifts, some windows over contig edges
+    rng = np.random.default_rng(20260802 + 3)
+    st = synth.make_static(rng, (60_000, 90_000), indel_frac=0.15, density=1 / 60)
+    bt = synth.make_batch(rng, st, 64, 2, 509, rc_frac=0.5, random_shifts=True,
+                          edge_frac=0.15, permute_csr=True)
+    save_pyref("cfg3_small", st, bt, *pyref_batch(fb, st, bt)[:1])
+    # annotated, dense variants (many segments per row), keep mask
+    rng = np.random.default_rng(20260802 + 11)
+    st = synth.make_static(rng, (20_000,), indel_frac=0.4, density=1 / 6, af_beta=(2.0, 1.0))
+    bt = synth.make_batch(rng, st, 24, 2, 700, rc_frac=0.5, random_shifts=True, edge_frac=0.2)
+    idx = bt.geno_offset_idx.ravel()
+    n_per = bt.geno_offsets[1, idx] - bt.geno_offsets[0, idx]
+    bt.keep_offsets = np.concatenate([[0], np.cumsum(n_per)]).astype(np.int64)
+    bt.keep = rng.random(int(bt.keep_offsets[-1])) < 0.8
+    out, av, ap = pyref_batch(fb, st, bt, annotate=True)
+    save_pyref("dense_annot", st, bt, out, av, ap)
+
+
+if __name__ == "__main__":
+    convert_reference_goldens()
+    generate_pyref()

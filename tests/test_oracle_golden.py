@@ -1,0 +1,121 @@
+"""Pins the CPU oracle against the reference's own frozen goldens and against the
+reference's pure-numpy fallback (fixtures made by tests/golden/make_fixtures.py).
+
+Mirrors the reference's replays: tests/parity/test_reconstruct_haplotypes_parity.py:13-21,
+test_get_diffs_sparse_parity.py, test_get_reference_parity.py, test_rc_alleles_parity.py,
+test_choose_exonic_variants_parity.py, and test_rayon_equivalence.py:31-62
+(serial == parallel == golden).
+"""
+
+import numpy as np
+import pytest
+
+from tests._fixtures import load_pyref, load_ref_cases
+
+
+@pytest.mark.parametrize("parallel", [False, True])
+def test_reconstruct_haplotypes_from_sparse_golden(oracle, parallel):
+    cases = load_ref_cases("reconstruct_haplotypes_from_sparse")
+    assert len(cases) == 200
+    n_keep = n_shift = 0
+    for ci, (inp, exp) in enumerate(cases):
+        out = np.zeros(int(inp[0][-1]), np.uint8)
+        oracle.reconstruct_haplotypes_from_sparse(out, *inp, parallel=parallel, n_threads=4 if parallel else 1)
+        np.testing.assert_array_equal(out, exp, err_msg=f"case {ci}")
+        n_keep += inp[13] is not None
+        n_shift += bool(np.any(inp[2] != 0))
+    assert n_keep == 36 and n_shift == 48  # SURVEY 8(c) census of the golden file
+
+
+def test_get_diffs_sparse_golden(oracle):
+    cases = load_ref_cases("get_diffs_sparse")
+    assert len(cases) == 200
+    modes = {"plain": 0, "keep": 0, "query": 0, "query+keep": 0}
+    for ci, (inp, exp) in enumerate(cases):
+        for par in (False, True):
+            got = oracle.get_diffs_sparse(*inp, parallel=par, n_threads=3 if par else 1)
+            np.testing.assert_array_equal(got, exp, err_msg=f"case {ci}")
+        q = inp[6] is not None and inp[7] is not None and inp[8] is not None
+        k = inp[4] is not None and inp[5] is not None
+        modes["query+keep" if q and k else "query" if q else "keep" if k else "plain"] += 1
+    assert modes == {"plain": 131, "keep": 34, "query": 21, "query+keep": 14}
+
+
+def test_get_reference_golden(oracle):
+    cases = load_ref_cases("get_reference")
+    assert len(cases) == 200
+    for ci, (inp, exp) in enumerate(cases):
+        regions, out_offsets, reference, ref_offsets, pad_char, parallel = inp
+        got = oracle.get_reference(regions, out_offsets, reference, ref_offsets, pad_char,
+                                   bool(parallel), None, n_threads=3 if parallel else 1)
+        np.testing.assert_array_equal(got, exp, err_msg=f"case {ci}")
+
+
+def test_rc_alleles_golden_pins_rc_row(oracle):
+    """rc_alleles (variants/mod.rs:90-108) is rc_row applied to every allele of the
+    masked rows -- the same rc_row (reverse.rs:45-53) the haplotype path uses."""
+    cases = load_ref_cases("rc_alleles")
+    assert len(cases) == 200
+    for ci, (inp, exp) in enumerate(cases):
+        data, seq_offsets, var_offsets, mask = inp
+        buf = np.ascontiguousarray(data, np.uint8).copy()
+        per_allele = np.repeat(np.asarray(mask, bool), np.diff(var_offsets))
+        oracle.rc_flat_rows_inplace(buf, seq_offsets, per_allele)
+        np.testing.assert_array_equal(buf, exp, err_msg=f"case {ci}")
+
+
+def test_choose_exonic_variants_golden(oracle):
+    cases = load_ref_cases("choose_exonic_variants")
+    assert len(cases) == 200
+    for ci, (inp, exp) in enumerate(cases):
+        keep, ko = oracle.choose_exonic_variants(*inp)
+        np.testing.assert_array_equal(keep, exp[0], err_msg=f"case {ci}")
+        np.testing.assert_array_equal(ko, exp[1], err_msg=f"case {ci}")
+
+
+def _run_pyref(oracle, d, annotate=False, n_threads=1):
+    K = d["geno_offset_idx"].size
+    L = int(d["output_length"])
+    out_offsets = np.arange(K + 1, dtype=np.int64) * L
+    out = np.full(K * L, 0xFF, np.uint8)  # sentinel: every byte must be written
+    av = np.full(K * L, -7, np.int32) if annotate else None
+    ap = np.full(K * L, -7, np.int32) if annotate else None
+    oracle.reconstruct_haplotypes_from_sparse(
+        out, out_offsets, d["regions"], d["shifts"], d["geno_offset_idx"], d["geno_offsets"],
+        d["geno_v_idxs"], d["v_starts"], d["ilens"], d["alt_alleles"], d["alt_offsets"],
+        d["ref"], d["ref_offsets"], d["pad_char"], d["keep"], d["keep_offsets"], av, ap,
+        to_rc=d["to_rc"], n_threads=n_threads)
+    return out, av, ap
+
+
+@pytest.mark.parametrize("name", ["cfg2_small", "cfg3_small", "dense_annot"])
+def test_oracle_equals_reference_numpy_fallback(oracle, name):
+    d = load_pyref(name)
+    annotate = d["expected_annot_v_idxs"] is not None
+    for nt in (1, 4):
+        out, av, ap = _run_pyref(oracle, d, annotate, nt)
+        np.testing.assert_array_equal(out, d["expected"])
+        if annotate:
+            np.testing.assert_array_equal(av, d["expected_annot_v_idxs"])
+            np.testing.assert_array_equal(ap, d["expected_annot_ref_pos"])
+
+
+def test_fused_fixed_length_matches_unfused(oracle):
+    d = load_pyref("cfg3_small")
+    out, oo = oracle.reconstruct_haplotypes_fused(
+        d["regions"], d["shifts"], d["geno_offset_idx"], d["geno_offsets"], d["geno_v_idxs"],
+        d["v_starts"], d["ilens"], d["alt_alleles"], d["alt_offsets"], d["ref"],
+        d["ref_offsets"], d["pad_char"], d["output_length"], None, None, d["to_rc"], False)
+    np.testing.assert_array_equal(out, d["expected"])
+    np.testing.assert_array_equal(np.diff(oo), int(d["output_length"]))
+
+
+def test_onehot_definition(oracle):
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (3, 5, 97), dtype=np.uint8)
+    x[0, 0, :6] = np.frombuffer(b"ACGTNa", np.uint8)
+    lc = oracle.onehot(x, "lc")
+    np.testing.assert_array_equal(lc, oracle.onehot_numpy(x))
+    np.testing.assert_array_equal(lc[0, 0, :6], [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0],
+                                                 [0, 0, 0, 1], [0, 0, 0, 0], [0, 0, 0, 0]])
+    np.testing.assert_array_equal(oracle.onehot(x, "cl"), np.swapaxes(lc, -1, -2))
