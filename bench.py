@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- haplotype windows/sec + achieved HBM GB/s on MI355X.
+
+A "step" is one pass of the hot path over one synthetic batch: ONE launch of the
+fused reconstruct -> reverse-complement -> one-hot kernel through the C-ABI
+(``gvl_reconstruct``) with every input already resident in HBM.  The default
+workload is BASELINE.json ``configs[2]`` -- 4096 windows x 2048 bp, SNP+indel,
+reverse-complement on half the rows, uint8 one-hot output -- which is the
+configuration the metric is quoted on ("4096x2048bp SNP+indel one-hot");
+``--workload cfg2`` gives the SNP-only ``configs[1]``.
+
+    python bench.py --gpus N --steps K --warmup W
+
+For N > 1 the driver launches one rank per GPU (torch.distributed.run); rows are
+independent, so each rank processes its own 4096-window batch (weak scaling, no
+data-path collective) and ``value`` = windows all ranks processed / max-over-ranks time.
+Rank 0 prints ONE JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 measured copy ceiling
+
+
+def algorithmic_bytes_per_window(L: int, mean_variants: float, haps: bool, onehot: bool) -> float:
+    """L*(r + h + 4*o) + 28*V + 61 (r = 1 reference read)."""
+    return L * (1 + (1 if haps else 0) + (4 if onehot else 0)) + 28.0 * mean_variants + 61.0
+
+
+def cpu_baseline(st, bt, haps: bool, budget_s: float = 12.0) -> dict:
+    """The oracle (C restatement of the reference's Rust/rayon path: reconstruct ->
+    rc_flat_rows -> one-hot) timed on the host cores over the same batch."""
+    from oracle import oracle
+
+    try:  # the shipped .so is x86-64-v3; rebuild for this host's CPU when gcc is here
+        oracle.build(march="native")
+    except Exception:
+        pass
+    threads = oracle.default_threads()
+    K = bt.n_windows
+    L = bt.output_length
+    out = np.empty(K * L, np.uint8)
+    oh = np.empty((K * L, 4), np.uint8)
+    oo = np.arange(K + 1, dtype=np.int64) * L
+    go = np.ascontiguousarray(bt.geno_offsets)
+
+    def run():
+        oracle.reconstruct_haplotypes_from_sparse(
+            out, oo, bt.regions, bt.shifts, bt.geno_offset_idx, go, bt.geno_v_idxs, st.v_starts,
+            st.ilens, st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets, st.pad_char,
+            bt.keep, bt.keep_offsets, None, None, True, to_rc=bt.to_rc, onehot_out=oh,
+            n_threads=threads)
+
+    run()  # warm
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 3 or time.perf_counter() < t_end:
+        t0 = time.perf_counter()
+        run()
+        times.append(time.perf_counter() - t0)
+        if len(times) >= 2000:
+            break
+    med = float(np.median(times))
+    return {
+        "value": K / med, "unit": "windows/s", "cores": threads, "kind": "port",
+        "sample": f"full batch ({K} windows x {L} bp, reconstruct+RC+one-hot), "
+                  f"{len(times)} iterations over {sum(times):.1f} s, median",
+        "ms_per_batch": med * 1e3,
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg4"])
+    ap.add_argument("--haps", action="store_true", help="also materialise haplotype bytes (h=1)")
+    ap.add_argument("--contig", type=int, default=None, help="override reference contig length (bp)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--slots", type=int, default=2, help="output ring slots")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from genvarloader_amd import HapsDevice, synth
+
+    # ---- synthetic dataset + this rank's batch (rows shard across ranks) -------------
+    cfg_idx = int(args.workload[3:])
+    st, bt = synth.make_config(args.workload, seed=20260802 + cfg_idx + 1000 * rank, contig=args.contig)
+    K, L = bt.n_windows, bt.output_length
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=bt.geno_offsets,
+                     geno_v_idxs=bt.geno_v_idxs, pad_char=st.pad_char, device=f"cuda:{local_rank}")
+    dbt = dev.prepare_batch(bt.regions, bt.shifts, bt.geno_offset_idx, L, to_rc=bt.to_rc)
+    slots = [dev.alloc_output(dbt, K * L, haps=args.haps, onehot=True) for _ in range(max(1, args.slots))]
+    stream = torch.cuda.current_stream()
+
+    def step(i: int) -> None:
+        dev.launch(dbt, slots[i % len(slots)][1], stream)
+
+    def barrier() -> None:
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(args.steps):
+        step(i)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    torch.cuda.synchronize()
+
+    wall = t1 - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
+    if dist is not None:
+        tt = torch.tensor([wall, kern_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, kern_ms = float(tt[0]), float(tt[1])
+
+    if rank == 0:
+        abytes = algorithmic_bytes_per_window(L, bt.mean_variants, args.haps, True) * K
+        achieved = abytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tf = REPO / "profiles" / "traffic.json"
+        if tf.exists():
+            try:
+                traffic = json.loads(tf.read_text()).get(f"{args.workload}{'+haps' if args.haps else ''}")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "haplotype windows/sec", "value": world * K * args.steps / wall, "unit": "windows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: {K} windows x {L} bp per GPU, "
+                            + ("SNP+indel, reverse-complement on half the rows" if cfg_idx >= 3 else "SNP-only")
+                            + ", uint8 one-hot (K,L,4)" + (" + haplotype bytes" if args.haps else ""),
+                "windows_per_batch": K, "length_bp": L, "ploidy": 2,
+                "mean_variants_per_window": round(bt.mean_variants, 3),
+                "reference_bp": int(st.ref.size), "parallelism": f"rows sharded over {world} GPU(s)",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "reconstruct_kernel<false>", "kernel_ms": kern_ms,
+                "algorithmic_bytes_per_launch": abytes,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(st, bt, args.haps, args.cpu_budget)
+        print(json.dumps(res), flush=True)
+
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,116 @@
+"""ctypes binding of ``libgvl_hip.so`` (the C-ABI declared in ``include/gvl_hip.h``).
+
+This is the stub a GenVarLoader maintainer would add next to the PyO3 module
+(``/root/reference/python/genvarloader/_dataset/_haps.py:38-43`` imports the FFI
+symbols by name; INTEGRATION.md shows the swap).  There is no CPU fallback: if
+the HIP library is missing or fails to load, importing the compute entry points
+raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_NAME = "libgvl_hip.so"
+
+# every symbol include/gvl_hip.h declares (tests check the library exports them all)
+SYMBOLS = (
+    "gvl_abi_version",
+    "gvl_last_error",
+    "gvl_pack_variants",
+    "gvl_reconstruct",
+    "gvl_get_diffs_sparse",
+    "gvl_hap_offsets",
+    "gvl_get_reference",
+    "gvl_rc_rows",
+    "gvl_reverse_rows_4",
+    "gvl_onehot",
+)
+
+GVL_ONEHOT_LC = 0
+GVL_ONEHOT_CL = 1
+
+_vp = C.c_void_p
+_i64 = C.c_int64
+
+
+class GvlStatic(C.Structure):
+    _fields_ = [
+        ("ref", _vp), ("ref_len", _i64), ("ref_offsets", _vp), ("n_contigs", _i64),
+        ("v_starts", _vp), ("ilens", _vp), ("alt_offsets", _vp), ("alt_alleles", _vp),
+        ("n_variants", _i64), ("alt_len", _i64), ("vrec", _vp),
+        ("geno_o_starts", _vp), ("geno_o_stops", _vp), ("n_geno_offsets", _i64),
+        ("geno_v_idxs", _vp), ("n_geno", _i64), ("pad_char", C.c_uint8),
+    ]
+
+
+class GvlBatch(C.Structure):
+    _fields_ = [
+        ("regions", _vp), ("regions_stride", _i64), ("shifts", _vp), ("geno_offset_idx", _vp),
+        ("batch", _i64), ("ploidy", _i64), ("keep", _vp), ("keep_offsets", _vp), ("to_rc", _vp),
+        ("output_length", _i64), ("out_offsets", _vp), ("max_row_len", _i64),
+    ]
+
+
+class GvlOut(C.Structure):
+    _fields_ = [
+        ("haps", _vp), ("onehot", _vp), ("onehot_layout", C.c_int32),
+        ("annot_v_idxs", _vp), ("annot_ref_pos", _vp), ("out_offsets", _vp),
+    ]
+
+
+class GvlError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+
+def lib_path() -> Path:
+    return Path(os.environ.get("GVL_HIP_LIB", _HERE / LIB_NAME))
+
+
+def load() -> C.CDLL:
+    """Load the HIP library or raise -- never falls back to a CPU path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    # libgvl_hip.so links libamdhip64; PyTorch-ROCm bundles its own copy of that runtime.
+    # Import torch first so that the process has ONE HIP runtime (torch's) and device
+    # pointers / streams handed across the C-ABI belong to it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover - the C-ABI itself does not need torch
+        pass
+    p = lib_path()
+    if not p.exists():
+        raise GvlError(
+            f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  genvarloader_amd has no CPU fallback."
+        )
+    try:
+        lib = C.CDLL(str(p))
+    except OSError as e:  # pragma: no cover
+        raise GvlError(f"failed to load {p}: {e}") from e
+    lib.gvl_last_error.restype = C.c_char_p
+    lib.gvl_abi_version.restype = C.c_int
+    for name in SYMBOLS:
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise GvlError(f"{p} does not export {name}")
+        if name not in ("gvl_last_error",):
+            fn.restype = C.c_int
+    _LIB = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc == 0:
+        return
+    msg = load().gvl_last_error().decode(errors="replace")
+    if rc == 1:
+        raise ValueError(msg)
+    raise GvlError(msg)

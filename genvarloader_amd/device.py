@@ -1,0 +1,318 @@
+"""Device-resident side of the haplotype hot path.
+
+``HapsDevice`` keeps what the reference caches per dataset on the host --
+``_HapsFfiStatic`` (``_haps.py:233-247``: v_starts / ilens / alt_alleles /
+alt_offsets / ref / ref_offsets) plus the sparse-genotype CSR (``_haps.py:435-460``)
+-- resident in HBM, together with the packed 16-byte variant records the kernel
+reads.  Its methods take the per-batch arrays of ``ReconstructionRequest``
+(``_haps.py:58-93``) and launch the HIP kernels through the C-ABI on the current
+torch HIP stream; they never synchronise the host except where the reference's
+own return type forces it (ragged output needs the total length to allocate).
+
+PyTorch is only the plumbing here (device memory + streams); every pointer that
+crosses into ``libgvl_hip.so`` is a raw ``data_ptr()``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import GvlBatch, GvlOut, GvlStatic
+
+
+def _dev(x, dtype: torch.dtype, device) -> torch.Tensor | None:
+    """numpy / torch -> contiguous device tensor of `dtype` (no copy when already there)."""
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        t = x
+    else:
+        a = np.ascontiguousarray(x)
+        if a.dtype == np.bool_:
+            a = a.view(np.uint8)
+        t = torch.from_numpy(a)
+    if t.dtype == torch.bool:
+        t = t.view(torch.uint8) if t.is_contiguous() else t.contiguous().view(torch.uint8)
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    t = t.to(device, non_blocking=True)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t: torch.Tensor | None):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream_ptr(stream=None):
+    s = torch.cuda.current_stream() if stream is None else stream
+    return C.c_void_p(s.cuda_stream)
+
+
+def _starts_stops(geno_offsets):
+    """(n+1,) or (2, n) -> (2, n) int64, as ``_as_starts_stops`` (_genotypes.py:13-21)."""
+    if isinstance(geno_offsets, torch.Tensor):
+        o = geno_offsets
+        if o.dim() == 1:
+            return torch.stack([o[:-1], o[1:]]).to(torch.int64).contiguous()
+        return o.to(torch.int64).contiguous()
+    o = np.asarray(geno_offsets)
+    if o.ndim == 1:
+        return np.ascontiguousarray(np.stack([o[:-1], o[1:]]), dtype=np.int64)
+    return np.ascontiguousarray(o, dtype=np.int64)
+
+
+@dataclass
+class DeviceBatch:
+    """Per-batch arrays in HBM + the C struct that points at them."""
+
+    regions: torch.Tensor
+    shifts: torch.Tensor
+    geno_offset_idx: torch.Tensor
+    keep: torch.Tensor | None
+    keep_offsets: torch.Tensor | None
+    to_rc: torch.Tensor | None
+    out_offsets: torch.Tensor | None
+    output_length: int
+    max_row_len: int
+    c: GvlBatch
+
+    @property
+    def n_rows(self) -> int:
+        return int(self.geno_offset_idx.numel())
+
+
+@dataclass
+class ReconOutput:
+    haps: torch.Tensor | None
+    onehot: torch.Tensor | None
+    out_offsets: torch.Tensor | None
+    annot_v_idxs: torch.Tensor | None = None
+    annot_ref_pos: torch.Tensor | None = None
+
+
+class HapsDevice:
+    def __init__(self, *, ref, ref_offsets, v_starts, ilens, alt_alleles, alt_offsets,
+                 geno_offsets, geno_v_idxs, pad_char=ord("N"), device="cuda"):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.GvlError("genvarloader_amd needs a HIP device (no CPU fallback)")
+        self.device = torch.device(device)
+        d = self.device
+        self.ref = _dev(ref, torch.uint8, d)
+        self.ref_offsets = _dev(ref_offsets, torch.int64, d)
+        self.v_starts = _dev(v_starts, torch.int32, d)
+        self.ilens = _dev(ilens, torch.int32, d)
+        self.alt_alleles = _dev(alt_alleles, torch.uint8, d)
+        self.alt_offsets = _dev(alt_offsets, torch.int64, d)
+        go = _starts_stops(geno_offsets)
+        self.geno_offsets = _dev(go, torch.int64, d)
+        self.geno_v_idxs = _dev(geno_v_idxs, torch.int32, d)
+        self.pad_char = int(pad_char)
+        n_var = int(self.v_starts.numel())
+        if int(self.alt_offsets.numel()) != n_var + 1 or int(self.ilens.numel()) != n_var:
+            raise ValueError("variant table arrays disagree on n_variants")
+        # 16-byte packed records (gvl_pack_variants) -- built once per dataset
+        self.vrec = torch.empty((max(n_var, 1), 4), dtype=torch.int32, device=d)
+        with torch.cuda.device(d):
+            _lib.check(self.lib.gvl_pack_variants(
+                _ptr(self.v_starts), _ptr(self.ilens), _ptr(self.alt_offsets), _ptr(self.alt_alleles),
+                C.c_int64(n_var), _ptr(self.vrec), _stream_ptr()))
+        n_go = int(self.geno_offsets.shape[1])
+        self.c = GvlStatic(
+            ref=self.ref.data_ptr(), ref_len=self.ref.numel(),
+            ref_offsets=self.ref_offsets.data_ptr(), n_contigs=self.ref_offsets.numel() - 1,
+            v_starts=self.v_starts.data_ptr(), ilens=self.ilens.data_ptr(),
+            alt_offsets=self.alt_offsets.data_ptr(), alt_alleles=self.alt_alleles.data_ptr(),
+            n_variants=n_var, alt_len=self.alt_alleles.numel(), vrec=self.vrec.data_ptr(),
+            geno_o_starts=self.geno_offsets[0].data_ptr(), geno_o_stops=self.geno_offsets[1].data_ptr(),
+            n_geno_offsets=n_go, geno_v_idxs=self.geno_v_idxs.data_ptr(),
+            n_geno=self.geno_v_idxs.numel(), pad_char=self.pad_char,
+        )
+
+    # ------------------------------------------------------------------ batches
+    def prepare_batch(self, regions, shifts, geno_offset_idx, output_length, keep=None,
+                      keep_offsets=None, to_rc=None, out_offsets=None, max_row_len=None) -> DeviceBatch:
+        d = self.device
+        reg = _dev(regions, torch.int32, d)
+        goi = _dev(geno_offset_idx, torch.int64, d)
+        if reg.dim() != 2 or reg.shape[1] < 3:
+            raise ValueError("regions must be (batch, >=3) int32")
+        if goi.dim() != 2 or goi.shape[0] != reg.shape[0]:
+            raise ValueError("geno_offset_idx must be (batch, ploidy) int64")
+        sh = _dev(shifts, torch.int32, d)
+        if tuple(sh.shape) != tuple(goi.shape):
+            raise ValueError("shifts must be (batch, ploidy) int32")
+        kp = _dev(keep, torch.uint8, d)
+        ko = _dev(keep_offsets, torch.int64, d)
+        rc = _dev(to_rc, torch.uint8, d)
+        n_rows = int(goi.numel())
+        if rc is not None and rc.numel() != n_rows:
+            raise ValueError("to_rc must have batch*ploidy entries")
+        if ko is not None and ko.numel() != n_rows + 1:
+            raise ValueError("keep_offsets must have batch*ploidy + 1 entries")
+        oo = _dev(out_offsets, torch.int64, d)
+        if oo is not None and oo.numel() != n_rows + 1:
+            raise ValueError("out_offsets must have batch*ploidy + 1 entries")
+        output_length = int(output_length)
+        if oo is not None and max_row_len is None:
+            max_row_len = int((oo[1:] - oo[:-1]).max().item()) if n_rows else 0  # host sync
+        mrl = int(max_row_len) if max_row_len is not None else max(output_length, 0)
+        c = GvlBatch(
+            regions=reg.data_ptr(), regions_stride=reg.shape[1], shifts=sh.data_ptr(),
+            geno_offset_idx=goi.data_ptr(), batch=reg.shape[0], ploidy=goi.shape[1],
+            keep=None if kp is None else kp.data_ptr(),
+            keep_offsets=None if ko is None else ko.data_ptr(),
+            to_rc=None if rc is None else rc.data_ptr(), output_length=output_length,
+            out_offsets=None if oo is None else oo.data_ptr(), max_row_len=mrl,
+        )
+        return DeviceBatch(reg, sh, goi, kp, ko, rc, oo, output_length, mrl, c)
+
+    def hap_offsets(self, bt: DeviceBatch, want_diffs=False):
+        """Fused-entry sizing (ffi/mod.rs:769-811) on the device.
+        -> (out_offsets i64[K+1], total_and_max i64[2], diffs | None); no host sync."""
+        n = bt.n_rows
+        oo = torch.empty(n + 1, dtype=torch.int64, device=self.device)
+        tm = torch.empty(2, dtype=torch.int64, device=self.device)
+        diffs = torch.empty(tuple(bt.geno_offset_idx.shape), dtype=torch.int32, device=self.device) if want_diffs else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.gvl_hap_offsets(C.byref(self.c), C.byref(bt.c), _ptr(diffs), _ptr(oo),
+                                                _ptr(tm), _stream_ptr()))
+        return oo, tm, diffs
+
+    def get_diffs_sparse(self, geno_offset_idx, keep=None, keep_offsets=None, q_starts=None, q_ends=None):
+        """get_diffs_sparse (ffi/mod.rs:145-157) -> i32 (B, P) device tensor."""
+        d = self.device
+        goi = _dev(geno_offset_idx, torch.int64, d)
+        kp, ko = _dev(keep, torch.uint8, d), _dev(keep_offsets, torch.int64, d)
+        qs, qe = _dev(q_starts, torch.int32, d), _dev(q_ends, torch.int32, d)
+        c = GvlBatch(geno_offset_idx=goi.data_ptr(), batch=goi.shape[0], ploidy=goi.shape[1],
+                     keep=None if kp is None else kp.data_ptr(),
+                     keep_offsets=None if ko is None else ko.data_ptr())
+        diffs = torch.empty(tuple(goi.shape), dtype=torch.int32, device=d)
+        with torch.cuda.device(d):
+            _lib.check(self.lib.gvl_get_diffs_sparse(C.byref(self.c), C.byref(c), _ptr(qs), _ptr(qe),
+                                                     C.c_int64(1), _ptr(diffs), _stream_ptr()))
+        return diffs
+
+    # -------------------------------------------------------------- reconstruct
+    def alloc_output(self, bt: DeviceBatch, total: int, *, haps=True, onehot=False, layout="lc",
+                     annotate=False, write_offsets=True) -> tuple[ReconOutput, GvlOut]:
+        d = self.device
+        n = bt.n_rows
+        h = torch.empty(total, dtype=torch.uint8, device=d) if haps else None
+        if onehot:
+            if layout == "lc":
+                oh = torch.empty((total, 4), dtype=torch.uint8, device=d)
+            else:
+                if bt.output_length < 0 or bt.out_offsets is not None:
+                    raise ValueError("channel-major one-hot needs fixed-length rows")
+                oh = torch.empty((n, 4, bt.output_length), dtype=torch.uint8, device=d)
+        else:
+            oh = None
+        av = torch.empty(total, dtype=torch.int32, device=d) if annotate else None
+        ap = torch.empty(total, dtype=torch.int32, device=d) if annotate else None
+        oo = None
+        if write_offsets and bt.out_offsets is None:
+            oo = torch.empty(n + 1, dtype=torch.int64, device=d)
+        c = GvlOut(haps=None if h is None else h.data_ptr(),
+                   onehot=None if oh is None else oh.data_ptr(),
+                   onehot_layout=_lib.GVL_ONEHOT_LC if layout == "lc" else _lib.GVL_ONEHOT_CL,
+                   annot_v_idxs=None if av is None else av.data_ptr(),
+                   annot_ref_pos=None if ap is None else ap.data_ptr(),
+                   out_offsets=None if oo is None else oo.data_ptr())
+        return ReconOutput(h, oh, oo if oo is not None else bt.out_offsets, av, ap), c
+
+    def launch(self, bt: DeviceBatch, out_c: GvlOut, stream=None) -> None:
+        """One pass of the hot path over one batch: a single kernel launch."""
+        _lib.check(self.lib.gvl_reconstruct(C.byref(self.c), C.byref(bt.c), C.byref(out_c), _stream_ptr(stream)))
+
+    def reconstruct(self, regions, shifts, geno_offset_idx, output_length, keep=None, keep_offsets=None,
+                    to_rc=None, *, out_offsets=None, haps=True, onehot=False, layout="lc",
+                    annotate=False) -> ReconOutput:
+        """reconstruct_haplotypes_fused (ffi/mod.rs:722-860) on the device.
+        Fixed length: one launch, no host sync.  Ragged (output_length < 0): sizes on
+        the device, then one host read of {total, max} to allocate (the reference
+        returns an exactly-sized buffer, ffi/mod.rs:814-815)."""
+        with torch.cuda.device(self.device):
+            bt = self.prepare_batch(regions, shifts, geno_offset_idx, output_length, keep, keep_offsets,
+                                    to_rc, out_offsets)
+            n = bt.n_rows
+            if bt.out_offsets is not None:
+                total = int(bt.out_offsets[-1].item()) if n else 0
+            elif bt.output_length >= 0:
+                total = n * bt.output_length
+            else:
+                oo, tm, _ = self.hap_offsets(bt)
+                total, mx = (int(v) for v in tm.cpu().tolist())  # host sync (allocation size)
+                bt = self.prepare_batch(bt.regions, bt.shifts, bt.geno_offset_idx, bt.output_length,
+                                        bt.keep, bt.keep_offsets, bt.to_rc, oo, max_row_len=mx)
+            out, out_c = self.alloc_output(bt, total, haps=haps, onehot=onehot, layout=layout,
+                                           annotate=annotate)
+            if n == 0 or total == 0:
+                if bt.out_offsets is None:
+                    out.out_offsets.zero_()
+                return out
+            self.launch(bt, out_c)
+            out._keepalive = bt  # batch tensors must outlive the async launch
+            return out
+
+    # ------------------------------------------------------------ reference / rc
+    def get_reference(self, regions, out_offsets, to_rc=None, *, onehot=False, max_row_len=None):
+        """get_reference (ffi/mod.rs:2401-2429) -> u8[total] (and (total, 4) one-hot)."""
+        d = self.device
+        with torch.cuda.device(d):
+            reg = _dev(regions, torch.int32, d)
+            oo = _dev(out_offsets, torch.int64, d)
+            rc = _dev(to_rc, torch.uint8, d)
+            n = int(reg.shape[0])
+            total = int(oo[-1].item()) if n else 0
+            if max_row_len is None:
+                max_row_len = int((oo[1:] - oo[:-1]).max().item()) if n else 0
+            out = torch.empty(total, dtype=torch.uint8, device=d)
+            oh = torch.empty((total, 4), dtype=torch.uint8, device=d) if onehot else None
+            if total == 0:
+                return (out, oh) if onehot else out
+            _lib.check(self.lib.gvl_get_reference(C.byref(self.c), _ptr(reg), C.c_int64(reg.shape[1]),
+                                                  C.c_int64(n), _ptr(oo), C.c_int64(max_row_len), _ptr(rc),
+                                                  _ptr(out), _ptr(oh), _stream_ptr()))
+            return (out, oh) if onehot else out
+
+
+def rc_flat_rows_inplace(data: torch.Tensor, offsets, to_rc) -> None:
+    """rc_flat_rows_inplace (reverse.rs:56-69) on a device u8 tensor."""
+    lib = _lib.load()
+    d = data.device
+    oo, rc = _dev(offsets, torch.int64, d), _dev(to_rc, torch.uint8, d)
+    assert data.dtype == torch.uint8 and data.is_contiguous()
+    if data.numel() == 0 or rc.numel() == 0:
+        return
+    with torch.cuda.device(d):
+        _lib.check(lib.gvl_rc_rows(_ptr(data), _ptr(oo), _ptr(rc), C.c_int64(rc.numel()), _stream_ptr()))
+
+
+def reverse_flat_rows_inplace(data: torch.Tensor, offsets, to_rc) -> None:
+    """reverse_flat_rows_inplace<T> (reverse.rs:25-38) for 4-byte elements."""
+    lib = _lib.load()
+    d = data.device
+    oo, rc = _dev(offsets, torch.int64, d), _dev(to_rc, torch.uint8, d)
+    assert data.element_size() == 4 and data.is_contiguous()
+    if data.numel() == 0 or rc.numel() == 0:
+        return
+    with torch.cuda.device(d):
+        _lib.check(lib.gvl_reverse_rows_4(_ptr(data), _ptr(oo), _ptr(rc), C.c_int64(rc.numel()), _stream_ptr()))
+
+
+def onehot(x: torch.Tensor) -> torch.Tensor:
+    """Stand-alone one-hot (a10): u8 (...,) -> u8 (..., 4)."""
+    lib = _lib.load()
+    assert x.dtype == torch.uint8 and x.is_cuda
+    x = x.contiguous()
+    out = torch.empty(tuple(x.shape) + (4,), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.gvl_onehot(_ptr(x), C.c_int64(x.numel()), _ptr(out), _stream_ptr()))
+    return out

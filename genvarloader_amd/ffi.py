@@ -1,0 +1,228 @@
+"""Drop-in mirror of the reference's FFI entry points for the haplotype path.
+
+Same names, argument order, argument meaning and return shapes as the PyO3
+functions the reference's callers import by name (``_haps.py:38-43``,
+``_genotypes.py:5-9``, ``_reference.py:26``):
+
+===========================================  ===================================
+here                                          reference
+===========================================  ===================================
+``reconstruct_haplotypes_fused``              ``src/ffi/mod.rs:722-860``
+``reconstruct_haplotypes_from_sparse``        ``src/ffi/mod.rs:632-700`` (in place)
+``reconstruct_haplotypes_spliced_fused``      ``src/ffi/mod.rs:1981-2076``
+``reconstruct_annotated_haplotypes_fused``    ``src/ffi/mod.rs:2237-2397``
+``get_diffs_sparse``                          ``src/ffi/mod.rs:143-185``
+``get_reference``                             ``src/ffi/mod.rs:2401-2429``
+``reconstruct_haplotypes_fused_onehot``       new: fused one-hot (no counterpart;
+                                              replaces the user-side ``sp.DNA.ohe``)
+===========================================  ===================================
+
+numpy in -> numpy out (so a caller that swaps its import keeps working); the
+per-dataset arrays (reference, variant table, genotype CSR) are uploaded to HBM
+once and cached keyed by their host buffers, the way ``_HapsFfiStatic`` caches
+contiguous views on the host (``_haps.py:329-348``).  ``parallel`` is accepted and
+ignored (``_threads.py:122-127`` gates rayon; the GPU path is always parallel).
+Callers that want to stay on the device use :class:`genvarloader_amd.HapsDevice`.
+
+Errors: bad dtype/shape -> ``ValueError`` (the reference panics,
+``ffi/mod.rs:56-76``); HIP failures -> ``GvlError``; no CPU fallback.
+"""
+
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .device import HapsDevice, _starts_stops
+
+_STATIC_CACHE: "OrderedDict[tuple, HapsDevice]" = OrderedDict()
+_STATIC_CACHE_MAX = 4
+
+
+def _key(a):
+    a = np.asarray(a)
+    return (a.__array_interface__["data"][0], a.shape, a.dtype.str)
+
+
+def _req(a, dt, name, ndim=None):
+    """The reference asserts exact dtype + C-contiguity for the big arrays
+    (``_ffi_array``, _dataset/_utils.py:13-34); small ones are coerced."""
+    a = np.ascontiguousarray(a, dtype=dt)
+    if ndim is not None and a.ndim != ndim:
+        raise ValueError(f"`{name}` must be {ndim}-D")
+    return a
+
+
+def _static(geno_offsets, geno_v_idxs, v_starts, ilens, alt_alleles, alt_offsets, ref_, ref_offsets,
+            pad_char, device="cuda") -> HapsDevice:
+    # np.asarray is the identity for ndarrays; anything else becomes an array we keep
+    # alive in the cache entry, so an address-based key can never alias a dead buffer
+    arrs = tuple(np.asarray(a) for a in (geno_offsets, geno_v_idxs, v_starts, ilens, alt_alleles,
+                                         alt_offsets, ref_, ref_offsets))
+    geno_offsets, geno_v_idxs, v_starts, ilens, alt_alleles, alt_offsets, ref_, ref_offsets = arrs
+    key = tuple(_key(a) for a in arrs) + (int(pad_char), str(device))
+    dev = _STATIC_CACHE.get(key)
+    if dev is None:
+        dev = HapsDevice(
+            ref=_req(ref_, np.uint8, "ref_", 1), ref_offsets=_req(ref_offsets, np.int64, "ref_offsets", 1),
+            v_starts=_req(v_starts, np.int32, "v_starts", 1), ilens=_req(ilens, np.int32, "ilens", 1),
+            alt_alleles=_req(alt_alleles, np.uint8, "alt_alleles", 1),
+            alt_offsets=_req(alt_offsets, np.int64, "alt_offsets", 1),
+            geno_offsets=_starts_stops(geno_offsets), geno_v_idxs=_req(geno_v_idxs, np.int32, "geno_v_idxs", 1),
+            pad_char=int(pad_char), device=device)
+        # keep the host arrays alive so that the address-based key stays valid
+        dev._host_refs = arrs
+        _STATIC_CACHE[key] = dev
+        while len(_STATIC_CACHE) > _STATIC_CACHE_MAX:
+            _STATIC_CACHE.popitem(last=False)
+    else:
+        _STATIC_CACHE.move_to_end(key)
+    return dev
+
+
+def clear_static_cache() -> None:
+    _STATIC_CACHE.clear()
+
+
+def _np(t):
+    return None if t is None else t.cpu().numpy()
+
+
+def reconstruct_haplotypes_fused(
+    regions, shifts, geno_offset_idx, geno_offsets, geno_v_idxs, v_starts, ilens, alt_alleles,
+    alt_offsets, ref_, ref_offsets, pad_char, output_length, keep=None, keep_offsets=None,
+    to_rc=None, parallel=False,
+):
+    """-> (out_data u8[total], out_offsets i64[K+1])   (ffi/mod.rs:743)."""
+    dev = _static(geno_offsets, geno_v_idxs, v_starts, ilens, alt_alleles, alt_offsets, ref_,
+                  ref_offsets, pad_char)
+    out = dev.reconstruct(regions, shifts, geno_offset_idx, int(output_length), keep, keep_offsets, to_rc)
+    return _np(out.haps), _np(out.out_offsets)
+
+
+def reconstruct_haplotypes_fused_onehot(
+    regions, shifts, geno_offset_idx, geno_offsets, geno_v_idxs, v_starts, ilens, alt_alleles,
+    alt_offsets, ref_, ref_offsets, pad_char, output_length, keep=None, keep_offsets=None,
+    to_rc=None, parallel=False, *, layout="lc", return_haps=False,
+):
+    """Fused one-hot variant: -> (onehot u8 (total, 4) | (K, 4, L), out_offsets[, haps])."""
+    dev = _static(geno_offsets, geno_v_idxs, v_starts, ilens, alt_alleles, alt_offsets, ref_,
+                  ref_offsets, pad_char)
+    out = dev.reconstruct(regions, shifts, geno_offset_idx, int(output_length), keep, keep_offsets, to_rc,
+                          haps=return_haps, onehot=True, layout=layout)
+    if return_haps:
+        return _np(out.onehot), _np(out.out_offsets), _np(out.haps)
+    return _np(out.onehot), _np(out.out_offsets)
+
+
+def reconstruct_haplotypes_from_sparse(
+    out, out_offsets, regions, shifts, geno_offset_idx, geno_offsets, geno_v_idxs, v_starts, ilens,
+    alt_alleles, alt_offsets, ref, ref_offsets, pad_char, keep=None, keep_offsets=None,
+    annot_v_idxs=None, annot_ref_pos=None, parallel=False,
+):
+    """In place (ffi/mod.rs:634-655): writes `out` (and the annotation buffers)."""
+    if not (isinstance(out, np.ndarray) and out.dtype == np.uint8 and out.flags.c_contiguous):
+        raise ValueError("`out` must be a C-contiguous uint8 array")
+    dev = _static(geno_offsets, geno_v_idxs, v_starts, ilens, alt_alleles, alt_offsets, ref,
+                  ref_offsets, pad_char)
+    annotate = annot_v_idxs is not None or annot_ref_pos is not None
+    oo = _req(out_offsets, np.int64, "out_offsets", 1)
+    if len(oo) and int(oo[-1]) != out.size:
+        raise ValueError("out_offsets[-1] must equal len(out)")
+    res = dev.reconstruct(regions, shifts, geno_offset_idx, -1, keep, keep_offsets, None,
+                          out_offsets=oo, annotate=annotate)
+    out[...] = _np(res.haps)
+    if annot_v_idxs is not None:
+        annot_v_idxs[...] = _np(res.annot_v_idxs)
+    if annot_ref_pos is not None:
+        annot_ref_pos[...] = _np(res.annot_ref_pos)
+
+
+def reconstruct_haplotypes_spliced_fused(
+    permuted_regions, flat_shifts, flat_geno_offset_idx, out_offsets, geno_offsets, geno_v_idxs,
+    v_starts, ilens, alt_alleles, alt_offsets, ref_, ref_offsets, pad_char, keep=None,
+    keep_offsets=None, to_rc=None, parallel=False,
+):
+    """Caller-supplied (permuted) out_offsets, ploidy-1 rows (ffi/mod.rs:1983-2002) -> u8[total]."""
+    dev = _static(geno_offsets, geno_v_idxs, v_starts, ilens, alt_alleles, alt_offsets, ref_,
+                  ref_offsets, pad_char)
+    res = dev.reconstruct(permuted_regions, flat_shifts, flat_geno_offset_idx, -1, keep, keep_offsets,
+                          to_rc, out_offsets=_req(out_offsets, np.int64, "out_offsets", 1))
+    return _np(res.haps)
+
+
+def reconstruct_annotated_haplotypes_fused(
+    regions, shifts, geno_offset_idx, geno_offsets, geno_v_idxs, v_starts, ilens, alt_alleles,
+    alt_offsets, ref_, ref_offsets, pad_char, output_length, keep=None, keep_offsets=None,
+    to_rc=None, parallel=False,
+):
+    """-> (out_data, annot_v_idxs, annot_ref_pos, out_offsets)   (ffi/mod.rs:2237-2397)."""
+    dev = _static(geno_offsets, geno_v_idxs, v_starts, ilens, alt_alleles, alt_offsets, ref_,
+                  ref_offsets, pad_char)
+    out = dev.reconstruct(regions, shifts, geno_offset_idx, int(output_length), keep, keep_offsets, to_rc,
+                          annotate=True)
+    return _np(out.haps), _np(out.annot_v_idxs), _np(out.annot_ref_pos), _np(out.out_offsets)
+
+
+def get_diffs_sparse(geno_offset_idx, geno_v_idxs, geno_offsets, ilens, keep=None, keep_offsets=None,
+                     q_starts=None, q_ends=None, v_starts=None, parallel=False):
+    """-> i32 (B, P)   (ffi/mod.rs:145-157).  Query mode iff q_starts, q_ends, v_starts given."""
+    ilens = _req(ilens, np.int32, "ilens", 1)
+    n_var = len(ilens)
+    has_query = q_starts is not None and q_ends is not None and v_starts is not None
+    vs = _req(v_starts, np.int32, "v_starts", 1) if has_query else np.zeros(n_var, np.int32)
+    # diffs only read the CSR + ilens/v_starts: a stub reference/allele table is enough
+    dev = _diffs_static(geno_offsets, geno_v_idxs, vs, ilens)
+    d = dev.get_diffs_sparse(geno_offset_idx, keep, keep_offsets,
+                             q_starts if has_query else None, q_ends if has_query else None)
+    return _np(d)
+
+
+_DIFF_CACHE: "OrderedDict[tuple, HapsDevice]" = OrderedDict()
+
+
+def _diffs_static(geno_offsets, geno_v_idxs, v_starts, ilens) -> HapsDevice:
+    arrs = tuple(np.asarray(a) for a in (geno_offsets, geno_v_idxs, v_starts, ilens))
+    geno_offsets, geno_v_idxs, v_starts, ilens = arrs
+    key = tuple(_key(a) for a in arrs)
+    dev = _DIFF_CACHE.get(key)
+    if dev is None:
+        n = len(ilens)
+        dev = HapsDevice(ref=np.zeros(1, np.uint8), ref_offsets=np.array([0, 1], np.int64),
+                         v_starts=v_starts, ilens=ilens, alt_alleles=np.zeros(1, np.uint8),
+                         alt_offsets=np.zeros(n + 1, np.int64), geno_offsets=_starts_stops(geno_offsets),
+                         geno_v_idxs=_req(geno_v_idxs, np.int32, "geno_v_idxs", 1))
+        dev._host_refs = arrs
+        _DIFF_CACHE[key] = dev
+        while len(_DIFF_CACHE) > _STATIC_CACHE_MAX:
+            _DIFF_CACHE.popitem(last=False)
+    return dev
+
+
+def get_reference(regions, out_offsets, reference, ref_offsets, pad_char, parallel=False, to_rc=None):
+    """-> u8[total]   (ffi/mod.rs:2402-2411)."""
+    dev = _ref_static(reference, ref_offsets, pad_char)
+    return _np(dev.get_reference(regions, _req(out_offsets, np.int64, "out_offsets", 1), to_rc))
+
+
+_REF_CACHE: "OrderedDict[tuple, HapsDevice]" = OrderedDict()
+
+
+def _ref_static(reference, ref_offsets, pad_char) -> HapsDevice:
+    reference, ref_offsets = np.asarray(reference), np.asarray(ref_offsets)
+    key = (_key(reference), _key(ref_offsets), int(pad_char))
+    dev = _REF_CACHE.get(key)
+    if dev is None:
+        dev = HapsDevice(ref=_req(reference, np.uint8, "reference", 1),
+                         ref_offsets=_req(ref_offsets, np.int64, "ref_offsets", 1),
+                         v_starts=np.zeros(0, np.int32), ilens=np.zeros(0, np.int32),
+                         alt_alleles=np.zeros(0, np.uint8), alt_offsets=np.zeros(1, np.int64),
+                         geno_offsets=np.zeros((2, 1), np.int64), geno_v_idxs=np.zeros(0, np.int32),
+                         pad_char=int(pad_char))
+        dev._host_refs = (reference, ref_offsets)
+        _REF_CACHE[key] = dev
+        while len(_REF_CACHE) > _STATIC_CACHE_MAX:
+            _REF_CACHE.popitem(last=False)
+    return dev

@@ -1,0 +1,184 @@
+/*
+ * gvl_hip.h -- C-ABI of the MI355X (gfx950) haplotype hot path.
+ *
+ * This is the drop-in boundary: the entry points below are what GenVarLoader's
+ * FFI for haplotype reconstruction would bind (the reference binds a PyO3
+ * module, `src/ffi/mod.rs`; INTEGRATION.md shows the ctypes stub a maintainer
+ * would add).  Plain pointers and sizes only -- no torch / numpy types.
+ *
+ * Conventions
+ *  - Every data pointer is a DEVICE pointer (HBM) unless it says "host".
+ *  - Array dtypes/layouts are exactly the reference's FFI layouts
+ *    (python/genvarloader/_dataset/_haps.py:844-866): regions i32 (B, stride>=3)
+ *    [contig, start, end, ...], shifts i32 (B, P), geno_offset_idx i64 (B, P),
+ *    geno offsets as two i64 rows (starts, stops), geno_v_idxs i32, variant table
+ *    v_starts/ilens i32, alt_alleles u8 + alt_offsets i64 (n_variants + 1),
+ *    ref u8 + ref_offsets i64 (n_contigs + 1), keep u8(bool) + keep_offsets i64
+ *    (B*P + 1), to_rc u8(bool) (B*P).
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
+ *    calls are asynchronous on that stream and never synchronise the host.
+ *  - Return value 0 = ok; otherwise an error code, with a message available from
+ *    gvl_last_error() (thread local).  HIP launch failures are reported, not
+ *    swallowed; there is no CPU fallback anywhere in this library.
+ */
+#ifndef GVL_HIP_H
+#define GVL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GVL_ABI_VERSION 1
+
+enum {
+    GVL_OK = 0,
+    GVL_ERR_INVALID = 1, /* bad argument (NULL pointer, negative size, ...) */
+    GVL_ERR_HIP = 2,     /* a HIP runtime call / kernel launch failed */
+    GVL_ERR_UNSUPPORTED = 3
+};
+
+/* one-hot layouts (a10; the reference delegates one-hot to seqpro.DNA.ohe,
+ * docs/source/index.md:109-119 -- alphabet "ACGT", non-alphabet -> all zero) */
+enum {
+    GVL_ONEHOT_LC = 0, /* (total_bases, 4): base-major, what sp.DNA.ohe returns */
+    GVL_ONEHOT_CL = 1  /* (rows, 4, L): channel-major; fixed-length rows only   */
+};
+
+/* 16-byte packed variant record, built once per dataset by gvl_pack_variants()
+ * from v_starts / ilens / alt_offsets / alt_alleles so that the kernel needs one
+ * 16-B gather per variant instead of four dependent ones. */
+typedef struct gvl_vrec {
+    int32_t pos;     /* v_starts[v]                                        */
+    int32_t ilen;    /* ilens[v]                                           */
+    int32_t alen;    /* alt_offsets[v+1] - alt_offsets[v]                  */
+    uint32_t inl;    /* first 4 ALT bytes, little endian (zero padded)     */
+} gvl_vrec;
+
+/* Per-dataset, device-resident arrays.  Mirrors `_HapsFfiStatic`
+ * (_haps.py:233-247) + `Reference` (_reference.py:31-50) + the sparse genotype
+ * CSR (`genotypes/offsets.npy`, `variant_idxs.npy`). */
+typedef struct gvl_static {
+    const uint8_t *ref;          /* packed contigs                          */
+    int64_t ref_len;             /* bytes in `ref`                          */
+    const int64_t *ref_offsets;  /* n_contigs + 1                           */
+    int64_t n_contigs;
+    const int32_t *v_starts;     /* n_variants                              */
+    const int32_t *ilens;        /* n_variants                              */
+    const int64_t *alt_offsets;  /* n_variants + 1                          */
+    const uint8_t *alt_alleles;  /* alt_len bytes                           */
+    int64_t n_variants;
+    int64_t alt_len;
+    const gvl_vrec *vrec;        /* n_variants, from gvl_pack_variants()    */
+    const int64_t *geno_o_starts; /* n_geno_offsets: row 0 of the (2, n) array */
+    const int64_t *geno_o_stops;  /* n_geno_offsets: row 1                     */
+    int64_t n_geno_offsets;
+    const int32_t *geno_v_idxs;  /* n_geno                                  */
+    int64_t n_geno;
+    uint8_t pad_char;
+} gvl_static;
+
+/* Per-batch arrays.  Mirrors `ReconstructionRequest` (_haps.py:58-93) as
+ * marshalled at the fused call site (_haps.py:844-866). */
+typedef struct gvl_batch {
+    const int32_t *regions;        /* (batch, regions_stride) */
+    int64_t regions_stride;        /* >= 3 (runtime arrays are (B, 4)) */
+    const int32_t *shifts;         /* (batch, ploidy) */
+    const int64_t *geno_offset_idx; /* (batch, ploidy) */
+    int64_t batch;
+    int64_t ploidy;
+    const uint8_t *keep;           /* nullable */
+    const int64_t *keep_offsets;   /* nullable; batch*ploidy + 1 */
+    const uint8_t *to_rc;          /* nullable; batch*ploidy */
+    int64_t output_length;         /* >= 0 fixed length; -1 ragged */
+    const int64_t *out_offsets;    /* batch*ploidy + 1.  Required when
+                                      output_length < 0 (from gvl_hap_offsets or the
+                                      caller's splice plan, ffi/mod.rs:1983-2002);
+                                      NULL in fixed mode means row k starts at
+                                      k * output_length. */
+    int64_t max_row_len;           /* host hint: upper bound of any row's length
+                                      (fixed mode: ignored, output_length is used) */
+} gvl_batch;
+
+/* Outputs; any of the data pointers may be NULL (that output is skipped), but
+ * at least one of haps / onehot must be given. */
+typedef struct gvl_out {
+    uint8_t *haps;          /* total bytes (= out_offsets[-1]) */
+    uint8_t *onehot;        /* 4 * total bytes */
+    int32_t onehot_layout;  /* GVL_ONEHOT_LC / GVL_ONEHOT_CL */
+    int32_t *annot_v_idxs;  /* total i32, nullable (a11) */
+    int32_t *annot_ref_pos; /* total i32, nullable (a11) */
+    int64_t *out_offsets;   /* nullable: fixed mode writes k*output_length here
+                               (batch*ploidy + 1), the second return value of
+                               reconstruct_haplotypes_fused (ffi/mod.rs:743) */
+} gvl_out;
+
+int gvl_abi_version(void);
+const char *gvl_last_error(void);
+
+/* Build the packed variant records (once per dataset).
+ * Replaces nothing in the reference; it is the HBM layout this path reads
+ * instead of the four gathers at src/reconstruct/mod.rs:296-305. */
+int gvl_pack_variants(const int32_t *v_starts, const int32_t *ilens,
+                      const int64_t *alt_offsets, const uint8_t *alt_alleles,
+                      int64_t n_variants, gvl_vrec *vrec_out, void *stream);
+
+/* Haplotype reconstruction (+RC, +one-hot, +annotations) for a batch.
+ * Replaces: reconstruct_haplotypes_fused (src/ffi/mod.rs:722-860) steps 3-4b,
+ *   reconstruct_haplotypes_from_sparse (src/ffi/mod.rs:632-700; in place when
+ *   batch->out_offsets is given), reconstruct_haplotypes_spliced_fused
+ *   (src/ffi/mod.rs:1981-2076; caller-supplied out_offsets, ploidy 1),
+ *   reconstruct_annotated_haplotypes_fused (src/ffi/mod.rs:2237-2397),
+ *   rc_flat_rows_inplace on the result (src/reverse.rs:56-69), and the user-side
+ *   seqpro one-hot (docs/source/index.md:109-119). */
+int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *out,
+                    void *stream);
+
+/* Per-row length deltas.  Replaces get_diffs_sparse (src/ffi/mod.rs:143-185 ->
+ * src/genotypes/mod.rs:15-125).  Query mode iff q_starts, q_ends and st->v_starts
+ * are all non-NULL (q_* are read at q_stride elements per query, so
+ * regions+1 / regions+2 with stride 4 works); keep mode iff bt->keep and
+ * bt->keep_offsets are non-NULL.  Only bt->geno_offset_idx/batch/ploidy/keep* are
+ * read from `bt`.  diffs: i32 (batch, ploidy). */
+int gvl_get_diffs_sparse(const gvl_static *st, const gvl_batch *bt,
+                         const int32_t *q_starts, const int32_t *q_ends,
+                         int64_t q_stride, int32_t *diffs, void *stream);
+
+/* Output sizing of the fused entry: diffs in query mode on regions[:,1:3], then
+ * len_k = output_length >= 0 ? output_length : max(0, end - start + diff_k) and
+ * its exclusive prefix sum.  Replaces src/ffi/mod.rs:769-811.
+ * diffs (nullable) i32 (batch, ploidy); out_offsets i64 (batch*ploidy + 1);
+ * total_and_max (nullable) i64[2] <- {out_offsets[-1], max row length}. */
+int gvl_hap_offsets(const gvl_static *st, const gvl_batch *bt, int32_t *diffs,
+                    int64_t *out_offsets, int64_t *total_and_max, void *stream);
+
+/* Padded reference fetch (+RC, +one-hot).  Replaces get_reference
+ * (src/ffi/mod.rs:2401-2429 -> src/reference/mod.rs:56-120).  Only st->ref,
+ * ref_len, ref_offsets, n_contigs, pad_char are read.  Row i has length
+ * out_offsets[i+1]-out_offsets[i] (the caller passes end - start). */
+int gvl_get_reference(const gvl_static *st, const int32_t *regions,
+                      int64_t regions_stride, int64_t n_rows,
+                      const int64_t *out_offsets, int64_t max_row_len,
+                      const uint8_t *to_rc, uint8_t *out, uint8_t *onehot,
+                      void *stream);
+
+/* In-place reverse-complement of masked rows.  Replaces rc_flat_rows_inplace
+ * (src/reverse.rs:56-69; COMP semantics :9-21,:45-53). */
+int gvl_rc_rows(uint8_t *data, const int64_t *offsets, const uint8_t *to_rc,
+                int64_t n_rows, void *stream);
+
+/* In-place reversal (no complement) of masked rows of 4-byte elements (f32
+ * tracks / i32 annotations).  Replaces reverse_flat_rows_inplace<T>
+ * (src/reverse.rs:25-38). */
+int gvl_reverse_rows_4(void *data, const int64_t *offsets, const uint8_t *to_rc,
+                       int64_t n_rows, void *stream);
+
+/* Stand-alone one-hot of n bytes -> (n, 4) uint8 (GVL_ONEHOT_LC).  Replaces the
+ * user-side sp.DNA.ohe(haps) (docs/source/index.md:114). */
+int gvl_onehot(const uint8_t *in, int64_t n, uint8_t *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GVL_HIP_H */

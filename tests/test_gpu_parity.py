@@ -1,0 +1,374 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI
+(``genvarloader_amd`` -> ``libgvl_hip.so``), against the CPU oracle on the same inputs,
+against the committed golden fixtures, and -- at BASELINE.json's full sizes -- through
+size-independent properties.  Bit-exact everywhere (integer / byte work).
+
+Run with ``pytest -m gpu`` on an MI355X box.
+"""
+
+import numpy as np
+import pytest
+
+from tests._fixtures import load_pyref, load_ref_cases
+from tests.test_oracle_kats import RC_KATS, ROW_KATS, S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+
+    from genvarloader_amd import _lib
+
+    if not torch.cuda.is_available():
+        pytest.fail("gpu tests need a HIP device (no CPU fallback exists)")
+    _lib.load()  # fail loudly when the HIP library is missing
+    import genvarloader_amd.device as device
+    import genvarloader_amd.ffi as ffi
+
+    class G:
+        pass
+
+    g = G()
+    g.torch, g.ffi, g.device = torch, ffi, device
+    return g
+
+
+def make_dev(g, st, bt):
+    return g.device.HapsDevice(
+        ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+        alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=bt.geno_offsets,
+        geno_v_idxs=bt.geno_v_idxs, pad_char=st.pad_char)
+
+
+def oracle_fused(oracle, st, bt, onehot=False, annotate=False, n_threads=8):
+    args = (bt.regions, bt.shifts, bt.geno_offset_idx, bt.geno_offsets, bt.geno_v_idxs, st.v_starts,
+            st.ilens, st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets, st.pad_char,
+            bt.output_length, bt.keep, bt.keep_offsets, bt.to_rc, True)
+    if annotate:
+        return oracle.reconstruct_annotated_haplotypes_fused(*args, n_threads=n_threads)
+    return oracle.reconstruct_haplotypes_fused(*args, onehot=onehot, n_threads=n_threads)
+
+
+def check_batch(g, oracle, st, bt, layout="lc", annotate=False):
+    """HIP vs oracle: hap bytes, offsets, one-hot (and annotations)."""
+    dev = make_dev(g, st, bt)
+    out = dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, bt.output_length, bt.keep,
+                          bt.keep_offsets, bt.to_rc, haps=True, onehot=True, layout=layout,
+                          annotate=annotate)
+    g.torch.cuda.synchronize()
+    exp, exp_off, exp_oh = oracle_fused(oracle, st, bt, onehot=True)
+    np.testing.assert_array_equal(out.out_offsets.cpu().numpy(), exp_off)
+    np.testing.assert_array_equal(out.haps.cpu().numpy(), exp)
+    oh = out.onehot.cpu().numpy()
+    if layout == "lc":
+        np.testing.assert_array_equal(oh, exp_oh)
+    else:
+        K = bt.n_windows
+        np.testing.assert_array_equal(oh, exp_oh.reshape(K, bt.output_length, 4).transpose(0, 2, 1))
+    if annotate:
+        _, av, ap, _ = oracle_fused(oracle, st, bt, annotate=True)
+        np.testing.assert_array_equal(out.annot_v_idxs.cpu().numpy(), av)
+        np.testing.assert_array_equal(out.annot_ref_pos.cpu().numpy(), ap)
+    # one-hot only (no hap buffer) must give the same one-hot
+    out2 = dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, bt.output_length, bt.keep,
+                           bt.keep_offsets, bt.to_rc, haps=False, onehot=True, layout=layout)
+    np.testing.assert_array_equal(out2.onehot.cpu().numpy(), oh)
+    return out
+
+
+# ------------------------------------------------------------------ reference goldens
+def test_golden_reconstruct_haplotypes_from_sparse(gpu):
+    cases = load_ref_cases("reconstruct_haplotypes_from_sparse")
+    assert len(cases) == 200
+    for ci, (inp, exp) in enumerate(cases):
+        out = np.full(int(inp[0][-1]), 0xFF, np.uint8)
+        gpu.ffi.reconstruct_haplotypes_from_sparse(out, *inp)
+        np.testing.assert_array_equal(out, exp, err_msg=f"case {ci}")
+
+
+def test_golden_get_diffs_sparse(gpu):
+    cases = load_ref_cases("get_diffs_sparse")
+    assert len(cases) == 200
+    for ci, (inp, exp) in enumerate(cases):
+        got = gpu.ffi.get_diffs_sparse(*inp)
+        np.testing.assert_array_equal(got, exp, err_msg=f"case {ci}")
+
+
+def test_golden_get_reference(gpu):
+    cases = load_ref_cases("get_reference")
+    assert len(cases) == 200
+    for ci, (inp, exp) in enumerate(cases):
+        regions, out_offsets, reference, ref_offsets, pad_char, parallel = inp
+        got = gpu.ffi.get_reference(regions, out_offsets, reference, ref_offsets, pad_char, bool(parallel))
+        np.testing.assert_array_equal(got, exp, err_msg=f"case {ci}")
+
+
+def test_golden_rc_alleles_pins_rc_rows(gpu):
+    cases = load_ref_cases("rc_alleles")
+    for ci, (inp, exp) in enumerate(cases):
+        data, seq_offsets, var_offsets, mask = inp
+        per_allele = np.repeat(np.asarray(mask, bool), np.diff(var_offsets))
+        if len(per_allele) == 0:
+            continue
+        t = gpu.torch.from_numpy(np.ascontiguousarray(data, np.uint8).copy()).cuda()
+        gpu.device.rc_flat_rows_inplace(t, seq_offsets, per_allele)
+        np.testing.assert_array_equal(t.cpu().numpy(), exp, err_msg=f"case {ci}")
+
+
+# ------------------------------------------------------------------ known-answer rows
+@pytest.mark.parametrize("kat", ROW_KATS, ids=[k[0] for k in ROW_KATS])
+def test_row_kats(gpu, kat):
+    (_, v_idxs, v_starts, ilens, shift, alt, alt_off, ref, ref_start, L, pad, keep,
+     exp, exp_av, exp_ap) = kat
+    n = len(v_idxs)
+    common = dict(
+        regions=np.array([[0, ref_start, ref_start + L]], np.int32), shifts=np.array([[shift]], np.int32),
+        geno_offset_idx=np.array([[0]], np.int64), geno_offsets=np.array([[0], [n]], np.int64),
+        geno_v_idxs=np.array(v_idxs, np.int32), v_starts=np.array(v_starts, np.int32),
+        ilens=np.array(ilens, np.int32), alt_alleles=np.asarray(alt, np.uint8),
+        alt_offsets=np.array(alt_off, np.int64), ref_offsets=np.array([0, len(ref)], np.int64),
+        pad_char=pad, keep=None if keep is None else np.array(keep, bool),
+        keep_offsets=None if keep is None else np.array([0, n], np.int64))
+    out, av, ap, oo = gpu.ffi.reconstruct_annotated_haplotypes_fused(
+        ref_=np.asarray(ref, np.uint8), output_length=L, **common)
+    np.testing.assert_array_equal(out, exp)
+    np.testing.assert_array_equal(oo, [0, L])
+    if exp_av is not None:
+        np.testing.assert_array_equal(av, exp_av)
+    if exp_ap is not None:
+        np.testing.assert_array_equal(ap, exp_ap)
+    out2, _ = gpu.ffi.reconstruct_haplotypes_fused(ref_=np.asarray(ref, np.uint8), output_length=L, **common)
+    np.testing.assert_array_equal(out2, exp)
+
+
+def test_rc_kats(gpu):
+    for s, e in RC_KATS:
+        if not s:
+            continue
+        t = gpu.torch.from_numpy(S(s)).cuda()
+        gpu.device.rc_flat_rows_inplace(t, [0, len(s)], [True])
+        assert t.cpu().numpy().tobytes() == e.encode()
+    table = bytes.maketrans(b"ACGT", b"TGCA")
+    t = gpu.torch.arange(256, dtype=gpu.torch.uint8).cuda()
+    gpu.device.rc_flat_rows_inplace(t, np.arange(257), np.ones(256, bool))
+    assert t.cpu().numpy().tobytes() == bytes(table[b] for b in range(256))
+    f = gpu.torch.tensor([1.0, 2.0, 3.0, 9.0], dtype=gpu.torch.float32).cuda()
+    gpu.device.reverse_flat_rows_inplace(f, [0, 3, 4], [True, False])
+    assert f.cpu().tolist() == [3.0, 2.0, 1.0, 9.0]
+
+
+# ------------------------------------------------------------------ reference numpy fallback vectors
+@pytest.mark.parametrize("name", ["cfg2_small", "cfg3_small", "dense_annot"])
+def test_pyref_fixtures(gpu, name):
+    d = load_pyref(name)
+    annotate = d["expected_annot_v_idxs"] is not None
+    args = (d["regions"], d["shifts"], d["geno_offset_idx"], d["geno_offsets"], d["geno_v_idxs"],
+            d["v_starts"], d["ilens"], d["alt_alleles"], d["alt_offsets"], d["ref"], d["ref_offsets"],
+            d["pad_char"], int(d["output_length"]), d["keep"], d["keep_offsets"], d["to_rc"])
+    out, oo = gpu.ffi.reconstruct_haplotypes_fused(*args)
+    np.testing.assert_array_equal(out, d["expected"])
+    if annotate:
+        out, av, ap, _ = gpu.ffi.reconstruct_annotated_haplotypes_fused(*args)
+        np.testing.assert_array_equal(out, d["expected"])
+        np.testing.assert_array_equal(av, d["expected_annot_v_idxs"])
+        np.testing.assert_array_equal(ap, d["expected_annot_ref_pos"])
+    oh, _ = gpu.ffi.reconstruct_haplotypes_fused_onehot(*args)
+    exp_oh = (d["expected"][:, None] == np.frombuffer(b"ACGT", np.uint8)).astype(np.uint8)
+    np.testing.assert_array_equal(oh, exp_oh)
+
+
+# ------------------------------------------------------------------ synthetic, HIP vs oracle
+def _synth(seed, contigs, q, L, **kw):
+    from genvarloader_amd import synth
+
+    rng = np.random.default_rng(seed)
+    skw = {k: kw.pop(k) for k in ("indel_frac", "density", "af_beta", "n_frac") if k in kw}
+    st = synth.make_static(rng, contigs, **skw)
+    bt = synth.make_batch(rng, st, q, 2, L, **kw)
+    return st, bt
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 4, 5, 63, 255, 256, 257, 1023, 2047, 2048, 2049, 4099, 9000])
+def test_lengths_snp_indel_rc(gpu, oracle, L):
+    st, bt = _synth(100 + L, (50_000, 70_001), 40, L, indel_frac=0.2, density=1 / 40, rc_frac=0.5,
+                    random_shifts=True, edge_frac=0.2, permute_csr=True, slack=8)
+    check_batch(gpu, oracle, st, bt, annotate=(L % 2 == 1))
+
+
+@pytest.mark.parametrize("layout", ["lc", "cl"])
+def test_cfg2_full(gpu, oracle, layout):
+    from genvarloader_amd import synth
+
+    st, bt = synth.make_config("cfg2", contig=8 << 20)
+    assert bt.n_windows == 4096 and bt.output_length == 2048
+    check_batch(gpu, oracle, st, bt, layout=layout)
+
+
+def test_cfg3_full_with_properties(gpu, oracle):
+    from genvarloader_amd import synth
+
+    st, bt = synth.make_config("cfg3", contig=8 << 20, random_shifts=True)
+    assert bt.n_windows == 4096 and bt.output_length == 2048 and bt.to_rc.any()
+    out = check_batch(gpu, oracle, st, bt)
+    t = gpu.torch
+    K, L = bt.n_windows, bt.output_length
+    # property: RC folded into the kernel == forward output then rc_flat_rows_inplace
+    dev = make_dev(gpu, st, bt)
+    fwd = dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, L, to_rc=None)
+    buf = fwd.haps.clone()
+    gpu.device.rc_flat_rows_inplace(buf, np.arange(K + 1) * L, bt.to_rc)
+    assert t.equal(buf, out.haps)
+    # property: RC is an involution
+    gpu.device.rc_flat_rows_inplace(buf, np.arange(K + 1) * L, bt.to_rc)
+    assert t.equal(buf, fwd.haps)
+    # property: fused one-hot == stand-alone one-hot of the hap bytes; <= 1 hot per base
+    assert t.equal(gpu.device.onehot(out.haps), out.onehot)
+    assert int(out.onehot.sum(dim=1).max()) <= 1
+    n_acgt = sum(int((out.haps == c).sum()) for c in b"ACGT")
+    assert int(out.onehot.sum()) == n_acgt
+
+
+def test_cfg1_plumbing(gpu, oracle):
+    from genvarloader_amd import synth
+
+    st, bt = synth.make_config("cfg1", contig=4 << 20, ploidy=1)
+    assert bt.n_windows == 1024 and bt.output_length == 1024
+    check_batch(gpu, oracle, st, bt)
+
+
+def test_dense_variants_overflow_tables(gpu, oracle):
+    # > 64 segments / patches per row: exercises flush + compaction of the lane tables
+    st, bt = _synth(5, (30_000,), 32, 3000, indel_frac=0.5, density=1 / 3, af_beta=(5.0, 1.0),
+                    rc_frac=0.5, random_shifts=True, edge_frac=0.1)
+    assert bt.mean_variants > 300
+    check_batch(gpu, oracle, st, bt, annotate=True)
+    st, bt = _synth(6, (30_000,), 32, 3000, indel_frac=0.0, density=1 / 2, af_beta=(8.0, 1.0), rc_frac=0.5)
+    check_batch(gpu, oracle, st, bt, annotate=True)
+
+
+def test_long_rows_chunked(gpu, oracle):
+    # Enformer-like rows: several chunks per row, each wave replays the walk to its chunk
+    st, bt = _synth(8, (1 << 20,), 6, 131072, indel_frac=0.15, rc_frac=0.5, random_shifts=True)
+    check_batch(gpu, oracle, st, bt)
+    st, bt = _synth(9, (1 << 19,), 5, 40_001, indel_frac=0.3, density=1 / 20, rc_frac=0.5, edge_frac=0.4)
+    check_batch(gpu, oracle, st, bt, annotate=True)
+
+
+def test_keep_mask(gpu, oracle):
+    st, bt = _synth(12, (80_000,), 64, 1500, indel_frac=0.25, density=1 / 30, rc_frac=0.3)
+    idx = bt.geno_offset_idx.ravel()
+    n_per = bt.geno_offsets[1, idx] - bt.geno_offsets[0, idx]
+    bt.keep_offsets = np.concatenate([[0], np.cumsum(n_per)]).astype(np.int64)
+    bt.keep = np.random.default_rng(1).random(int(bt.keep_offsets[-1])) < 0.6
+    check_batch(gpu, oracle, st, bt, annotate=True)
+    # exonic keep-mask produced the reference way (genotypes/mod.rs:132-176)
+    keep, ko = oracle.choose_exonic_variants(bt.regions[:, 1], bt.regions[:, 2], bt.geno_offset_idx,
+                                             bt.geno_v_idxs, bt.geno_offsets, st.v_starts, st.ilens)
+    bt.keep, bt.keep_offsets = keep, ko
+    check_batch(gpu, oracle, st, bt)
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_ragged_mode(gpu, oracle, seed):
+    st, bt = _synth(seed, (60_000, 40_000), 100, 700, indel_frac=0.4, density=1 / 25, rc_frac=0.5,
+                    edge_frac=0.1, output_length=-1)
+    dev = make_dev(gpu, st, bt)
+    out = dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, -1, to_rc=bt.to_rc, haps=True, onehot=True)
+    exp, exp_off, exp_oh = oracle_fused(oracle, st, bt, onehot=True)
+    assert len(set(np.diff(exp_off))) > 5  # genuinely ragged
+    np.testing.assert_array_equal(out.out_offsets.cpu().numpy(), exp_off)
+    np.testing.assert_array_equal(out.haps.cpu().numpy(), exp)
+    np.testing.assert_array_equal(out.onehot.cpu().numpy(), exp_oh)
+    # device-side sizing alone: diffs + offsets + {total, max}
+    b = dev.prepare_batch(bt.regions, bt.shifts, bt.geno_offset_idx, -1)
+    oo, tm, diffs = dev.hap_offsets(b, want_diffs=True)
+    exp_d = oracle.get_diffs_sparse(bt.geno_offset_idx, bt.geno_v_idxs, bt.geno_offsets, st.ilens, None, None,
+                                    bt.regions[:, 1], bt.regions[:, 2], st.v_starts)
+    np.testing.assert_array_equal(diffs.cpu().numpy(), exp_d)
+    np.testing.assert_array_equal(oo.cpu().numpy(), exp_off)
+    assert tm.cpu().tolist() == [int(exp_off[-1]), int(np.diff(exp_off).max())]
+
+
+def test_offsets_scan_many_rows(gpu, oracle):
+    st, bt = _synth(31, (100_000,), 3000, 64, indel_frac=0.5, density=1 / 10, output_length=-1, slack=0)
+    dev = make_dev(gpu, st, bt)
+    b = dev.prepare_batch(bt.regions, bt.shifts, bt.geno_offset_idx, -1)
+    oo, tm, _ = dev.hap_offsets(b)
+    _, exp_off = oracle_fused(oracle, st, bt)
+    np.testing.assert_array_equal(oo.cpu().numpy(), exp_off)
+
+
+def test_spliced_caller_offsets(gpu, oracle):
+    # ploidy-1 flattened rows with caller-supplied offsets (ffi/mod.rs:1981-2076)
+    st, bt = _synth(41, (50_000,), 60, 300, indel_frac=0.3, density=1 / 30, rc_frac=0.5)
+    K = bt.n_windows
+    reg = np.repeat(bt.regions, 2, axis=0)
+    lens = np.random.default_rng(2).integers(0, 400, K)
+    oo = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    got = gpu.ffi.reconstruct_haplotypes_spliced_fused(
+        reg, bt.shifts.reshape(-1, 1), bt.geno_offset_idx.reshape(-1, 1), oo, bt.geno_offsets, bt.geno_v_idxs,
+        st.v_starts, st.ilens, st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets, st.pad_char,
+        None, None, bt.to_rc)
+    exp = np.zeros(int(oo[-1]), np.uint8)
+    oracle.reconstruct_haplotypes_from_sparse(
+        exp, oo, reg, bt.shifts.reshape(-1, 1), bt.geno_offset_idx.reshape(-1, 1), bt.geno_offsets,
+        bt.geno_v_idxs, st.v_starts, st.ilens, st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets,
+        st.pad_char, to_rc=bt.to_rc)
+    np.testing.assert_array_equal(got, exp)
+
+
+def test_get_reference_synthetic(gpu, oracle):
+    st, bt = _synth(51, (30_000, 10_000, 5), 300, 900, edge_frac=0.5, rc_frac=0.5)
+    lens = (bt.regions[:, 2] - bt.regions[:, 1]).astype(np.int64)
+    oo = np.concatenate([[0], np.cumsum(lens)])
+    to_rc = bt.regions[:, 3] == -1
+    exp = oracle.get_reference(bt.regions, oo, st.ref, st.ref_offsets, st.pad_char, True, to_rc)
+    got = gpu.ffi.get_reference(bt.regions, oo, st.ref, st.ref_offsets, st.pad_char, True, to_rc)
+    np.testing.assert_array_equal(got, exp)
+    dev = gpu.ffi._ref_static(st.ref, st.ref_offsets, st.pad_char)
+    out, oh = dev.get_reference(bt.regions, oo, to_rc, onehot=True)
+    np.testing.assert_array_equal(oh.cpu().numpy(), oracle.onehot(exp))
+
+
+def test_get_diffs_modes(gpu, oracle):
+    st, bt = _synth(61, (40_000,), 200, 500, indel_frac=0.5, density=1 / 15)
+    idx = bt.geno_offset_idx.ravel()
+    n_per = bt.geno_offsets[1, idx] - bt.geno_offsets[0, idx]
+    ko = np.concatenate([[0], np.cumsum(n_per)]).astype(np.int64)
+    keep = np.random.default_rng(3).random(int(ko[-1])) < 0.5
+    qs, qe = bt.regions[:, 1] + 100, bt.regions[:, 2] - 100
+    for kw in (dict(), dict(keep=keep, keep_offsets=ko), dict(q_starts=qs, q_ends=qe, v_starts=st.v_starts),
+               dict(keep=keep, keep_offsets=ko, q_starts=qs, q_ends=qe, v_starts=st.v_starts)):
+        exp = oracle.get_diffs_sparse(bt.geno_offset_idx, bt.geno_v_idxs, bt.geno_offsets, st.ilens, **kw)
+        got = gpu.ffi.get_diffs_sparse(bt.geno_offset_idx, bt.geno_v_idxs, bt.geno_offsets, st.ilens, **kw)
+        np.testing.assert_array_equal(got, exp)
+
+
+def test_onehot_standalone(gpu, oracle):
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 3, 4, 5, 1023, 100_003):
+        x = rng.integers(0, 256, n, dtype=np.uint8)
+        x[: min(n, 6)] = np.frombuffer(b"ACGTNa", np.uint8)[: min(n, 6)]
+        got = gpu.device.onehot(gpu.torch.from_numpy(x).cuda()).cpu().numpy()
+        np.testing.assert_array_equal(got, oracle.onehot(x))
+
+
+def test_empty_and_errors(gpu):
+    from genvarloader_amd import synth
+
+    rng = np.random.default_rng(0)
+    st = synth.make_static(rng, (10_000,))
+    bt = synth.make_batch(rng, st, 4, 2, 100)
+    dev = make_dev(gpu, st, bt)
+    out = dev.reconstruct(bt.regions[:0], bt.shifts[:0], bt.geno_offset_idx[:0], 100)
+    assert out.haps.numel() == 0 and out.out_offsets.cpu().tolist() == [0]
+    with pytest.raises(ValueError):
+        dev.reconstruct(bt.regions[:, :2], bt.shifts, bt.geno_offset_idx, 100)
+    with pytest.raises(ValueError):
+        dev.reconstruct(bt.regions, bt.shifts[:, :1], bt.geno_offset_idx, 100)
+    with pytest.raises(ValueError):
+        dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, 100, haps=False, onehot=False)
+    with pytest.raises(ValueError):  # channel-major one-hot is fixed-length only
+        dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, -1, onehot=True, layout="cl")
