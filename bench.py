@@ -93,6 +93,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--slots", type=int, default=2, help="output ring slots")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the batches alternate over")
     args = ap.parse_args()
 
     import torch
@@ -122,9 +123,13 @@ def main() -> None:
     dbt = dev.prepare_batch(bt.regions, bt.shifts, bt.geno_offset_idx, L, to_rc=bt.to_rc)
     slots = [dev.alloc_output(dbt, K * L, haps=args.haps, onehot=True) for _ in range(max(1, args.slots))]
     stream = torch.cuda.current_stream()
+    streams = [stream] + [torch.cuda.Stream() for _ in range(max(0, args.streams - 1))]
+    n_slots = max(len(slots), len(streams))
+    while len(slots) < n_slots:
+        slots.append(dev.alloc_output(dbt, K * L, haps=args.haps, onehot=True))
 
     def step(i: int) -> None:
-        dev.launch(dbt, slots[i % len(slots)][1], stream)
+        dev.launch(dbt, slots[i % len(slots)][1], streams[i % len(streams)])
 
     def barrier() -> None:
         if dist is not None:
@@ -142,6 +147,8 @@ def main() -> None:
     ev0.record(stream)
     for i in range(args.steps):
         step(i)
+    for st_ in streams[1:]:
+        stream.wait_stream(st_)
     ev1.record(stream)
     torch.cuda.synchronize()
     t1 = time.perf_counter()

@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "gvl_hip.h"
@@ -44,13 +45,16 @@ typedef unsigned int u32;
 typedef unsigned char u8;
 
 constexpr int WAVE = 64;
-constexpr int WG_WAVES = 4;
+constexpr int WG_WAVES = 8;               // one wave per row, 8 rows per workgroup
 constexpr int WG_THREADS = WAVE * WG_WAVES;
 constexpr int GROUP = 4;                   // bases per lane per trip
 constexpr int TRIP = WAVE * GROUP;         // 256 bases per wave trip
 constexpr int SEG_CAP = 64;                // lane-resident segment table
 constexpr int SEG_FLUSH = 59;              // flush before a step could overflow
 constexpr int PATCH_FLUSH = 62;
+constexpr int CAP_V = 32;                 // variants per row the cooperative planner handles
+constexpr int CAP_P = 32;                 // SNP patches per (row, chunk) in the shared plan
+constexpr int CHUNK_TRIPS = 8;            // trips per chunk on the planned path (chunk_len <= 2048)
 
 enum : u32 { K_REF = 0, K_ALLELE = 1, K_PAD_LEAD = 2, K_PAD_TRAIL = 3 };
 constexpr i64 DELTA_BIAS = 1ll << 40;      // src - out_start + BIAS fits 42 bits
@@ -94,17 +98,17 @@ __device__ __host__ __forceinline__ u32 onehot_dword(u32 b) {
          : b == 'T' ? 0x01000000u : 0u;
 }
 
-// LDS tables shared by the wave's lanes: [0] one-hot, [1] one-hot of the
-// complement, [2] complement byte.
+// LDS tables shared by the workgroup: one-hot dword of a byte, one-hot of its
+// complement (= the byte-reversed dword: A<->T, C<->G swaps channels 0<->3, 1<->2),
+// and the complement byte.
 struct Luts { u32 oh[256]; u32 oh_rc[256]; u32 comp[256]; };
 
-__device__ __forceinline__ void init_luts(Luts &l) {
-    for (int b = threadIdx.x; b < 256; b += blockDim.x) {
-        u32 c = comp_byte((u32)b);
-        l.oh[b] = onehot_dword((u32)b);
-        l.oh_rc[b] = onehot_dword(c);
-        l.comp[b] = c;
-    }
+__device__ __forceinline__ void init_luts(Luts &l) {   // 256-thread workgroups
+    const int b = threadIdx.x & 255;
+    const u32 d = onehot_dword((u32)b);
+    l.oh[b] = d;
+    l.oh_rc[b] = __builtin_bswap32(d);
+    l.comp[b] = comp_byte((u32)b);
     __syncthreads();
 }
 
@@ -118,74 +122,85 @@ struct ReconArgs {
     const int *regions; i64 regions_stride; const int *shifts; const i64 *geno_offset_idx;
     const u8 *keep; const i64 *keep_offsets; const u8 *to_rc; const i64 *out_offsets;
     i64 fixed_len;      // >= 0 or -1
-    i64 n_queries; int ploidy; int chunks; int chunk_len;
+    i64 n_rows; int ploidy; int ploidy_shift; int chunk_len;
+    int dbg;
     int ref_only;       // get_reference mode: no variants, shift 0, row len from out_offsets
     u32 pad;
     // out
-    u8 *haps; u8 *onehot; int onehot_cl; int *av; int *ap; i64 *out_offsets_w;
+    u8 *haps; u8 *onehot; int *av; int *ap; i64 *out_offsets_w;
+    u64 *stamps;        // diagnostic builds (-DGVL_DIAG): per-workgroup phase time stamps
 };
 
-// Per-wave mirror of the segment table for the (rare, divergent) slow path.
+// Per-wave mirror of the segment table + staging, used only by "general" trips.
 struct SegMirror { int out[SEG_CAP]; u32 lo[SEG_CAP]; u32 hi[SEG_CAP]; int a[SEG_CAP]; int b[SEG_CAP]; };
-
 template <bool ANNOT>
-__global__ __launch_bounds__(WG_THREADS) void reconstruct_kernel(const ReconArgs A) {
-    __shared__ Luts luts;
-    __shared__ SegMirror mirror[WG_WAVES];
-    init_luts(luts);
+struct Stage {
+    u32 w[WAVE];
+    int av[GROUP][ANNOT ? WAVE : 1];
+    int ap[GROUP][ANNOT ? WAVE : 1];
+};
 
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int wave = rfl((int)(threadIdx.x >> 6));
-    SegMirror &M = mirror[wave];
+__device__ __forceinline__ i64 seg_delta(u32 lo, u32 hi) {
+    return (i64)((((u64)(hi & 0x3FFFFFFFu)) << 32) | lo) - DELTA_BIAS;
+}
 
-    // unit -> (query, chunk, hap): the haps of a query and neighbouring chunks of a
-    // row sit in one workgroup so that they share the reference window in L1/L2.
-    const i64 unit = (i64)blockIdx.x * WG_WAVES + wave;
-    const i64 n_units = A.n_queries * A.chunks * A.ploidy;
-    if (unit >= n_units) return;
-    const int hap = (int)(unit % A.ploidy);
-    const i64 qc = unit / A.ploidy;
-    const int chunk = (int)(qc % A.chunks);
-    const i64 query = qc / A.chunks;
-    const i64 k = query * A.ploidy + hap;
+enum { OH_NONE = 0, OH_LC = 1, OH_CL = 2 };
+
+// ---------------------------------------------------------------------------------
+// Scalar path: ONE wave replays the reference's walk on the scalar unit and streams its
+// (row, chunk).  Handles everything (any number of variants / segments, via flush +
+// compaction of the 64-entry lane tables).  It is the fallback of the planned path below
+// for rows the cooperative planner does not take (more than CAP_V variants, table
+// overflow) -- it costs ~10x more issue slots per row, so it is not the default.
+// ---------------------------------------------------------------------------------
+template <int OH, bool HAPS, bool ANNOT>
+__device__ __forceinline__ void recon_wave_scalar(const ReconArgs &A, const Luts &luts, SegMirror &M,
+                                                   Stage<ANNOT> &G, const i64 k, const int chunk,
+                                                   const int lane) {
+    const i64 query = A.ploidy_shift >= 0 ? (k >> A.ploidy_shift) : (i64)((u32)k / (u32)A.ploidy);
 
     // ---- row parameters (level-1 loads; wave-uniform) -------------------------
     const int *reg = A.regions + query * A.regions_stride;
     const i64 c_idx = rfl(reg[0]);
     const i64 ref_start = rfl(reg[1]);
-    const int reg_end = rfl(reg[2]);
     i64 shift = 0, o_idx = 0;
+    bool ref_zero_fill = false;
     if (!A.ref_only) {
         shift = rfl(A.shifts[k]);
         o_idx = rfl64(A.geno_offset_idx[k]);
+    } else {
+        ref_zero_fill = ref_start >= (i64)rfl(reg[2]);   // reference/mod.rs:16-18
     }
     const bool rc = A.to_rc ? (rfl((int)A.to_rc[k]) != 0) : false;
-    i64 row_base, L;
+    i64 row_base; int L;
     if (A.out_offsets) {
         row_base = rfl64(A.out_offsets[k]);
-        L = rfl64(A.out_offsets[k + 1]) - row_base;
+        L = (int)(rfl64(A.out_offsets[k + 1]) - row_base);
     } else {
         row_base = k * A.fixed_len;
-        L = A.fixed_len;
+        L = (int)A.fixed_len;
     }
     if (A.out_offsets_w && chunk == 0 && lane == 0) {
         A.out_offsets_w[k] = row_base;
-        if (k == A.n_queries * A.ploidy - 1) A.out_offsets_w[k + 1] = row_base + L;
+        if (k == A.n_rows - 1) A.out_offsets_w[k + 1] = row_base + L;
     }
-    const i64 lo_clip = (i64)chunk * A.chunk_len;
-    const i64 hi_clip = imin(lo_clip + A.chunk_len, L);
+    const int lo_clip = chunk * A.chunk_len;
     if (lo_clip >= L) return;
+    const int hi_clip = (L - lo_clip > A.chunk_len) ? lo_clip + A.chunk_len : L;
 
     // ---- level-2 loads ---------------------------------------------------------
     const i64 c_s = rfl64(A.ref_offsets[c_idx]);
     const i64 R = rfl64(A.ref_offsets[c_idx + 1]) - c_s;
-    i64 o_s = 0, n_var = 0, keep_off = 0;
+    const bool has_keep = A.keep && A.keep_offsets;
+    i64 o_s = 0, keep_off = 0;
+    int n_var = 0;
     if (!A.ref_only) {
         o_s = rfl64(A.go_starts[o_idx]);
-        n_var = imax(rfl64(A.go_stops[o_idx]) - o_s, 0);
-        if (A.keep && A.keep_offsets) keep_off = rfl64(A.keep_offsets[k]);
+        const i64 nv = rfl64(A.go_stops[o_idx]) - o_s;
+        n_var = nv < 0 ? 0 : (nv > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)nv);
+        if (A.dbg & 1) n_var = 0;
+        if (has_keep) keep_off = rfl64(A.keep_offsets[k]);
     }
-    const bool has_keep = A.keep && A.keep_offsets;
 
     // ---- segment / patch tables (lane s holds entry s) ------------------------
     int s_out = 0; u32 s_lo = 0, s_hi = 0; int s_a = 0, s_b = 0;
@@ -193,33 +208,29 @@ __global__ __launch_bounds__(WG_THREADS) void reconstruct_kernel(const ReconArgs
     int nseg = 0, npatch = 0;
     u32 last_kind = 0xFFu; i64 last_delta = 0;
 
-    auto push = [&](u32 kind, i64 o_start, i64 len, i64 src, int id, int vpos) {
-        i64 s = imax(o_start, lo_clip), e = imin(o_start + len, hi_clip);
-        if (e <= s) return;
-        i64 delta = src - o_start;
-        if (kind == K_REF && last_kind == K_REF && delta == last_delta) return;  // extends the open run
-        u64 enc = (u64)(delta + DELTA_BIAS) | ((u64)kind << 62);
+    // Append a segment [o_start, o_start+len) of `kind` whose byte at output position p
+    // is source[delta + p].  Output coordinates are ints (< 2^31); a reference run that
+    // continues the previous one (same delta) is merged, which is what makes SNPs free.
+    auto push = [&](u32 kind, int o_start, int len, i64 src, int id, int vpos) {
+        if (len <= 0 || o_start + len <= lo_clip || o_start >= hi_clip) return;
+        const i64 delta = src - o_start;
+        if (kind == K_REF && last_kind == K_REF && delta == last_delta) return;
+        const u64 enc = (u64)(delta + DELTA_BIAS) | ((u64)kind << 62);
         if (lane == nseg) {
-            s_out = (int)s; s_lo = (u32)enc; s_hi = (u32)(enc >> 32);
-            M.out[lane] = (int)s; M.lo[lane] = (u32)enc; M.hi[lane] = (u32)(enc >> 32);
-            if (ANNOT) { s_a = id; s_b = vpos; M.a[lane] = id; M.b[lane] = vpos; }
+            s_out = o_start; s_lo = (u32)enc; s_hi = (u32)(enc >> 32);
+            if (ANNOT) { s_a = id; s_b = vpos; }
         }
         last_kind = kind; last_delta = delta; ++nseg;
     };
-    auto push_patch = [&](i64 o_pos, int byte, int id) {
-        if (o_pos < lo_clip || o_pos >= hi_clip) return;
-        if (lane == npatch) { p_out = (int)o_pos; p_val = byte; if (ANNOT) p_id = id; }
-        ++npatch;
-    };
 
     // ---- walk state: reconstruct/mod.rs:61-83 -----------------------------------
-    i64 ref_idx = ref_start, out_idx = 0, shifted = 0;
-    bool ref_zero_fill = false;
-    if (A.ref_only && ref_start >= (i64)reg_end) ref_zero_fill = true;  // reference/mod.rs:16-18
+    i64 ref_idx = ref_start, shifted = 0;
+    int out_idx = 0;
     if (ref_idx < 0) {
-        i64 raw = -ref_idx;
+        const i64 raw = -ref_idx;
         shifted = imin(shift, raw);
-        i64 n = raw - shifted;
+        // a pad longer than the row is clamped: the row is then all pad either way
+        const int n = (int)imin(raw - shifted, (i64)L);
         push(K_PAD_LEAD, 0, n, 0, -1, -1);
         out_idx = n;
         ref_idx = 0;
@@ -227,14 +238,20 @@ __global__ __launch_bounds__(WG_THREADS) void reconstruct_kernel(const ReconArgs
 
     // variant record registers for the current trip of 64 variants
     int r_pos = 0, r_ilen = 0, r_alen = 0, r_inl = 0, r_vi = 0, r_a0lo = 0, r_a0hi = 0, r_keep = 1;
-    i64 vi = 0;          // next variant of the row
-    i64 vb = -1;         // base of the loaded trip (-1: none)
+    int vi = 0;          // next variant of the row
+    int vb = -WAVE;      // base of the loaded trip
     bool walk_done = false;
-    i64 emit_pos = lo_clip;
+    int emit_pos = lo_clip;
 
     const u32 padb = A.pad & 0xFFu;
-    u8 *hap_row = A.haps ? A.haps + row_base : nullptr;
-    u8 *oh_row = A.onehot ? A.onehot + 4 * row_base : nullptr;
+    // RC is folded into the store: forward position p lands at L-4-p (group) with the
+    // group's 4 bytes reversed (one v_perm with a uniform selector) and complemented
+    // (second LUT).  `lane_off` is the lane's share of the store offset, in bases.
+    const u32 rc_sel = rc ? 0x00010203u : 0x03020100u;
+    const u32 *oh_t = rc ? luts.oh_rc : luts.oh;
+    const int lane_pos = rc ? -GROUP * lane : GROUP * lane;
+    u8 *hap_row = HAPS ? A.haps + row_base : nullptr;
+    u8 *oh_row = OH != OH_NONE ? A.onehot + 4 * row_base : nullptr;
     int *av_row = (ANNOT && A.av) ? A.av + row_base : nullptr;
     int *ap_row = (ANNOT && A.ap) ? A.ap + row_base : nullptr;
 
@@ -243,35 +260,36 @@ __global__ __launch_bounds__(WG_THREADS) void reconstruct_kernel(const ReconArgs
         while (!walk_done && nseg <= SEG_FLUSH && npatch <= PATCH_FLUSH) {
             bool stop = (vi >= n_var) || (out_idx >= hi_clip);
             if (!stop) {
-                if (vb < 0 || vi - vb >= WAVE) {
+                if (vi - vb >= WAVE) {
                     // gather the next 64 variant records (levels 3 and 4)
                     vb = vi;
-                    i64 j = vb + lane;
-                    bool valid = j < n_var;
+                    const int j = vb + lane;
+                    const bool valid = j < n_var;
                     int v = valid ? A.geno_v_idxs[o_s + j] : 0;
                     v = v < 0 ? 0 : ((i64)v >= A.n_variants ? (int)(A.n_variants - 1) : v);
                     r_vi = v;
                     if (valid) {
                         const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.vrec + v);
-                        i64 a0 = A.alt_offsets[v];
+                        const i64 a0 = A.alt_offsets[v];
                         r_pos = rec.x; r_ilen = rec.y; r_alen = rec.z; r_inl = rec.w;
                         r_a0lo = (int)(u32)(u64)a0; r_a0hi = (int)(u32)((u64)a0 >> 32);
                         r_keep = has_keep ? (int)A.keep[keep_off + j] : 1;
                     }
                 }
-                const int i = (int)(vi - vb);
+                const int i = vi - vb;
                 ++vi;
                 // --- one step of reconstruct/mod.rs:85-198 ---
                 if (has_keep && rdl(r_keep, i) == 0) continue;           // :86-90
                 const i64 pos = rdl(r_pos, i);
-                const i64 d = rdl(r_ilen, i);
-                const i64 alen = rdl(r_alen, i);
-                const i64 v_end = pos - imin(0, d) + 1;                   // :96
-                if (pos < ref_start && d < 0 && v_end >= ref_start) {     // :99-102
-                    ref_idx = v_end;
+                const int d = rdl(r_ilen, i);
+                const int alen = rdl(r_alen, i);
+                const i64 v_end = pos - (d < 0 ? (i64)d : 0) + 1;         // :96
+                if (pos < ref_idx) {
+                    // :99-102 DEL spanning the window start (only possible while pos < ref_start
+                    // <= ref_idx), else :108-110 first ALT wins
+                    if (pos < ref_start && d < 0 && v_end >= ref_start) ref_idx = v_end;
                     continue;
                 }
-                if (pos < ref_idx) continue;                              // :108-110
                 i64 skip = 0;
                 if (shifted < shift) {                                    // :115-146
                     const i64 dist = pos - ref_idx;
@@ -286,23 +304,30 @@ __global__ __launch_bounds__(WG_THREADS) void reconstruct_kernel(const ReconArgs
                         ref_idx = pos;
                     }
                 }
-                const i64 al = alen - skip;
-                const i64 n = pos - ref_idx;
-                if (out_idx + n >= L) {                                   // :154-158 (">=")
+                const i64 n64 = pos - ref_idx;
+                if (n64 >= (i64)(L - out_idx)) {                          // :154-158 (">=")
                     stop = true;
                 } else {
-                    push(K_REF, out_idx, n, c_s + ref_idx, -1, -1);
-                    out_idx += n;
-                    const i64 w = imin(al, L - out_idx);                  // :178
+                    const int n = (int)n64;
                     const int id = rdl(r_vi, i);
-                    if (d == 0 && alen == 1 && w == 1) {
-                        // pure SNP: the reference run continues, one byte is patched
-                        push(K_REF, out_idx, 1, c_s + pos, -1, -1);
-                        push_patch(out_idx, rdl(r_inl, i) & 0xFF, id);
+                    if (d == 0 && alen == 1) {
+                        // pure SNP (skip == 0 here): the reference run continues through the
+                        // variant's own base and one output byte is patched
+                        push(K_REF, out_idx, n + 1, c_s + ref_idx, -1, -1);
+                        out_idx += n;
+                        if (out_idx >= lo_clip && out_idx < hi_clip) {
+                            if (lane == npatch) { p_out = out_idx; p_val = rdl(r_inl, i) & 0xFF; if (ANNOT) p_id = id; }
+                            ++npatch;
+                        }
+                        out_idx += 1;
                     } else {
+                        push(K_REF, out_idx, n, c_s + ref_idx, -1, -1);
+                        out_idx += n;
+                        const i64 al = (i64)alen - skip;
+                        const int w = (int)imin(al, (i64)(L - out_idx));  // :178
                         push(K_ALLELE, out_idx, w, rdl64(r_a0lo, r_a0hi, i) + skip, id, (int)pos);
+                        out_idx += w;
                     }
-                    out_idx += w;
                     ref_idx = v_end;                                      // :193
                     if (out_idx >= L) stop = true;                        // :195-197
                 }
@@ -310,93 +335,123 @@ __global__ __launch_bounds__(WG_THREADS) void reconstruct_kernel(const ReconArgs
             if (stop) {
                 // residual shift + tail: reconstruct/mod.rs:200-255
                 if (shifted < shift) ref_idx = imin(ref_idx + (shift - shifted), R);
-                const i64 u = L - out_idx;
+                const int u = L - out_idx;
                 if (u > 0) {
-                    const i64 w = imin(u, R - ref_idx);
-                    i64 end = out_idx;
+                    const i64 avail = R - ref_idx;
+                    const int w = (int)imin((i64)u, avail);
+                    int end = out_idx;
                     if (w > 0) { push(K_REF, out_idx, w, c_s + ref_idx, -1, -1); end += w; }
                     if (end < L) push(K_PAD_TRAIL, end, L - end, 0, -1, -1);
                 }
-                out_idx = imax(out_idx, L);
+                out_idx = out_idx > L ? out_idx : L;
                 walk_done = true;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         // =================== emit [emit_pos, limit) ===============================
-        const int cov = (int)imin(imax(out_idx, lo_clip), hi_clip);
-        const int limit = walk_done ? (int)hi_clip : (cov & ~3);
-        int sc = 0, pc = 0;
-        for (int p0 = (int)emit_pos; p0 < limit; p0 += TRIP) {
+        // One trip = 256 bases, 4 per lane.  A trip that lies inside ONE reference run
+        // (the common case) is "uniform": every lane loads its 4 bytes from a scalar
+        // base.  Other trips take the general path: per-lane segment lookup through the
+        // LDS mirror; lanes on a boundary / in an allele / pad / row end assemble their
+        // 4 bytes one by one.  Then: SNP patches, reverse-complement, one-hot LUT, store.
+        const int cov = out_idx < lo_clip ? lo_clip : (out_idx > hi_clip ? hi_clip : out_idx);
+        const int limit = walk_done ? hi_clip : (cov & ~3);
+        int sc = -1, pc = 0;
+        int c_next = emit_pos;      // start of segment sc+1 (or cov)
+        bool c_ok = false;          // segment sc is a reference run that stays inside `ref`
+        const u8 *c_base = A.ref;   // A.ref + delta of segment sc
+        int c_apb = 0;              // annotation: contig coordinate of output position 0
+        int np_pos = npatch > 0 ? rdl(p_out, 0) : 0x7FFFFFFF;
+        bool mirror_valid = false;
+        for (int p0 = emit_pos; p0 < limit; p0 += TRIP) {
+            const int t_end = (limit - p0 > TRIP) ? p0 + TRIP : limit;
+            while (c_next <= p0) {      // advance to the segment that holds p0
+                ++sc;
+                const u32 hi = (u32)rdl((int)s_hi, sc);
+                const i64 dl = seg_delta((u32)rdl((int)s_lo, sc), hi);
+                const int c_start = rdl(s_out, sc);
+                c_next = sc + 1 < nseg ? rdl(s_out, sc + 1) : cov;
+                const int e = c_next < limit ? c_next : limit;
+                c_ok = (hi >> 30) == K_REF && dl + (c_start > emit_pos ? c_start : emit_pos) >= 0 &&
+                       dl + e <= A.ref_len && !ref_zero_fill;
+                c_base = A.ref + dl;
+                if (ANNOT) c_apb = (int)(dl - c_s);
+            }
             const int p = p0 + GROUP * lane;
             const bool act = p < limit;
-            // segment holding p: scalar cursor + the few starts inside this trip
-            while (sc + 1 < nseg && rdl(s_out, sc + 1) <= p0) ++sc;
-            int idx = sc;
-            for (int s = sc + 1; s < nseg; ++s) {
-                const int st = rdl(s_out, s);
-                if (st >= p0 + TRIP) break;
-                idx += (p >= st) ? 1 : 0;
-            }
-            const u32 lo = (u32)bperm(idx, (int)s_lo);
-            const u32 hi = (u32)bperm(idx, (int)s_hi);
-            int nxt = bperm(idx + 1 < SEG_CAP ? idx + 1 : SEG_CAP - 1, s_out);
-            if (idx + 1 >= nseg) nxt = cov;
-            const u32 kind = hi >> 30;
-            const i64 delta = (i64)((((u64)(hi & 0x3FFFFFFFu)) << 32) | lo) - DELTA_BIAS;
-            const i64 src = delta + p;
-            const bool full = act && (p + GROUP <= limit);
-            const bool fast = full && kind == K_REF && (p + GROUP <= nxt) && src >= 0 &&
-                              src + GROUP <= A.ref_len && !ref_zero_fill;
-            u32 w = 0;
+            const bool full = p + GROUP <= limit;
+            u32 wv = 0;
             int av4[GROUP], ap4[GROUP];
-            if (fast) {
-                w = load_u32_unaligned(A.ref + src);
+            if (c_ok && c_next >= t_end && ((t_end - p0) & 3) == 0) {
+                // ---- uniform trip -------------------------------------------------
+                if (act && !(A.dbg & 4)) wv = load_u32_unaligned(c_base + p0 + (u32)(GROUP * lane));
                 if (ANNOT) {
 #pragma unroll
-                    for (int i = 0; i < GROUP; ++i) { av4[i] = -1; ap4[i] = (int)(src - c_s) + i; }
+                    for (int i = 0; i < GROUP; ++i) { av4[i] = -1; ap4[i] = c_apb + p + i; }
                 }
-            } else if (act) {
-                // slow path: group straddles a segment boundary, sits in an allele or a
-                // pad run, or is the partial group at the end of the row
-                int li = idx;
+            } else {
+                // ---- general trip -------------------------------------------------
+                if (!mirror_valid) {
+                    M.out[lane] = s_out; M.lo[lane] = s_lo; M.hi[lane] = s_hi;
+                    if (ANNOT) { M.a[lane] = s_a; M.b[lane] = s_b; }
+                    mirror_valid = true;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                if (act) {
+                    // largest li with M.out[li] <= p (binary search; nseg <= 64)
+                    int li = 0;
 #pragma unroll
-                for (int i = 0; i < GROUP; ++i) {
-                    const int pp = p + i;
-                    u32 b = 0; int a_v = -1, a_p = -1;
-                    if (pp < limit) {
-                        while (li + 1 < nseg && M.out[li + 1] <= pp) ++li;
-                        const u32 l2 = M.lo[li], h2 = M.hi[li];
-                        const u32 k2 = h2 >> 30;
-                        const i64 s2 = (i64)((((u64)(h2 & 0x3FFFFFFFu)) << 32) | l2) - DELTA_BIAS + pp;
-                        if (ref_zero_fill) {
-                            b = 0;
-                        } else if (k2 == K_REF) {
-                            b = (s2 >= 0 && s2 < A.ref_len) ? (u32)A.ref[s2] : padb;
-                            a_p = (int)(s2 - c_s);
-                        } else if (k2 == K_ALLELE) {
-                            b = (s2 >= 0 && s2 < A.alt_len) ? (u32)A.alt_alleles[s2] : padb;
-                            if (ANNOT) { a_v = M.a[li]; a_p = M.b[li]; }
-                        } else {
-                            b = padb;
-                            a_p = (k2 == K_PAD_LEAD) ? -1 : 2147483647;
+                    for (int step = 32; step > 0; step >>= 1) {
+                        const int t = li + step;
+                        if (t < nseg && M.out[t] <= p) li = t;
+                    }
+                    const u32 l0 = M.lo[li], h0 = M.hi[li];
+                    const int nx = li + 1 < nseg ? M.out[li + 1] : cov;
+                    const i64 src = seg_delta(l0, h0) + p;
+                    if ((h0 >> 30) == K_REF && p + GROUP <= nx && full && src >= 0 &&
+                        src + GROUP <= A.ref_len && !ref_zero_fill) {
+                        wv = load_u32_unaligned(A.ref + src);
+                        if (ANNOT) {
+#pragma unroll
+                            for (int i = 0; i < GROUP; ++i) { av4[i] = -1; ap4[i] = (int)(src - c_s) + i; }
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < GROUP; ++i) {
+                            const int pp = p + i;
+                            u32 b = 0; int a_v = -1, a_p = -1;
+                            if (pp < limit) {
+                                while (li + 1 < nseg && M.out[li + 1] <= pp) ++li;
+                                const u32 l2 = M.lo[li], h2 = M.hi[li];
+                                const u32 k2 = h2 >> 30;
+                                const i64 s2 = seg_delta(l2, h2) + pp;
+                                if (ref_zero_fill) {
+                                    b = 0;
+                                } else if (k2 == K_REF) {
+                                    b = (s2 >= 0 && s2 < A.ref_len) ? (u32)A.ref[s2] : padb;
+                                    a_p = (int)(s2 - c_s);
+                                } else if (k2 == K_ALLELE) {
+                                    b = (s2 >= 0 && s2 < A.alt_len) ? (u32)A.alt_alleles[s2] : padb;
+                                    if (ANNOT) { a_v = M.a[li]; a_p = M.b[li]; }
+                                } else {
+                                    b = padb;
+                                    a_p = (k2 == K_PAD_LEAD) ? -1 : 2147483647;
+                                }
+                            }
+                            wv |= b << (8 * i);
+                            if (ANNOT) { av4[i] = a_v; ap4[i] = a_p; }
                         }
                     }
-                    w |= b << (8 * i);
-                    if (ANNOT) { av4[i] = a_v; ap4[i] = a_p; }
                 }
             }
-            // SNP patches that land in this trip (sorted; scalar cursor)
-            while (pc < npatch) {
-                const int pp = rdl(p_out, pc);
-                if (pp >= p0 + TRIP) break;
-                const u32 pv = (u32)rdl(p_val, pc);
-                const u32 dd = (u32)(pp - p);
+            // ---- SNP patches that land in this trip (sorted; scalar cursor) ----------
+            while (np_pos < t_end) {
+                const u32 dd = (u32)(np_pos - p);
                 if (dd < (u32)GROUP) {
                     const u32 sh = dd * 8;
-                    w = (w & ~(0xFFu << sh)) | (pv << sh);
+                    wv = (wv & ~(0xFFu << sh)) | ((u32)rdl(p_val, pc) << sh);
                 }
                 if (ANNOT) {
                     const int pid = rdl(p_id, pc);
@@ -404,35 +459,31 @@ __global__ __launch_bounds__(WG_THREADS) void reconstruct_kernel(const ReconArgs
                     for (int i = 0; i < GROUP; ++i) if (dd == (u32)i) av4[i] = pid;
                 }
                 ++pc;
+                np_pos = pc < npatch ? rdl(p_out, pc) : 0x7FFFFFFF;
             }
-            if (!act) continue;
-
-            // ---- stores: RC folded into the index + LUT ---------------------------
-            if (full) {
-                const int jo = rc ? (int)(L - GROUP - p) : p;
-                u32 ww = rc ? __builtin_bswap32(w) : w;
-                const u32 b0 = ww & 0xFF, b1 = (ww >> 8) & 0xFF, b2 = (ww >> 16) & 0xFF, b3 = ww >> 24;
-                if (oh_row) {
-                    const u32 *t = rc ? luts.oh_rc : luts.oh;
-                    if (!A.onehot_cl) {
-                        u32x4_a4 o = {t[b0], t[b1], t[b2], t[b3]};
-                        *reinterpret_cast<u32x4_a4 *>(oh_row + 4 * (i64)jo) = o;
-                    } else {
-                        // channel-major (rows, 4, L): plane a holds byte a of each one-hot dword
-                        const u32 d0 = t[b0], d1 = t[b1], d2 = t[b2], d3 = t[b3];
+            // ---- stores ------------------------------------------------------------------
+            if (full && !(A.dbg & 2)) {
+                // forward: jo = p; RC: jo = L - 4 - p.  In both cases jo = jo0 + lane_pos.
+                const int jo = (rc ? L - GROUP - p0 : p0) + lane_pos;
+                const u32 ww = __builtin_amdgcn_perm(0u, wv, rc_sel);
+                const u32 b0_ = ww & 0xFF, b1_ = (ww >> 8) & 0xFF, b2_ = (ww >> 16) & 0xFF, b3_ = ww >> 24;
+                if (OH == OH_LC) {
+                    u32x4_a4 o = {oh_t[b0_], oh_t[b1_], oh_t[b2_], oh_t[b3_]};
+                    *reinterpret_cast<u32x4_a4 *>(oh_row + 4 * (i64)jo) = o;
+                } else if (OH == OH_CL) {
+                    // channel-major (rows, 4, L): plane a holds byte a of each one-hot dword
+                    const u32 d0 = oh_t[b0_], d1 = oh_t[b1_], d2 = oh_t[b2_], d3 = oh_t[b3_];
 #pragma unroll
-                        for (int a = 0; a < 4; ++a) {
-                            const u32 sh = 8 * a;
-                            const u32 v = ((d0 >> sh) & 0xFF) | (((d1 >> sh) & 0xFF) << 8) |
-                                          (((d2 >> sh) & 0xFF) << 16) | (((d3 >> sh) & 0xFF) << 24);
-                            u8 *dst = oh_row + (i64)a * L + jo;
-                            __builtin_memcpy(dst, &v, 4);
-                        }
+                    for (int a = 0; a < 4; ++a) {
+                        const u32 sh = 8 * a;
+                        const u32 v = ((d0 >> sh) & 0xFF) | (((d1 >> sh) & 0xFF) << 8) |
+                                      (((d2 >> sh) & 0xFF) << 16) | (((d3 >> sh) & 0xFF) << 24);
+                        __builtin_memcpy(oh_row + (i64)a * L + jo, &v, 4);
                     }
                 }
-                if (hap_row) {
+                if (HAPS) {
                     u32 hv = ww;
-                    if (rc) hv = luts.comp[b0] | (luts.comp[b1] << 8) | (luts.comp[b2] << 16) | (luts.comp[b3] << 24);
+                    if (rc) hv = luts.comp[b0_] | (luts.comp[b1_] << 8) | (luts.comp[b2_] << 16) | (luts.comp[b3_] << 24);
                     __builtin_memcpy(hap_row + jo, &hv, 4);
                 }
                 if (ANNOT) {
@@ -445,27 +496,40 @@ __global__ __launch_bounds__(WG_THREADS) void reconstruct_kernel(const ReconArgs
                         *reinterpret_cast<i32x4_a4 *>(ap_row + jo) = o;
                     }
                 }
-            } else {
-                // partial group at the row end: per-base stores
+            }
+            if (limit & 3) {
+                // the partial group at the row end (L % 4 != 0): the owning lane parks its
+                // patched bytes; lanes 0..(L&3)-1 then store one base each
+                const int p_last = limit & ~3;
+                if (p_last >= p0 && p_last < p0 + TRIP) {
+                    if (act && !full) {
+                        G.w[0] = wv;
+                        if (ANNOT) {
 #pragma unroll
-                for (int i = 0; i < GROUP; ++i) {
-                    const int pp = p + i;
-                    if (pp >= limit) break;
-                    const u32 b = (w >> (8 * i)) & 0xFF;
-                    const i64 jo = rc ? (L - 1 - pp) : (i64)pp;
-                    if (oh_row) {
-                        const u32 d = rc ? luts.oh_rc[b] : luts.oh[b];
-                        if (!A.onehot_cl) {
-                            __builtin_memcpy(oh_row + 4 * jo, &d, 4);
-                        } else {
-#pragma unroll
-                            for (int a = 0; a < 4; ++a) oh_row[(i64)a * L + jo] = (u8)((d >> (8 * a)) & 0xFF);
+                            for (int i = 0; i < GROUP; ++i) { G.av[i][0] = av4[i]; G.ap[i][0] = ap4[i]; }
                         }
                     }
-                    if (hap_row) hap_row[jo] = (u8)(rc ? luts.comp[b] : b);
-                    if (ANNOT) {
-                        if (av_row) av_row[jo] = av4[i];
-                        if (ap_row) ap_row[jo] = ap4[i];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (lane < (limit & 3)) {
+                        const int pp = p_last + lane;
+                        const u32 b = (G.w[0] >> (8 * lane)) & 0xFF;
+                        const i64 jo = rc ? (i64)(L - 1 - pp) : (i64)pp;
+                        if (OH != OH_NONE) {
+                            const u32 d = oh_t[b];
+                            if (OH == OH_LC) {
+                                __builtin_memcpy(oh_row + 4 * jo, &d, 4);
+                            } else {
+#pragma unroll
+                                for (int a = 0; a < 4; ++a) oh_row[(i64)a * L + jo] = (u8)((d >> (8 * a)) & 0xFF);
+                            }
+                        }
+                        if (HAPS) hap_row[jo] = (u8)(rc ? luts.comp[b] : b);
+                        if (ANNOT) {
+                            if (av_row) av_row[jo] = G.av[lane][0];
+                            if (ap_row) ap_row[jo] = G.ap[lane][0];
+                        }
                     }
                 }
             }
@@ -476,7 +540,7 @@ __global__ __launch_bounds__(WG_THREADS) void reconstruct_kernel(const ReconArgs
         // =================== compact: drop what has been emitted ==================
         {
             int cnt = 0;
-            for (int s = 0; s < nseg; ++s) cnt += (rdl(s_out, s) <= (int)emit_pos) ? 1 : 0;
+            for (int s = 0; s < nseg; ++s) cnt += (rdl(s_out, s) <= emit_pos) ? 1 : 0;
             const int s0 = cnt > 0 ? cnt - 1 : 0;
             if (s0 > 0) {
                 const int srcl = lane + s0 < SEG_CAP ? lane + s0 : SEG_CAP - 1;
@@ -486,10 +550,8 @@ __global__ __launch_bounds__(WG_THREADS) void reconstruct_kernel(const ReconArgs
                 if (ANNOT) { s_a = bperm(srcl, s_a); s_b = bperm(srcl, s_b); }
                 nseg -= s0;
             }
-            M.out[lane] = s_out; M.lo[lane] = s_lo; M.hi[lane] = s_hi;
-            if (ANNOT) { M.a[lane] = s_a; M.b[lane] = s_b; }
             int pcnt = 0;
-            for (int s = 0; s < npatch; ++s) pcnt += (rdl(p_out, s) < (int)emit_pos) ? 1 : 0;
+            for (int s = 0; s < npatch; ++s) pcnt += (rdl(p_out, s) < emit_pos) ? 1 : 0;
             if (pcnt > 0) {
                 const int srcl = lane + pcnt < WAVE ? lane + pcnt : WAVE - 1;
                 p_out = bperm(srcl, p_out);
@@ -499,6 +561,569 @@ __global__ __launch_bounds__(WG_THREADS) void reconstruct_kernel(const ReconArgs
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------
+// wave64 scans on the DPP network (row_shr 1/2/4/8, row_bcast15, row_bcast31; the
+// gfx9-family sequence LLVM's atomic optimizer emits) -- no LDS round trips.
+// ---------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_mov(int identity, int v) {
+    return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
+}
+struct OpMaxU { static constexpr int identity = 0;  __device__ static int f(int a, int b) { return (int)(((u32)a > (u32)b) ? (u32)a : (u32)b); } };
+struct OpMaxI { static constexpr int identity = -1; __device__ static int f(int a, int b) { return a > b ? a : b; } };
+struct OpAdd  { static constexpr int identity = 0;  __device__ static int f(int a, int b) { return a + b; } };
+// saturating add of values in [0, 2^31): a + b never wraps in u32, clamp to 2^31 - 1
+struct OpSat  { static constexpr int identity = 0;  __device__ static int f(int a, int b) { u32 t = (u32)a + (u32)b; return (int)(t > 0x7FFFFFFFu ? 0x7FFFFFFFu : t); } };
+
+template <typename Op>
+__device__ __forceinline__ int wave_scan_inclusive(int v) {
+    constexpr int id = Op::identity;
+    v = Op::f(v, dpp_mov<0x111, 0xf>(id, v));   // row_shr:1
+    v = Op::f(v, dpp_mov<0x112, 0xf>(id, v));   // row_shr:2
+    v = Op::f(v, dpp_mov<0x114, 0xf>(id, v));   // row_shr:4
+    v = Op::f(v, dpp_mov<0x118, 0xf>(id, v));   // row_shr:8
+    v = Op::f(v, dpp_mov<0x142, 0xa>(id, v));   // row_bcast:15 -> rows 1, 3
+    v = Op::f(v, dpp_mov<0x143, 0xc>(id, v));   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+template <typename Op>
+__device__ __forceinline__ int wave_scan_exclusive(int v) {
+    return dpp_mov<0x138, 0xf>(Op::identity, wave_scan_inclusive<Op>(v));   // wave_shr:1
+}
+
+// ---------------------------------------------------------------------------------
+// Planned path.  A workgroup = 8 waves = 8 rows of one chunk index; wave w owns row w.
+//   P1  lanes 0..7 of wave 0 load the 8 rows' parameters (one lane per row), one barrier
+//   P2  the wave gathers its row's variant records, lane j = variant j
+//   P3  the reference's sequential walk, restated as wave-wide scans (shift == 0):
+//         * "first ALT wins": variant i is applied iff pos_i >= max(ref_idx0, v_end of every
+//           applied variant before it) -- an exclusive prefix-max, iterated to its (unique)
+//           fixed point when deletions knock out later variants
+//         * output offsets of the applied variants: exclusive prefix-sum of
+//           (reference run + allele length) -- the indel shift
+//         * the loop's ">= L" break: applied = prefix of lanes whose allele starts before L
+//         * segment table: one REF run + one ALLELE entry per applied indel (SNPs do not
+//           split a run, they become patches), scattered to LDS at prefix-count slots
+//   P3b lanes 0..7, one per trip, turn the table into trip descriptors: "uniform" trips
+//       (inside ONE reference run) carry the source offset; plus the trip's patch slice
+//   P4  the wave streams its row from the descriptors, all reference loads issued first
+// Rows the scans do not take (shift != 0, > 64 variants, table overflow, extreme
+// coordinates, no fixed point in 4 rounds) run recon_wave_scalar instead.
+// ---------------------------------------------------------------------------------
+struct RowIn {
+    i64 c_s, R, ref_start, shift, o_s, keep_off, row_base;
+    int n_var, L, rc, flags;     // flags: 1 = no work (row out of range / chunk past the row), 2 = scalar path, 4 = zero fill
+};
+template <bool ANNOT>
+struct RowPlan {
+    int s_out[SEG_CAP]; u32 s_lo[SEG_CAP], s_hi[SEG_CAP];
+    int s_a[ANNOT ? SEG_CAP : 1], s_b[ANNOT ? SEG_CAP : 1];
+    int p_out[WAVE], p_val[WAVE], p_id[ANNOT ? WAVE : 1];
+};
+constexpr u32 GENERAL_HI = 0x80000000u;
+
+#ifdef GVL_DIAG
+#define GVL_STAMP(i) do { if (A.stamps && tid == 0) A.stamps[((u64)blockIdx.x * gridDim.y + blockIdx.y) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GVL_STAMP(i) do { } while (0)
+#endif
+
+template <int OH, bool HAPS, bool ANNOT>
+__global__ __launch_bounds__(WG_THREADS) void reconstruct_kernel(const ReconArgs A) {
+    __shared__ Luts luts;
+    __shared__ SegMirror mirror[WG_WAVES];
+    __shared__ Stage<ANNOT> stage[WG_WAVES];
+    __shared__ RowIn rin[WG_WAVES];
+    __shared__ RowPlan<ANNOT> plan[WG_WAVES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wave = rfl(tid >> 6);
+    const int chunk = blockIdx.y;
+    const int lo_clip = chunk * A.chunk_len;
+    const bool has_keep = A.keep && A.keep_offsets;
+    const bool planned_ok = A.chunk_len <= CHUNK_TRIPS * TRIP && !(A.dbg & 8);
+
+    GVL_STAMP(0);
+    if (tid < 256) {  // LUTs
+        const u32 d = onehot_dword((u32)tid);
+        luts.oh[tid] = d;
+        luts.oh_rc[tid] = __builtin_bswap32(d);
+        luts.comp[tid] = comp_byte((u32)tid);
+    }
+    // ---- P1: row parameters, one lane per row --------------------------------------
+    if (tid < WG_WAVES) {
+        RowIn ri;
+        ri.c_s = ri.R = ri.ref_start = ri.shift = ri.o_s = ri.keep_off = ri.row_base = 0;
+        ri.n_var = ri.L = ri.rc = 0;
+        ri.flags = 1;
+        const i64 k = (i64)blockIdx.x * WG_WAVES + tid;
+        if (k < A.n_rows) {
+            const i64 query = A.ploidy_shift >= 0 ? (k >> A.ploidy_shift) : (i64)((u32)k / (u32)A.ploidy);
+            const int *reg = A.regions + query * A.regions_stride;
+            const i64 c_idx = reg[0];
+            ri.ref_start = reg[1];
+            i64 o_idx = 0;
+            int fl = 0;
+            if (!A.ref_only) {
+                ri.shift = A.shifts[k];
+                o_idx = A.geno_offset_idx[k];
+            } else if (ri.ref_start >= (i64)reg[2]) {
+                fl |= 4;                                 // reference/mod.rs:16-18
+            }
+            ri.rc = A.to_rc ? (int)A.to_rc[k] : 0;
+            if (A.out_offsets) {
+                ri.row_base = A.out_offsets[k];
+                ri.L = (int)(A.out_offsets[k + 1] - ri.row_base);
+            } else {
+                ri.row_base = k * A.fixed_len;
+                ri.L = (int)A.fixed_len;
+            }
+            if (A.out_offsets_w && chunk == 0) {
+                A.out_offsets_w[k] = ri.row_base;
+                if (k == A.n_rows - 1) A.out_offsets_w[k + 1] = ri.row_base + ri.L;
+            }
+            if (lo_clip >= ri.L) {
+                fl |= 1;
+            } else {
+                ri.c_s = A.ref_offsets[c_idx];
+                ri.R = A.ref_offsets[c_idx + 1] - ri.c_s;
+                if (!A.ref_only) {
+                    ri.o_s = A.go_starts[o_idx];
+                    const i64 nv = A.go_stops[o_idx] - ri.o_s;
+                    ri.n_var = nv < 0 ? 0 : (nv > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)nv);
+                    if (A.dbg & 1) ri.n_var = 0;
+                    if (has_keep) ri.keep_off = A.keep_offsets[k];
+                }
+                if (ri.n_var > WAVE || ri.shift != 0 || !planned_ok) fl |= 2;
+            }
+            ri.flags = fl;
+        }
+        rin[tid] = ri;
+    }
+    GVL_STAMP(1);
+    __syncthreads();
+
+    GVL_STAMP(2);
+    const RowIn &ri = rin[wave];
+    int flags = rfl(ri.flags);
+    if (flags & 1) return;
+    const i64 k = (i64)blockIdx.x * WG_WAVES + wave;
+    RowPlan<ANNOT> &pl = plan[wave];
+    Stage<ANNOT> &G = stage[wave];
+    const int L = rfl(ri.L);
+    const i64 c_s = rfl64(ri.c_s);
+    const int hi_clip = (L - lo_clip > A.chunk_len) ? lo_clip + A.chunk_len : L;
+    int nseg = 0, npatch = 0;
+
+    if (!(flags & 2)) {
+        // ---- P2: variant records (lane j = variant j) --------------------------------------
+        const int n_var = rfl(ri.n_var);
+        const i64 o_s = rfl64(ri.o_s);
+        const int ref_start = (int)rfl64(ri.ref_start);
+        const i64 R = rfl64(ri.R);
+        int pos = 0, d = 0, alen = 0, inl = 0, vi = 0; i64 a0 = 0;
+        bool valid = lane < n_var;
+        if (valid) {
+            int v = A.geno_v_idxs[o_s + lane];
+            v = v < 0 ? 0 : ((i64)v >= A.n_variants ? (int)(A.n_variants - 1) : v);
+            const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.vrec + v);
+            a0 = A.alt_offsets[v];
+            pos = rec.x; d = rec.y; alen = rec.z; inl = rec.w; vi = v;
+            if (has_keep) valid = A.keep[rfl64(ri.keep_off) + lane] != 0;
+        }
+        GVL_STAMP(3);
+        // ---- P3: the walk as scans (reconstruct/mod.rs:61-255 with shift == 0) ------------------
+        // coordinates beyond 2^30 (or nonsense) go to the scalar path: everything below is i32
+        const bool weird = valid && (pos < 0 || pos >= (1 << 30) || d <= -(1 << 30) || d >= (1 << 30) ||
+                                     alen < 0 || alen >= (1 << 30));
+        bool ok = __builtin_amdgcn_ballot_w64(weird) == 0 && ref_start > -(1 << 30) && ref_start < (1 << 30);
+        const int E = pos - (d < 0 ? d : 0) + 1;                        // v_ref_end, :96
+        const int n_lead = ref_start < 0 ? ((-ref_start < L) ? -ref_start : L) : 0;   // :68-83
+        int ref_idx0 = ref_start < 0 ? 0 : ref_start;
+        // DEL spanning the window start (:99-102): the last one in order sets ref_idx
+        const u64 m_span = __builtin_amdgcn_ballot_w64(valid && pos < ref_start && d < 0 && E >= ref_start);
+        if (m_span) ref_idx0 = rdl(E, 63 - __builtin_clzll(m_span));
+        const bool cand = valid && pos >= ref_start;
+        // first ALT wins (:108-110): fixed point of B = {i : pos_i >= max(ref_idx0, max E over B before i)}
+        bool inB = cand;
+        int PM = 0;
+        {
+            u64 mB = __builtin_amdgcn_ballot_w64(inB);
+            bool stable = false;
+#pragma unroll 1
+            for (int it = 0; it < 4 && !stable; ++it) {
+                PM = wave_scan_exclusive<OpMaxU>(inB ? E : 0);
+                PM = PM > ref_idx0 ? PM : ref_idx0;
+                inB = cand && pos >= PM;
+                const u64 m2 = __builtin_amdgcn_ballot_w64(inB);
+                stable = m2 == mB;
+                mB = m2;
+            }
+            ok = ok && stable;
+        }
+        // output offsets: exclusive prefix sum of (reference run + allele)      (the indel shift)
+        const int n_i = inB ? pos - PM : 0;
+        const int X = wave_scan_exclusive<OpSat>(inB ? OpSat::f(n_i, alen) : 0);
+        const int allele_out = OpSat::f(OpSat::f(n_lead, X), n_i);
+        const bool applied = inB && allele_out < L;                       // :154-158 break
+        const int w_i = applied ? ((alen < L - allele_out) ? alen : L - allele_out) : 0;   // :178
+        const bool is_snp = d == 0 && alen == 1;
+        const bool nonsnp = applied && !is_snp;
+        const bool snp = applied && is_snp;
+        // state after the loop
+        const u64 m_app = __builtin_amdgcn_ballot_w64(applied);
+        int ref_idx_end = ref_idx0, out_idx_end = n_lead;
+        if (m_app) {
+            const int last = 63 - __builtin_clzll(m_app);
+            ref_idx_end = rdl(E, last);
+            out_idx_end = rdl(allele_out, last) + rdl(w_i, last);
+        }
+        // the reference run in front of each applied indel starts after the previous applied indel
+        const int prevNS = wave_scan_exclusive<OpMaxI>(nonsnp ? lane : -1);
+        const int pidx = prevNS < 0 ? 0 : prevNS;
+        const int p_end = bperm(pidx, allele_out + alen);                 // not truncated: it has a successor
+        const int p_E = bperm(pidx, E);
+        const int run_start = prevNS < 0 ? n_lead : p_end;
+        const i64 run_src = c_s + (prevNS < 0 ? ref_idx0 : p_E);
+        const bool e_ref = nonsnp && allele_out > run_start && allele_out > lo_clip && run_start < hi_clip;
+        const bool e_all = nonsnp && w_i > 0 && allele_out + w_i > lo_clip && allele_out < hi_clip;
+        const int lead_kept = (n_lead > 0 && n_lead > lo_clip && 0 < hi_clip) ? 1 : 0;
+        const int slot0 = lead_kept + wave_scan_exclusive<OpAdd>((e_ref ? 1 : 0) + (e_all ? 1 : 0));
+        const u64 m_ns = __builtin_amdgcn_ballot_w64(nonsnp);
+        int n_ent = lead_kept;
+        {
+            const u64 m1 = __builtin_amdgcn_ballot_w64(e_ref), m2 = __builtin_amdgcn_ballot_w64(e_all);
+            n_ent += __builtin_popcountll(m1) + __builtin_popcountll(m2);
+        }
+        // tail: the run after the last applied indel (through any SNPs) + contig end + right pad (:200-255)
+        int t_start = n_lead; i64 t_src = c_s + ref_idx0;
+        if (m_ns) {
+            const int last = 63 - __builtin_clzll(m_ns);
+            t_start = rdl(allele_out, last) + rdl(alen, last);
+            t_src = c_s + rdl(E, last);
+        }
+        int t_end = out_idx_end;
+        {
+            const int u = L - out_idx_end;
+            if (u > 0) {
+                const i64 avail = R - ref_idx_end;
+                const int w = (int)imin((i64)u, avail);
+                if (w > 0) t_end = out_idx_end + w;
+            }
+        }
+        const bool tail_ref = t_end > t_start && t_end > lo_clip && t_start < hi_clip;
+        const bool tail_pad = t_end < L && L > lo_clip && t_end < hi_clip;
+        const int n_total = n_ent + (tail_ref ? 1 : 0) + (tail_pad ? 1 : 0);
+        const u64 m_snp = __builtin_amdgcn_ballot_w64(snp && allele_out >= lo_clip && allele_out < hi_clip);
+        ok = ok && n_total <= SEG_CAP;
+        if (ok) {
+            auto enc = [](u32 kind, i64 delta, u32 &lo, u32 &hi) {
+                const u64 e = (u64)(delta + DELTA_BIAS) | ((u64)kind << 62);
+                lo = (u32)e; hi = (u32)(e >> 32);
+            };
+            if (lane == 0) {
+                if (lead_kept) {
+                    u32 lo, hi; enc(K_PAD_LEAD, 0, lo, hi);
+                    pl.s_out[0] = 0; pl.s_lo[0] = lo; pl.s_hi[0] = hi;
+                    if (ANNOT) { pl.s_a[0] = -1; pl.s_b[0] = -1; }
+                }
+                int q = n_ent;
+                if (tail_ref) {
+                    u32 lo, hi; enc(K_REF, t_src - t_start, lo, hi);
+                    pl.s_out[q] = t_start; pl.s_lo[q] = lo; pl.s_hi[q] = hi;
+                    if (ANNOT) { pl.s_a[q] = -1; pl.s_b[q] = -1; }
+                    ++q;
+                }
+                if (tail_pad) {
+                    u32 lo, hi; enc(K_PAD_TRAIL, 0, lo, hi);
+                    pl.s_out[q] = t_end; pl.s_lo[q] = lo; pl.s_hi[q] = hi;
+                    if (ANNOT) { pl.s_a[q] = -1; pl.s_b[q] = -1; }
+                }
+            }
+            int q = slot0;
+            if (e_ref) {
+                u32 lo, hi; enc(K_REF, run_src - run_start, lo, hi);
+                pl.s_out[q] = run_start; pl.s_lo[q] = lo; pl.s_hi[q] = hi;
+                if (ANNOT) { pl.s_a[q] = -1; pl.s_b[q] = -1; }
+                ++q;
+            }
+            if (e_all) {
+                u32 lo, hi; enc(K_ALLELE, a0 - allele_out, lo, hi);
+                pl.s_out[q] = allele_out; pl.s_lo[q] = lo; pl.s_hi[q] = hi;
+                if (ANNOT) { pl.s_a[q] = vi; pl.s_b[q] = pos; }
+            }
+            if ((m_snp >> lane) & 1ull) {
+                const int ps = __builtin_popcountll(m_snp & ((1ull << lane) - 1ull));
+                pl.p_out[ps] = allele_out; pl.p_val[ps] = inl & 0xFF;
+                if (ANNOT) pl.p_id[ps] = vi;
+            }
+            nseg = n_total;
+            npatch = __builtin_popcountll(m_snp);
+        } else {
+            flags |= 2;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    GVL_STAMP(4);
+#ifdef GVL_DIAG
+    if (A.stamps && lane == 0 && (flags & 2)) atomicAdd((unsigned long long *)&A.stamps[((u64)blockIdx.x * gridDim.y + blockIdx.y) * 8 + 7], 1ull);
+#endif
+    if (flags & 2) {
+        recon_wave_scalar<OH, HAPS, ANNOT>(A, luts, mirror[wave], stage[wave], k, chunk, lane);
+        return;
+    }
+
+    // ---- P3b: trip descriptors, lane u = trip u of this row -------------------------------
+    const bool ref_zero_fill = (flags & 4) != 0;
+    const int limit = hi_clip;
+    u32 d_lo = 0, d_hi = GENERAL_HI; int d_pc0 = 0, d_pcn = 0, d_idx = 0;
+    if (lane < CHUNK_TRIPS) {
+        const int p0 = lo_clip + lane * TRIP;
+        if (p0 < limit) {
+            const int t_end = (limit - p0 > TRIP) ? p0 + TRIP : limit;
+            int idx = 0;
+            for (int s2 = 1; s2 < nseg; ++s2) idx += (pl.s_out[s2] <= p0) ? 1 : 0;
+            const int nxt = idx + 1 < nseg ? pl.s_out[idx + 1] : limit;
+            const u32 hi = pl.s_hi[idx];
+            const i64 src0 = seg_delta(pl.s_lo[idx], hi) + p0;
+            const bool uniform = (hi >> 30) == K_REF && nxt >= t_end && ((t_end - p0) & 3) == 0 && src0 >= 0 &&
+                                 src0 + (t_end - p0) <= A.ref_len && !ref_zero_fill;
+            for (int q = 0; q < npatch; ++q) {
+                const int pp = pl.p_out[q];
+                d_pc0 += pp < p0 ? 1 : 0;
+                d_pcn += pp < t_end ? 1 : 0;
+            }
+            d_lo = (u32)(u64)src0;
+            d_idx = idx;
+            if (uniform) d_hi = (u32)((u64)src0 >> 32);
+        }
+    }
+    GVL_STAMP(5);
+
+    // ---- P4: stream ----------------------------------------------------------------------
+    const bool rc = rfl(ri.rc) != 0;
+    const i64 row_base = rfl64(ri.row_base);
+    const u32 padb = A.pad & 0xFFu;
+    const u32 rc_sel = rc ? 0x00010203u : 0x03020100u;
+    const u32 *oh_t = rc ? luts.oh_rc : luts.oh;
+    const int lane_pos = rc ? -GROUP * lane : GROUP * lane;
+    u8 *hap_row = HAPS ? A.haps + row_base : nullptr;
+    u8 *oh_row = OH != OH_NONE ? A.onehot + 4 * row_base : nullptr;
+    int *av_row = (ANNOT && A.av) ? A.av + row_base : nullptr;
+    int *ap_row = (ANNOT && A.ap) ? A.ap + row_base : nullptr;
+
+    // finish one trip: SNP patches, reverse-complement, one-hot LUT, stores
+    auto finish = [&](const int p0, const int pc0, const int pcn, u32 wv, int (&av4)[GROUP], int (&ap4)[GROUP]) {
+        const int p = p0 + GROUP * lane;
+        const bool act = p < limit;
+        const bool full = p + GROUP <= limit;
+        for (int q = pc0; q < pcn; ++q) {
+            const u32 dd = (u32)(pl.p_out[q] - p);
+            if (dd < (u32)GROUP) {
+                const u32 sh = dd * 8;
+                wv = (wv & ~(0xFFu << sh)) | ((u32)pl.p_val[q] << sh);
+            }
+            if (ANNOT) {
+                const int pid = pl.p_id[q];
+#pragma unroll
+                for (int i = 0; i < GROUP; ++i) if (dd == (u32)i) av4[i] = pid;
+            }
+        }
+        if (full && !(A.dbg & 2)) {
+            const int jo = (rc ? L - GROUP - p0 : p0) + lane_pos;
+            const u32 ww = __builtin_amdgcn_perm(0u, wv, rc_sel);
+            const u32 b0_ = ww & 0xFF, b1_ = (ww >> 8) & 0xFF, b2_ = (ww >> 16) & 0xFF, b3_ = ww >> 24;
+            if (OH == OH_LC) {
+                u32x4_a4 o = {oh_t[b0_], oh_t[b1_], oh_t[b2_], oh_t[b3_]};
+                *reinterpret_cast<u32x4_a4 *>(oh_row + 4 * (i64)jo) = o;
+            } else if (OH == OH_CL) {
+                const u32 d0 = oh_t[b0_], d1 = oh_t[b1_], d2 = oh_t[b2_], d3 = oh_t[b3_];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const u32 sh = 8 * a;
+                    const u32 v = ((d0 >> sh) & 0xFF) | (((d1 >> sh) & 0xFF) << 8) |
+                                  (((d2 >> sh) & 0xFF) << 16) | (((d3 >> sh) & 0xFF) << 24);
+                    __builtin_memcpy(oh_row + (i64)a * L + jo, &v, 4);
+                }
+            }
+            if (HAPS) {
+                u32 hv = ww;
+                if (rc) hv = luts.comp[b0_] | (luts.comp[b1_] << 8) | (luts.comp[b2_] << 16) | (luts.comp[b3_] << 24);
+                __builtin_memcpy(hap_row + jo, &hv, 4);
+            }
+            if (ANNOT) {
+                if (av_row) {
+                    i32x4_a4 o = rc ? i32x4_a4{av4[3], av4[2], av4[1], av4[0]} : i32x4_a4{av4[0], av4[1], av4[2], av4[3]};
+                    *reinterpret_cast<i32x4_a4 *>(av_row + jo) = o;
+                }
+                if (ap_row) {
+                    i32x4_a4 o = rc ? i32x4_a4{ap4[3], ap4[2], ap4[1], ap4[0]} : i32x4_a4{ap4[0], ap4[1], ap4[2], ap4[3]};
+                    *reinterpret_cast<i32x4_a4 *>(ap_row + jo) = o;
+                }
+            }
+        }
+        if (limit & 3) {
+            // partial group at the row end (L % 4 != 0): per-base stores by lanes 0..(L&3)-1
+            const int p_last = limit & ~3;
+            if (p_last >= p0 && p_last < p0 + TRIP) {
+                if (act && !full) {
+                    G.w[0] = wv;
+                    if (ANNOT) {
+#pragma unroll
+                        for (int i = 0; i < GROUP; ++i) { G.av[i][0] = av4[i]; G.ap[i][0] = ap4[i]; }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < (limit & 3)) {
+                    const int pp = p_last + lane;
+                    const u32 b = (G.w[0] >> (8 * lane)) & 0xFF;
+                    const i64 jo = rc ? (i64)(L - 1 - pp) : (i64)pp;
+                    if (OH != OH_NONE) {
+                        const u32 dd = oh_t[b];
+                        if (OH == OH_LC) {
+                            __builtin_memcpy(oh_row + 4 * jo, &dd, 4);
+                        } else {
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) oh_row[(i64)a * L + jo] = (u8)((dd >> (8 * a)) & 0xFF);
+                        }
+                    }
+                    if (HAPS) hap_row[jo] = (u8)(rc ? luts.comp[b] : b);
+                    if (ANNOT) {
+                        if (av_row) av_row[jo] = G.av[lane][0];
+                        if (ap_row) ap_row[jo] = G.ap[lane][0];
+                    }
+                }
+            }
+        }
+    };
+
+    // pass A: all reference loads of the uniform trips first (they are independent)
+    u32 wq[CHUNK_TRIPS];
+    u32 gmask = 0;
+#pragma unroll
+    for (int u = 0; u < CHUNK_TRIPS; ++u) {
+        wq[u] = 0;
+        const int p0 = lo_clip + u * TRIP;
+        if (p0 < limit) {
+            const u32 bhi = (u32)rdl((int)d_hi, u);
+            if (bhi != GENERAL_HI) {
+                const i64 base = (i64)(((u64)bhi << 32) | (u32)rdl((int)d_lo, u));
+                if (p0 + GROUP * lane < limit && !(A.dbg & 4)) wq[u] = load_u32_unaligned(A.ref + base + (u32)(GROUP * lane));
+            } else {
+                gmask |= 1u << u;
+            }
+        }
+    }
+    // pass G: general trips (a segment boundary / allele / pad / row end inside the trip).
+    // A group of 4 bases overlaps at most 4 segments; each contributes one masked dword
+    // load from ITS source, so the group costs one memory latency, not one per byte.
+    while (gmask) {
+        const int u = __builtin_ctz(gmask);
+        gmask &= gmask - 1;
+        const int p0 = lo_clip + u * TRIP;
+        const int p = p0 + GROUP * lane;
+        u32 wv = 0;
+        int av4[GROUP], ap4[GROUP];
+        if (ANNOT) {
+#pragma unroll
+            for (int i = 0; i < GROUP; ++i) { av4[i] = -1; ap4[i] = -1; }
+        }
+        if (p < limit) {
+            int seg = __builtin_amdgcn_readlane(d_idx, u);
+            while (seg + 1 < nseg && pl.s_out[seg + 1] <= p) ++seg;
+            const int g_end = (limit - p > GROUP) ? p + GROUP : limit;
+            int cur = p;
+            u32 words[GROUP], masks[GROUP];
+#pragma unroll
+            for (int t = 0; t < GROUP; ++t) {
+                words[t] = 0; masks[t] = 0;
+                if (cur < g_end) {
+                    const u32 lo = pl.s_lo[seg], hi = pl.s_hi[seg];
+                    const u32 kind = hi >> 30;
+                    const int s_end = seg + 1 < nseg ? pl.s_out[seg + 1] : limit;
+                    const int e = s_end < g_end ? s_end : g_end;
+                    const u32 m_hi = (e - p) >= 4 ? 0xFFFFFFFFu : ((1u << (8 * (e - p))) - 1u);
+                    const u32 m_lo = (1u << (8 * (cur - p))) - 1u;
+                    masks[t] = m_hi & ~m_lo;
+                    const i64 src = seg_delta(lo, hi) + p;
+                    if (ref_zero_fill) {
+                        words[t] = 0;
+                    } else if (kind == K_REF || kind == K_ALLELE) {
+                        const u8 *arr = kind == K_REF ? A.ref : A.alt_alleles;
+                        const i64 alen_ = kind == K_REF ? A.ref_len : A.alt_len;
+                        if (src >= 0 && src + GROUP <= alen_) {
+                            words[t] = load_u32_unaligned(arr + src);
+                        } else {   // array edge: byte by byte, out of range -> pad
+                            u32 wb = 0;
+#pragma unroll
+                            for (int i = 0; i < GROUP; ++i) {
+                                const i64 s2 = src + i;
+                                const u32 bb = (p + i >= cur && p + i < e && s2 >= 0 && s2 < alen_) ? (u32)arr[s2] : padb;
+                                wb |= bb << (8 * i);
+                            }
+                            words[t] = wb;
+                        }
+                    } else {
+                        words[t] = padb * 0x01010101u;
+                    }
+                    if (ANNOT) {
+#pragma unroll
+                        for (int i = 0; i < GROUP; ++i) {
+                            if (p + i >= cur && p + i < e) {
+                                if (kind == K_REF) { av4[i] = -1; ap4[i] = (int)(src - c_s) + i; }
+                                else if (kind == K_ALLELE) { av4[i] = pl.s_a[seg]; ap4[i] = pl.s_b[seg]; }
+                                else { av4[i] = -1; ap4[i] = kind == K_PAD_LEAD ? -1 : 2147483647; }
+                            }
+                        }
+                    }
+                    cur = e;
+                    ++seg;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < GROUP; ++t) wv |= words[t] & masks[t];
+        }
+        finish(p0, rdl(d_pc0, u), rdl(d_pcn, u), wv, av4, ap4);
+    }
+    // pass B: finish the uniform trips
+#pragma unroll
+    for (int u = 0; u < CHUNK_TRIPS; ++u) {
+        const int p0 = lo_clip + u * TRIP;
+        if (p0 < limit && (u32)rdl((int)d_hi, u) != GENERAL_HI) {
+            int av4[GROUP], ap4[GROUP];
+            if (ANNOT) {
+                const i64 base = (i64)(((u64)(u32)rdl((int)d_hi, u) << 32) | (u32)rdl((int)d_lo, u));
+                const int apb = (int)(base - c_s) + GROUP * lane;
+#pragma unroll
+                for (int i = 0; i < GROUP; ++i) { av4[i] = -1; ap4[i] = apb + i; }
+            }
+            finish(p0, rdl(d_pc0, u), rdl(d_pcn, u), wq[u], av4, ap4);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    GVL_STAMP(6);
+}
+
+#undef GVL_STAMP
+typedef void (*recon_fn)(const ReconArgs);
+static recon_fn recon_table(int oh, bool haps, bool annot) {
+#define GVL_K(o, h, a) reconstruct_kernel<o, h, a>
+    if (annot) {
+        if (oh == OH_NONE) return GVL_K(OH_NONE, true, true);
+        if (oh == OH_LC) return haps ? GVL_K(OH_LC, true, true) : GVL_K(OH_LC, false, true);
+        return haps ? GVL_K(OH_CL, true, true) : GVL_K(OH_CL, false, true);
+    }
+    if (oh == OH_NONE) return GVL_K(OH_NONE, true, false);
+    if (oh == OH_LC) return haps ? GVL_K(OH_LC, true, false) : GVL_K(OH_LC, false, false);
+    return haps ? GVL_K(OH_CL, true, false) : GVL_K(OH_CL, false, false);
+#undef GVL_K
 }
 
 // ---------------------------------------------------------------------------
@@ -689,6 +1314,7 @@ __global__ __launch_bounds__(256) void onehot_kernel(const u8 *in, i64 n, u8 *ou
 // host side of the C-ABI
 // ---------------------------------------------------------------------------
 thread_local char g_err[512] = "";
+u64 *g_stamps = nullptr;
 
 int fail(int code, const char *fmt, const char *what) {
     snprintf(g_err, sizeof(g_err), fmt, what);
@@ -705,16 +1331,26 @@ int check_launch(const char *what) {
 }
 
 int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
-    // one wave owns `chunk_len` bases of a row; rows up to 4096 bp are one chunk
+    // one wave owns `chunk_len` bases of a row (blockIdx.y = chunk, so <= 65535 chunks);
+    // rows up to 2048 bp are one chunk (= CHUNK_TRIPS trips, what the planned path handles)
     i64 cl = 2048;
-    if (max_len <= 4096) cl = ((max_len + TRIP - 1) / TRIP) * TRIP;
+    if (max_len <= 2048) cl = ((max_len + TRIP - 1) / TRIP) * TRIP;
     if (cl < TRIP) cl = TRIP;
     i64 c = (max_len + cl - 1) / cl;
+    if (c > 65535) {
+        cl = (((max_len + 65534) / 65535 + 2047) / 2048) * 2048;
+        c = (max_len + cl - 1) / cl;
+    }
     if (c < 1) c = 1;
-    if (c > 0x7FFFFFFF) return 1;
+    if (c > 65535 || cl > 0x7FFFFF00ll) return 1;
     *chunks = (int)c;
     *chunk_len = (int)cl;
     return 0;
+}
+
+int log2_exact(i64 v) {
+    for (int s = 0; s < 31; ++s) if ((1ll << s) == v) return s;
+    return -1;
 }
 
 }  // namespace
@@ -722,6 +1358,9 @@ int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
 extern "C" {
 
 int gvl_abi_version(void) { return GVL_ABI_VERSION; }
+#ifdef GVL_DIAG
+void gvl_diag_set_stamps(void *buf) { g_stamps = (u64 *)buf; }
+#endif
 const char *gvl_last_error(void) { return g_err; }
 
 int gvl_pack_variants(const int32_t *v_starts, const int32_t *ilens, const int64_t *alt_offsets,
@@ -769,28 +1408,29 @@ int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *ou
     A.keep = bt->keep; A.keep_offsets = (const i64 *)bt->keep_offsets; A.to_rc = bt->to_rc;
     A.out_offsets = (const i64 *)bt->out_offsets;
     A.fixed_len = bt->out_offsets ? -1 : bt->output_length;
-    A.n_queries = bt->batch; A.ploidy = (int)bt->ploidy;
+    A.n_rows = bt->batch * bt->ploidy; A.ploidy = (int)bt->ploidy; A.ploidy_shift = log2_exact(bt->ploidy);
     // longest row: fixed mode -> output_length; caller-supplied offsets -> the
     // caller's max_row_len hint (must bound every row, or longer rows are left
     // partly unwritten)
     i64 ml = bt->out_offsets ? bt->max_row_len : bt->output_length;
     if (bt->out_offsets && bt->output_length > ml) ml = bt->output_length;
     if (ml < 0) ml = 0;
-    if (pick_chunk(ml, &A.chunks, &A.chunk_len)) return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: too many chunks");
+    int chunks = 1;
+    if (pick_chunk(ml, &chunks, &A.chunk_len)) return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: too many chunks");
     A.ref_only = 0;
+    { const char *e = getenv("GVL_DBG"); A.dbg = e ? atoi(e) : 0; }
     A.pad = st->pad_char;
-    A.haps = out->haps; A.onehot = out->onehot; A.onehot_cl = out->onehot_layout == GVL_ONEHOT_CL;
+    A.haps = out->haps; A.onehot = out->onehot;
     A.av = out->annot_v_idxs; A.ap = out->annot_ref_pos; A.out_offsets_w = (i64 *)out->out_offsets;
+    A.stamps = g_stamps;
 
-    const i64 units = bt->batch * bt->ploidy * (i64)A.chunks;
-    const i64 grid = (units + WG_WAVES - 1) / WG_WAVES;
+    const i64 grid = (A.n_rows + WG_WAVES - 1) / WG_WAVES;
     if (grid <= 0) return GVL_OK;
-    if (grid > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: batch too large for one launch");
+    if (A.n_rows > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: batch too large for one launch");
     const bool annot = out->annot_v_idxs || out->annot_ref_pos;
-    if (annot)
-        hipLaunchKernelGGL(reconstruct_kernel<true>, dim3((unsigned)grid), dim3(WG_THREADS), 0, (hipStream_t)stream, A);
-    else
-        hipLaunchKernelGGL(reconstruct_kernel<false>, dim3((unsigned)grid), dim3(WG_THREADS), 0, (hipStream_t)stream, A);
+    const int oh = !out->onehot ? OH_NONE : (out->onehot_layout == GVL_ONEHOT_CL ? OH_CL : OH_LC);
+    recon_fn fn = recon_table(oh, out->haps != nullptr, annot);
+    fn<<<dim3((unsigned)grid, (unsigned)chunks), dim3(WG_THREADS), 0, (hipStream_t)stream>>>(A);
     return check_launch("gvl_reconstruct");
 }
 
@@ -808,15 +1448,16 @@ int gvl_get_reference(const gvl_static *st, const int32_t *regions, int64_t regi
     A.ref = st->ref; A.ref_len = st->ref_len; A.ref_offsets = (const i64 *)st->ref_offsets;
     A.regions = regions; A.regions_stride = regions_stride;
     A.to_rc = to_rc; A.out_offsets = (const i64 *)out_offsets; A.fixed_len = -1;
-    A.n_queries = n_rows; A.ploidy = 1;
-    if (pick_chunk(max_row_len, &A.chunks, &A.chunk_len)) return fail(GVL_ERR_INVALID, "%s", "gvl_get_reference: too many chunks");
+    A.n_rows = n_rows; A.ploidy = 1; A.ploidy_shift = 0;
+    int chunks = 1;
+    if (pick_chunk(max_row_len, &chunks, &A.chunk_len)) return fail(GVL_ERR_INVALID, "%s", "gvl_get_reference: too many chunks");
     A.ref_only = 1;
     A.pad = st->pad_char;
     A.haps = out; A.onehot = onehot;
-    const i64 units = n_rows * (i64)A.chunks;
-    const i64 grid = (units + WG_WAVES - 1) / WG_WAVES;
-    if (grid > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_get_reference: batch too large");
-    hipLaunchKernelGGL(reconstruct_kernel<false>, dim3((unsigned)grid), dim3(WG_THREADS), 0, (hipStream_t)stream, A);
+    const i64 grid = (n_rows + WG_WAVES - 1) / WG_WAVES;
+    if (n_rows > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_get_reference: batch too large");
+    recon_fn fn = recon_table(onehot ? OH_LC : OH_NONE, out != nullptr, false);
+    fn<<<dim3((unsigned)grid, (unsigned)chunks), dim3(WG_THREADS), 0, (hipStream_t)stream>>>(A);
     return check_launch("gvl_get_reference");
 }
 

@@ -1,0 +1,32 @@
+"""Phase timeline of the planned kernel (diagnostic build: tools/libgvl_hip_diag.so)."""
+import ctypes as C, os, sys
+os.environ["GVL_HIP_LIB"] = os.path.join(os.path.dirname(__file__), "libgvl_hip_diag.so")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from genvarloader_amd import HapsDevice, synth, _lib
+wl = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+st, bt = synth.make_config(wl)
+dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens, alt_alleles=st.alt_alleles,
+                 alt_offsets=st.alt_offsets, geno_offsets=bt.geno_offsets, geno_v_idxs=bt.geno_v_idxs, pad_char=st.pad_char)
+dbt = dev.prepare_batch(bt.regions, bt.shifts, bt.geno_offset_idx, bt.output_length, to_rc=bt.to_rc)
+out, oc = dev.alloc_output(dbt, bt.n_windows * bt.output_length, haps=False, onehot=True)
+nwg = (bt.n_windows + 7) // 8
+stamps = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
+lib = _lib.load()
+for i in range(20): dev.launch(dbt, oc)
+torch.cuda.synchronize()
+lib.gvl_diag_set_stamps(C.c_void_p(stamps.data_ptr()))
+dev.launch(dbt, oc); torch.cuda.synchronize()
+s = stamps.cpu().numpy().reshape(nwg, 8).astype(np.float64) * 10.0  # memrealtime ticks of 100 MHz -> ns
+t0 = s[:, 0].min()
+names = ["start", "P1 done", "sync", "P2 recs", "P3 scans", "P3b desc", "end(wave0)"]
+for i, n in enumerate(names):
+    col = s[:, i] - t0
+    print(f"{n:16s} min {col.min():8.0f}  median {np.median(col):8.0f}  max {col.max():8.0f} ns")
+d = np.diff(s[:, :7], axis=1)
+print("per-WG phase durations (median ns):", np.median(d, axis=0).round(0))
+
+nfb = stamps.cpu().numpy().reshape(nwg, 8)[:, 7]
+print("rows on the scalar path:", int(nfb.sum()), "of", bt.n_windows, "; WGs with >=1:", int((nfb > 0).sum()))
+end = s[:, 6] - s[:, 0]
+print("wave0 end-start median ns: WGs without fallback", np.median(end[nfb == 0]).round(0), " with fallback", np.median(end[nfb > 0]).round(0) if (nfb>0).any() else None)
