@@ -93,7 +93,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--slots", type=int, default=2, help="output ring slots")
-    ap.add_argument("--streams", type=int, default=1, help="HIP streams the batches alternate over")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="batches kept in flight (one HIP stream each) in the timed region")
     args = ap.parse_args()
 
     import torch
@@ -124,39 +125,53 @@ def main() -> None:
     slots = [dev.alloc_output(dbt, K * L, haps=args.haps, onehot=True) for _ in range(max(1, args.slots))]
     stream = torch.cuda.current_stream()
     streams = [stream] + [torch.cuda.Stream() for _ in range(max(0, args.streams - 1))]
-    n_slots = max(len(slots), len(streams))
-    while len(slots) < n_slots:
+    while len(slots) < len(streams) + 1:      # an output slot per batch in flight (+1 being consumed)
         slots.append(dev.alloc_output(dbt, K * L, haps=args.haps, onehot=True))
 
-    def step(i: int) -> None:
-        dev.launch(dbt, slots[i % len(slots)][1], streams[i % len(streams)])
+    def step(i: int, pipelined: bool = True) -> None:
+        # a batch is independent of the previous one: the loader keeps `--streams` batches in
+        # flight on separate HIP streams, so the latency-bound head of one batch (parameter
+        # and variant gathers, scans) overlaps the store-bound tail of another
+        dev.launch(dbt, slots[i % len(slots)][1], streams[i % len(streams)] if pipelined else stream)
 
     def barrier() -> None:
         if dist is not None:
             dist.barrier()
 
+    def join() -> None:
+        for st_ in streams[1:]:
+            stream.wait_stream(st_)
+
+    # ---- warmup, then EXACTLY K timed steps ---------------------------------------------
     for i in range(args.warmup):
         step(i)
+    join()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record(stream)
     for i in range(args.steps):
         step(i)
-    for st_ in streams[1:]:
-        stream.wait_stream(st_)
-    ev1.record(stream)
+    join()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
     torch.cuda.synchronize()
-
     wall = t1 - t0
-    kern_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
+
+    # ---- the kernel's own duration: same K launches back to back on ONE stream, HIP events on
+    # that stream (this is what `rocprofv3 --kernel-trace --stats` reports per launch) -----------
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    for i in range(min(args.warmup, 10)):
+        step(i, pipelined=False)
+    torch.cuda.synchronize()
+    ev0.record(stream)
+    for i in range(args.steps):
+        step(i, pipelined=False)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    kern_ms = ev0.elapsed_time(ev1) / args.steps
     if dist is not None:
         tt = torch.tensor([wall, kern_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -184,12 +199,15 @@ def main() -> None:
                 "windows_per_batch": K, "length_bp": L, "ploidy": 2,
                 "mean_variants_per_window": round(bt.mean_variants, 3),
                 "reference_bp": int(st.ref.size), "parallelism": f"rows sharded over {world} GPU(s)",
+                "batches_in_flight": len(streams),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "reconstruct_kernel<false>", "kernel_ms": kern_ms,
+                "kernel": "reconstruct_kernel<OH_LC, haps=%s, annot=false>" % ("true" if args.haps else "false"),
+                "kernel_ms": kern_ms, "kernel_ms_how": "HIP events around K back-to-back launches on one stream",
                 "algorithmic_bytes_per_launch": abytes,
+                "pipelined_GBps": abytes * world / (wall / args.steps) / 1e9 / world,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

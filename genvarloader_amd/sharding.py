@@ -1,0 +1,77 @@
+"""Row sharding of a batch across the GPUs of one node.
+
+The path shards embarrassingly: rows ``k = (query, hap)`` write disjoint output slices and
+only read shared inputs -- the property that makes the reference's rayon ``par_iter`` safe
+(``/root/reference/src/reconstruct/mod.rs:374-375,428-452``).  Each rank therefore takes a
+contiguous block of QUERIES (so the ``P`` haplotypes of a query, which share ``to_rc`` and the
+reference window, stay together and ``(b, P, L)`` reshapes hold), runs the kernel on its
+block, and no collective is on the data path.  The per-dataset arrays (reference, variant
+table, genotype CSR) are replicated on every GPU.
+
+``all_gather_rows`` is the optional final gather for a single consumer (RCCL over xGMI when
+the process group backend is ``nccl``; ``gloo`` in the CPU tests): fixed-length rows gather
+as equal-size blocks (padded to the largest shard), ragged rows gather lengths first.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_bounds(n_queries: int, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous block of queries for `rank`: sizes differ by at most one."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    base, rem = divmod(int(n_queries), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_batch(rank: int, world: int, regions, shifts, geno_offset_idx, to_rc=None, keep=None,
+                keep_offsets=None, out_offsets=None) -> dict:
+    """Slice the per-batch arrays (``ReconstructionRequest``, _haps.py:58-93) to this rank's
+    queries.  ``keep`` / ``keep_offsets`` / ``out_offsets`` are re-based to the shard."""
+    regions = np.asarray(regions)
+    goi = np.asarray(geno_offset_idx)
+    B, P = goi.shape
+    lo, hi = shard_bounds(B, world, rank)
+    k0, k1 = lo * P, hi * P
+    out = dict(regions=regions[lo:hi], shifts=np.asarray(shifts)[lo:hi], geno_offset_idx=goi[lo:hi],
+               to_rc=None if to_rc is None else np.asarray(to_rc)[k0:k1], keep=None, keep_offsets=None,
+               out_offsets=None, query_range=(lo, hi), row_range=(k0, k1))
+    if keep is not None and keep_offsets is not None:
+        ko = np.asarray(keep_offsets, np.int64)
+        out["keep"] = np.asarray(keep)[ko[k0]:ko[k1]]
+        out["keep_offsets"] = ko[k0:k1 + 1] - ko[k0]
+    if out_offsets is not None:
+        oo = np.asarray(out_offsets, np.int64)
+        out["out_offsets"] = oo[k0:k1 + 1] - oo[k0]
+    return out
+
+
+def all_gather_rows(local, row_lengths=None, group=None):
+    """Gather every rank's rows on every rank, in rank order.
+
+    ``local``: torch tensor whose first dimension is this rank's rows (fixed-length rows,
+    e.g. ``(rows, L)`` haplotypes or ``(rows, L, 4)`` one-hot), or a flat 1-D tensor of ragged
+    rows with ``row_lengths`` (1-D int64 tensor, one entry per local row).
+    Returns the concatenated tensor (and the concatenated lengths in the ragged case)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    dev = local.device
+    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    counts = [int(c.item()) for c in counts]
+    mx = max(counts) if counts else 0
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    data = torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    if row_lengths is None:
+        return data
+    lens = all_gather_rows(row_lengths.to(dev), None, group)
+    return data, lens

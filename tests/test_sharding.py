@@ -1,0 +1,115 @@
+"""N > 1 path on CPU: world_size-2 ``gloo`` processes shard a batch by queries, each rank
+reconstructs its shard (the oracle stands in for the kernel here -- this test is about the
+partitioning + gather, the kernel itself is covered by the gpu tests), and the gathered
+result must equal the unsharded one.  Also the host-side synthetic generator."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from genvarloader_amd import sharding, synth
+
+
+def test_shard_bounds_cover_and_balance():
+    for n in (0, 1, 7, 8, 4096, 4099):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_bounds(4, 2, 2)
+
+
+def test_shard_batch_rebases_offsets():
+    rng = np.random.default_rng(0)
+    st = synth.make_static(rng, (50_000,), indel_frac=0.3, density=1 / 40)
+    bt = synth.make_batch(rng, st, 10, 2, 300, rc_frac=0.5)
+    idx = bt.geno_offset_idx.ravel()
+    n_per = bt.geno_offsets[1, idx] - bt.geno_offsets[0, idx]
+    ko = np.concatenate([[0], np.cumsum(n_per)]).astype(np.int64)
+    keep = rng.random(int(ko[-1])) < 0.5
+    oo = np.arange(21, dtype=np.int64) * 300
+    parts = [sharding.shard_batch(r, 3, bt.regions, bt.shifts, bt.geno_offset_idx, bt.to_rc, keep, ko, oo)
+             for r in range(3)]
+    assert sum(len(p["regions"]) for p in parts) == 10
+    np.testing.assert_array_equal(np.concatenate([p["keep"] for p in parts]), keep)
+    for p in parts:
+        assert p["keep_offsets"][0] == 0 and p["out_offsets"][0] == 0
+        assert len(p["keep_offsets"]) == p["geno_offset_idx"].size + 1
+        assert len(p["to_rc"]) == p["geno_offset_idx"].size
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, seed, ragged, q):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle
+
+        rng = np.random.default_rng(seed)
+        st = synth.make_static(rng, (80_000,), indel_frac=0.3, density=1 / 50)
+        bt = synth.make_batch(rng, st, 37, 2, 400, rc_frac=0.5, output_length=-1 if ragged else None)
+        sh = sharding.shard_batch(rank, world, bt.regions, bt.shifts, bt.geno_offset_idx, bt.to_rc)
+        out, oo = oracle.reconstruct_haplotypes_fused(
+            sh["regions"], sh["shifts"], sh["geno_offset_idx"], bt.geno_offsets, bt.geno_v_idxs, st.v_starts,
+            st.ilens, st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, bt.output_length,
+            None, None, sh["to_rc"], False)
+        if ragged:
+            data, lens = sharding.all_gather_rows(torch.from_numpy(out), torch.from_numpy(np.diff(oo)))
+            got = (data.numpy(), lens.numpy())
+        else:
+            rows = torch.from_numpy(out).reshape(-1, bt.output_length)
+            got = (sharding.all_gather_rows(rows).numpy().ravel(), None)
+        full, full_oo = oracle.reconstruct_haplotypes_fused(
+            bt.regions, bt.shifts, bt.geno_offset_idx, bt.geno_offsets, bt.geno_v_idxs, st.v_starts, st.ilens,
+            st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, bt.output_length, None, None,
+            bt.to_rc, False)
+        ok = np.array_equal(got[0], full) and (got[1] is None or np.array_equal(got[1], np.diff(full_oo)))
+        q.put((rank, bool(ok), int(got[0].size)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_two_rank_gloo_shard_and_gather(ragged):
+    import torch.multiprocessing as mp
+
+    from oracle import oracle
+
+    oracle.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 11, ragged, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] for r in res), res
+
+
+def test_synth_configs_shapes():
+    st, bt = synth.make_config("cfg3", contig=1 << 20, windows=256)
+    assert bt.regions.shape == (128, 4) and bt.regions.dtype == np.int32
+    assert bt.shifts.shape == (128, 2) and bt.geno_offset_idx.dtype == np.int64
+    assert bt.geno_offsets.shape[0] == 2 and bt.to_rc.shape == (256,)
+    assert (np.diff(st.v_starts) > 0).all() and len(st.alt_offsets) == len(st.v_starts) + 1
+    assert ((st.ilens != 0).mean() > 0.05) and bt.output_length == 2048
+    st2, bt2 = synth.make_config("cfg3", contig=1 << 20, windows=256)
+    np.testing.assert_array_equal(bt.geno_v_idxs, bt2.geno_v_idxs)  # seeded
