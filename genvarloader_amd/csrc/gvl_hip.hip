@@ -625,13 +625,13 @@ struct RowPlan {
 constexpr u32 GENERAL_HI = 0x80000000u;
 
 #ifdef GVL_DIAG
-#define GVL_STAMP(i) do { if (A.stamps && tid == 0) A.stamps[((u64)blockIdx.x * gridDim.y + blockIdx.y) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define GVL_STAMP(i) do { if (A.stamps && tid == 0) A.stamps[((u64)blockIdx.x * gridDim.y + blockIdx.y) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define GVL_STAMP(i) do { } while (0)
 #endif
 
 template <int OH, bool HAPS, bool ANNOT>
-__global__ __launch_bounds__(WG_THREADS) void reconstruct_kernel(const ReconArgs A) {
+__global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void reconstruct_kernel(const ReconArgs A) {
     __shared__ Luts luts;
     __shared__ SegMirror mirror[WG_WAVES];
     __shared__ Stage<ANNOT> stage[WG_WAVES];
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(WG_THREADS) void reconstruct_kernel(const ReconArgs
     }
     GVL_STAMP(4);
 #ifdef GVL_DIAG
-    if (A.stamps && lane == 0 && (flags & 2)) atomicAdd((unsigned long long *)&A.stamps[((u64)blockIdx.x * gridDim.y + blockIdx.y) * 8 + 7], 1ull);
+    if (A.stamps && lane == 0 && (flags & 2)) atomicAdd((unsigned long long *)&A.stamps[((u64)blockIdx.x * gridDim.y + blockIdx.y) * 16 + 9], 1ull);
 #endif
     if (flags & 2) {
         recon_wave_scalar<OH, HAPS, ANNOT>(A, luts, mirror[wave], stage[wave], k, chunk, lane);
@@ -879,28 +879,48 @@ __global__ __launch_bounds__(WG_THREADS) void reconstruct_kernel(const ReconArgs
     }
 
     // ---- P3b: trip descriptors, lane u = trip u of this row -------------------------------
+    // A trip (256 bases) is described by the <= 3 table entries that cover it (class 0..2 =
+    // 1..3 entries; the typical indel trip is REF | ALLELE | REF); anything else (4+ entries,
+    // a source that would be read past an array end, the partial last group, zero fill) is
+    // class 3 = general.  Entry j spans [b_j, b_{j+1}) with b_0 <= p0.
     const bool ref_zero_fill = (flags & 4) != 0;
     const int limit = hi_clip;
-    u32 d_lo = 0, d_hi = GENERAL_HI; int d_pc0 = 0, d_pcn = 0, d_idx = 0;
+    int d_cls = 3, d_b1 = 0, d_b2 = 0, d_pc0 = 0, d_pcn = 0, d_idx = 0;
+    u32 d_lo0 = 0, d_hi0 = 0, d_lo1 = 0, d_hi1 = 0, d_lo2 = 0, d_hi2 = 0;
     if (lane < CHUNK_TRIPS) {
         const int p0 = lo_clip + lane * TRIP;
         if (p0 < limit) {
             const int t_end = (limit - p0 > TRIP) ? p0 + TRIP : limit;
             int idx = 0;
             for (int s2 = 1; s2 < nseg; ++s2) idx += (pl.s_out[s2] <= p0) ? 1 : 0;
-            const int nxt = idx + 1 < nseg ? pl.s_out[idx + 1] : limit;
-            const u32 hi = pl.s_hi[idx];
-            const i64 src0 = seg_delta(pl.s_lo[idx], hi) + p0;
-            const bool uniform = (hi >> 30) == K_REF && nxt >= t_end && ((t_end - p0) & 3) == 0 && src0 >= 0 &&
-                                 src0 + (t_end - p0) <= A.ref_len && !ref_zero_fill;
+            auto at = [&](int i) { return i < SEG_CAP ? i : SEG_CAP - 1; };
+            const int b1 = idx + 1 < nseg ? pl.s_out[at(idx + 1)] : limit;
+            const int b2 = idx + 2 < nseg ? pl.s_out[at(idx + 2)] : limit;
+            const int b3 = idx + 3 < nseg ? pl.s_out[at(idx + 3)] : limit;
+            d_lo0 = pl.s_lo[at(idx)]; d_hi0 = pl.s_hi[at(idx)];
+            d_lo1 = pl.s_lo[at(idx + 1)]; d_hi1 = pl.s_hi[at(idx + 1)];
+            d_lo2 = pl.s_lo[at(idx + 2)]; d_hi2 = pl.s_hi[at(idx + 2)];
+            int cls = b1 >= t_end ? 0 : (b2 >= t_end ? 1 : (b3 >= t_end ? 2 : 3));
+            // every group that overlaps entry j loads the dword at delta_j + p, i.e. up to 3
+            // bytes before/after the entry's own span: those must stay inside the array
+            auto in_bounds = [&](u32 lo, u32 hi, int s, int e) {
+                const u32 kind = hi >> 30;
+                if (kind != K_REF && kind != K_ALLELE) return true;
+                const i64 dl = seg_delta(lo, hi);
+                const i64 len = kind == K_REF ? A.ref_len : A.alt_len;
+                const int s3 = (s - 3 > p0 ? s - 3 : p0), e3 = (e + 3 < t_end ? e + 3 : t_end);
+                return dl + s3 >= 0 && dl + e3 <= len;
+            };
+            bool okb = in_bounds(d_lo0, d_hi0, p0, b1 < t_end ? b1 : t_end);
+            if (cls >= 1 && cls < 3) okb = okb && in_bounds(d_lo1, d_hi1, b1, b2 < t_end ? b2 : t_end);
+            if (cls == 2) okb = okb && in_bounds(d_lo2, d_hi2, b2, t_end);
+            if (!okb || ((t_end - p0) & 3) != 0 || ref_zero_fill) cls = 3;
             for (int q = 0; q < npatch; ++q) {
                 const int pp = pl.p_out[q];
                 d_pc0 += pp < p0 ? 1 : 0;
                 d_pcn += pp < t_end ? 1 : 0;
             }
-            d_lo = (u32)(u64)src0;
-            d_idx = idx;
-            if (uniform) d_hi = (u32)((u64)src0 >> 32);
+            d_cls = cls; d_b1 = b1; d_b2 = b2; d_idx = idx;
         }
     }
     GVL_STAMP(5);
@@ -918,7 +938,7 @@ __global__ __launch_bounds__(WG_THREADS) void reconstruct_kernel(const ReconArgs
     int *ap_row = (ANNOT && A.ap) ? A.ap + row_base : nullptr;
 
     // finish one trip: SNP patches, reverse-complement, one-hot LUT, stores
-    auto finish = [&](const int p0, const int pc0, const int pcn, u32 wv, int (&av4)[GROUP], int (&ap4)[GROUP]) {
+    auto finish = [&](const int p0, const int pc0, const int pcn, u32 wv, int (&av4)[GROUP], int (&ap4)[GROUP]) -> u32 {
         const int p = p0 + GROUP * lane;
         const bool act = p < limit;
         const bool full = p + GROUP <= limit;
@@ -967,6 +987,14 @@ __global__ __launch_bounds__(WG_THREADS) void reconstruct_kernel(const ReconArgs
                 }
             }
         }
+        return wv;
+    };
+
+    // the partial group at the row end (L % 4 != 0) -- only class-3 trips can hold it
+    auto finish_partial = [&](const int p0, const u32 wv, int (&av4)[GROUP], int (&ap4)[GROUP]) {
+        const int p = p0 + GROUP * lane;
+        const bool act = p < limit;
+        const bool full = p + GROUP <= limit;
         if (limit & 3) {
             // partial group at the row end (L % 4 != 0): per-base stores by lanes 0..(L&3)-1
             const int p_last = limit & ~3;
@@ -1004,23 +1032,92 @@ __global__ __launch_bounds__(WG_THREADS) void reconstruct_kernel(const ReconArgs
         }
     };
 
-    // pass A: all reference loads of the uniform trips first (they are independent)
+    // Trip classes: 0 = one entry (uniform), 1/2 = two/three entries ("multi": the typical
+    // indel trip), 3 = general.  Loads are issued in the order multi (up to 2 trips), then
+    // all class-0 trips, so that everything is in flight before the first wait.
+    auto entry_load = [&](const u32 lo, const u32 hi, const int p, const bool pred) -> u32 {
+        const u32 kind = hi >> 30;                       // uniform
+        if (kind == K_REF || kind == K_ALLELE) {
+            const u8 *arr = (kind == K_REF ? A.ref : A.alt_alleles) + seg_delta(lo, hi);
+            u32 v = 0;
+            if (pred && !(A.dbg & 4)) v = load_u32_unaligned(arr + p);
+            return v;
+        }
+        return padb * 0x01010101u;
+    };
+    auto bytes_below = [](int k) -> u32 { return k <= 0 ? 0u : (k >= 4 ? 0xFFFFFFFFu : ((1u << (8 * k)) - 1u)); };
+    auto multi_issue = [&](const int u, u32 (&w3)[3]) {
+        const int p = lo_clip + u * TRIP + GROUP * lane;
+        const int cls = rdl(d_cls, u);
+        const int b1 = rdl(d_b1, u), b2 = rdl(d_b2, u);
+        w3[0] = entry_load((u32)rdl((int)d_lo0, u), (u32)rdl((int)d_hi0, u), p, p < limit && p < b1);
+        w3[1] = entry_load((u32)rdl((int)d_lo1, u), (u32)rdl((int)d_hi1, u), p, p < limit && p + GROUP > b1 && p < b2);
+        w3[2] = 0;
+        if (cls >= 2) w3[2] = entry_load((u32)rdl((int)d_lo2, u), (u32)rdl((int)d_hi2, u), p, p < limit && p + GROUP > b2);
+    };
+    auto multi_finish = [&](const int u, const u32 (&w3)[3]) {
+        const int p0 = lo_clip + u * TRIP;
+        const int p = p0 + GROUP * lane;
+        const int cls = rdl(d_cls, u);
+        const int b1 = rdl(d_b1, u), b2 = rdl(d_b2, u);
+        const u32 m1 = bytes_below(b1 - p);           // bytes of entry 0
+        const u32 m2 = bytes_below(b2 - p);           // bytes of entries 0 and 1
+        const u32 wv = (w3[0] & m1) | (w3[1] & m2 & ~m1) | (w3[2] & ~m2);
+        int av4[GROUP], ap4[GROUP];
+        if (ANNOT) {
+            const u32 lo_[3] = {(u32)rdl((int)d_lo0, u), (u32)rdl((int)d_lo1, u), (u32)rdl((int)d_lo2, u)};
+            const u32 hi_[3] = {(u32)rdl((int)d_hi0, u), (u32)rdl((int)d_hi1, u), (u32)rdl((int)d_hi2, u)};
+            const int i0 = rdl(d_idx, u);
+#pragma unroll
+            for (int i = 0; i < GROUP; ++i) {
+                const int pp = p + i;
+                const int j = pp >= b1 ? ((cls >= 2 && pp >= b2) ? 2 : 1) : 0;
+                const u32 lo = j == 0 ? lo_[0] : (j == 1 ? lo_[1] : lo_[2]);
+                const u32 hi = j == 0 ? hi_[0] : (j == 1 ? hi_[1] : hi_[2]);
+                const u32 kind = hi >> 30;
+                const int se = i0 + j < SEG_CAP ? i0 + j : SEG_CAP - 1;
+                if (kind == K_REF) { av4[i] = -1; ap4[i] = (int)(seg_delta(lo, hi) + pp - c_s); }
+                else if (kind == K_ALLELE) { av4[i] = pl.s_a[se]; ap4[i] = pl.s_b[se]; }
+                else { av4[i] = -1; ap4[i] = kind == K_PAD_LEAD ? -1 : 2147483647; }
+            }
+        }
+        finish(p0, rdl(d_pc0, u), rdl(d_pcn, u), wv, av4, ap4);
+    };
+    u32 gmask, mmask, umask;
+    {
+        const u64 bg = __builtin_amdgcn_ballot_w64(lane < CHUNK_TRIPS && lo_clip + lane * TRIP < limit && d_cls == 3);
+        const u64 bm = __builtin_amdgcn_ballot_w64(lane < CHUNK_TRIPS && lo_clip + lane * TRIP < limit && (d_cls == 1 || d_cls == 2));
+        const u64 bu = __builtin_amdgcn_ballot_w64(lane < CHUNK_TRIPS && lo_clip + lane * TRIP < limit && d_cls == 0);
+        gmask = (u32)bg; mmask = (u32)bm; umask = (u32)bu;
+    }
+    // the first two multi trips: loads now, finish after the class-0 loads are out
+    int mu_a = -1, mu_b = -1;
+    u32 wa[3] = {0, 0, 0}, wb[3] = {0, 0, 0};
+    if (mmask) { mu_a = __builtin_ctz(mmask); mmask &= mmask - 1; multi_issue(mu_a, wa); }
+    if (mmask) { mu_b = __builtin_ctz(mmask); mmask &= mmask - 1; multi_issue(mu_b, wb); }
+    // pass A: class-0 trips, 4 bytes per lane from one scalar base
     u32 wq[CHUNK_TRIPS];
-    u32 gmask = 0;
 #pragma unroll
     for (int u = 0; u < CHUNK_TRIPS; ++u) {
         wq[u] = 0;
-        const int p0 = lo_clip + u * TRIP;
-        if (p0 < limit) {
-            const u32 bhi = (u32)rdl((int)d_hi, u);
-            if (bhi != GENERAL_HI) {
-                const i64 base = (i64)(((u64)bhi << 32) | (u32)rdl((int)d_lo, u));
-                if (p0 + GROUP * lane < limit && !(A.dbg & 4)) wq[u] = load_u32_unaligned(A.ref + base + (u32)(GROUP * lane));
-            } else {
-                gmask |= 1u << u;
-            }
+        if ((umask >> u) & 1u) {
+            const int p = lo_clip + u * TRIP + GROUP * lane;
+            wq[u] = entry_load((u32)rdl((int)d_lo0, u), (u32)rdl((int)d_hi0, u), p, p < limit);
         }
     }
+    if (mu_a >= 0) multi_finish(mu_a, wa);
+    if (mu_b >= 0) multi_finish(mu_b, wb);
+    while (mmask) {   // a third, fourth ... multi trip in one chunk: one at a time
+        const int u = __builtin_ctz(mmask);
+        mmask &= mmask - 1;
+        u32 w3[3];
+        multi_issue(u, w3);
+        multi_finish(u, w3);
+    }
+    GVL_STAMP(6);
+#ifdef GVL_DIAG
+    if (A.stamps && tid == 0) A.stamps[((u64)blockIdx.x * gridDim.y + blockIdx.y) * 16 + 10] = __builtin_popcount(gmask);
+#endif
     // pass G: general trips (a segment boundary / allele / pad / row end inside the trip).
     // A group of 4 bases overlaps at most 4 segments; each contributes one masked dword
     // load from ITS source, so the group costs one memory latency, not one per byte.
@@ -1036,18 +1133,39 @@ __global__ __launch_bounds__(WG_THREADS) void reconstruct_kernel(const ReconArgs
             for (int i = 0; i < GROUP; ++i) { av4[i] = -1; ap4[i] = -1; }
         }
         if (p < limit) {
-            int seg = __builtin_amdgcn_readlane(d_idx, u);
-            while (seg + 1 < nseg && pl.s_out[seg + 1] <= p) ++seg;
+            // segment holding p: the trip's first segment + the starts before p (independent
+            // LDS reads; a fifth boundary inside one trip falls through to the while loop)
+            const int s0 = __builtin_amdgcn_readlane(d_idx, u);
+            int seg = s0;
+            {
+                int c = 0;
+#pragma unroll
+                for (int j = 1; j <= 4; ++j) {
+                    const int sj = s0 + j < SEG_CAP ? s0 + j : SEG_CAP - 1;
+                    c += (s0 + j < nseg && pl.s_out[sj] <= p) ? 1 : 0;
+                }
+                seg += c;
+                if (c == 4) while (seg + 1 < nseg && pl.s_out[seg + 1] <= p) ++seg;
+            }
             const int g_end = (limit - p > GROUP) ? p + GROUP : limit;
+            // table entries seg .. seg+3 (a group of 4 bases overlaps at most 4 segments)
+            u32 e_lo[GROUP], e_hi[GROUP]; int e_nx[GROUP];
+#pragma unroll
+            for (int t = 0; t < GROUP; ++t) {
+                const int st = seg + t < SEG_CAP ? seg + t : SEG_CAP - 1;
+                const int sn = seg + t + 1 < SEG_CAP ? seg + t + 1 : SEG_CAP - 1;
+                e_lo[t] = pl.s_lo[st]; e_hi[t] = pl.s_hi[st];
+                e_nx[t] = seg + t + 1 < nseg ? pl.s_out[sn] : limit;
+            }
             int cur = p;
             u32 words[GROUP], masks[GROUP];
 #pragma unroll
             for (int t = 0; t < GROUP; ++t) {
                 words[t] = 0; masks[t] = 0;
                 if (cur < g_end) {
-                    const u32 lo = pl.s_lo[seg], hi = pl.s_hi[seg];
+                    const u32 lo = e_lo[t], hi = e_hi[t];
                     const u32 kind = hi >> 30;
-                    const int s_end = seg + 1 < nseg ? pl.s_out[seg + 1] : limit;
+                    const int s_end = e_nx[t];
                     const int e = s_end < g_end ? s_end : g_end;
                     const u32 m_hi = (e - p) >= 4 ? 0xFFFFFFFFu : ((1u << (8 * (e - p))) - 1u);
                     const u32 m_lo = (1u << (8 * (cur - p))) - 1u;
@@ -1074,41 +1192,49 @@ __global__ __launch_bounds__(WG_THREADS) void reconstruct_kernel(const ReconArgs
                         words[t] = padb * 0x01010101u;
                     }
                     if (ANNOT) {
+                        const int st = seg + t < SEG_CAP ? seg + t : SEG_CAP - 1;
 #pragma unroll
                         for (int i = 0; i < GROUP; ++i) {
                             if (p + i >= cur && p + i < e) {
                                 if (kind == K_REF) { av4[i] = -1; ap4[i] = (int)(src - c_s) + i; }
-                                else if (kind == K_ALLELE) { av4[i] = pl.s_a[seg]; ap4[i] = pl.s_b[seg]; }
+                                else if (kind == K_ALLELE) { av4[i] = pl.s_a[st]; ap4[i] = pl.s_b[st]; }
                                 else { av4[i] = -1; ap4[i] = kind == K_PAD_LEAD ? -1 : 2147483647; }
                             }
                         }
                     }
                     cur = e;
-                    ++seg;
                 }
             }
 #pragma unroll
             for (int t = 0; t < GROUP; ++t) wv |= words[t] & masks[t];
         }
-        finish(p0, rdl(d_pc0, u), rdl(d_pcn, u), wv, av4, ap4);
+        wv = finish(p0, rdl(d_pc0, u), rdl(d_pcn, u), wv, av4, ap4);
+        finish_partial(p0, wv, av4, ap4);
     }
-    // pass B: finish the uniform trips
+    GVL_STAMP(7);
+    // pass B: finish the class-0 trips
 #pragma unroll
     for (int u = 0; u < CHUNK_TRIPS; ++u) {
-        const int p0 = lo_clip + u * TRIP;
-        if (p0 < limit && (u32)rdl((int)d_hi, u) != GENERAL_HI) {
+        if ((umask >> u) & 1u) {
+            const int p0 = lo_clip + u * TRIP;
             int av4[GROUP], ap4[GROUP];
             if (ANNOT) {
-                const i64 base = (i64)(((u64)(u32)rdl((int)d_hi, u) << 32) | (u32)rdl((int)d_lo, u));
-                const int apb = (int)(base - c_s) + GROUP * lane;
+                const u32 lo = (u32)rdl((int)d_lo0, u), hi = (u32)rdl((int)d_hi0, u);
+                const u32 kind = hi >> 30;
+                const int se = rdl(d_idx, u);
+                const int p = p0 + GROUP * lane;
 #pragma unroll
-                for (int i = 0; i < GROUP; ++i) { av4[i] = -1; ap4[i] = apb + i; }
+                for (int i = 0; i < GROUP; ++i) {
+                    if (kind == K_REF) { av4[i] = -1; ap4[i] = (int)(seg_delta(lo, hi) + p + i - c_s); }
+                    else if (kind == K_ALLELE) { av4[i] = pl.s_a[se]; ap4[i] = pl.s_b[se]; }
+                    else { av4[i] = -1; ap4[i] = kind == K_PAD_LEAD ? -1 : 2147483647; }
+                }
             }
             finish(p0, rdl(d_pc0, u), rdl(d_pcn, u), wq[u], av4, ap4);
         }
     }
     __builtin_amdgcn_s_waitcnt(0);
-    GVL_STAMP(6);
+    GVL_STAMP(8);
 }
 
 #undef GVL_STAMP

@@ -11,22 +11,26 @@ dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, i
 dbt = dev.prepare_batch(bt.regions, bt.shifts, bt.geno_offset_idx, bt.output_length, to_rc=bt.to_rc)
 out, oc = dev.alloc_output(dbt, bt.n_windows * bt.output_length, haps=False, onehot=True)
 nwg = (bt.n_windows + 7) // 8
-stamps = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(nwg * 16, dtype=torch.int64, device="cuda")
 lib = _lib.load()
 for i in range(20): dev.launch(dbt, oc)
 torch.cuda.synchronize()
 lib.gvl_diag_set_stamps(C.c_void_p(stamps.data_ptr()))
 dev.launch(dbt, oc); torch.cuda.synchronize()
-s = stamps.cpu().numpy().reshape(nwg, 8).astype(np.float64) * 10.0  # memrealtime ticks of 100 MHz -> ns
+raw = stamps.cpu().numpy().reshape(nwg, 16)
+s = raw.astype(np.float64) * 10.0  # memrealtime ticks of 100 MHz -> ns
 t0 = s[:, 0].min()
-names = ["start", "P1 done", "sync", "P2 recs", "P3 scans", "P3b desc", "end(wave0)"]
+names = ["start", "P1 done", "sync", "P2 recs", "P3 scans", "P3b desc", "passA issued", "passG done", "end(wave0)"]
 for i, n in enumerate(names):
     col = s[:, i] - t0
     print(f"{n:16s} min {col.min():8.0f}  median {np.median(col):8.0f}  max {col.max():8.0f} ns")
-d = np.diff(s[:, :7], axis=1)
+d = np.diff(s[:, :9], axis=1)
 print("per-WG phase durations (median ns):", np.median(d, axis=0).round(0))
 
-nfb = stamps.cpu().numpy().reshape(nwg, 8)[:, 7]
-print("rows on the scalar path:", int(nfb.sum()), "of", bt.n_windows, "; WGs with >=1:", int((nfb > 0).sum()))
-end = s[:, 6] - s[:, 0]
-print("wave0 end-start median ns: WGs without fallback", np.median(end[nfb == 0]).round(0), " with fallback", np.median(end[nfb > 0]).round(0) if (nfb>0).any() else None)
+nfb = raw[:, 9]
+ng = raw[:, 10]
+print("rows on the scalar path:", int(nfb.sum()), "of", bt.n_windows)
+end = s[:, 8] - s[:, 0]
+for g in sorted(set(ng.tolist())):
+    m = ng == g
+    print(f"wave0 general trips={g}: {m.sum():4d} WGs  passG median {np.median(d[m, 6]):7.0f} ns  total median {np.median(end[m]):7.0f} max {end[m].max():7.0f}")
