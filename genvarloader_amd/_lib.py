@@ -28,6 +28,8 @@ SYMBOLS = (
     "gvl_rc_rows",
     "gvl_reverse_rows_4",
     "gvl_onehot",
+    "gvl_intervals_to_tracks",
+    "gvl_realign_tracks",
 )
 
 GVL_ONEHOT_LC = 0

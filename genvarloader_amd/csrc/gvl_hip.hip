@@ -1436,6 +1436,300 @@ __global__ __launch_bounds__(256) void onehot_kernel(const u8 *in, i64 n, u8 *ou
     }
 }
 
+
+// ---------------------------------------------------------------------------------
+// Tracks (BASELINE config 4): interval painting and realignment of
+// reference-coordinate f32 tracks to a haplotype.  First correct version: one wave per
+// (row, chunk) replays the reference's walk on the scalar unit into a lane-resident
+// segment table (same flush/compaction scheme as recon_wave_scalar) and streams 4 values
+// per lane per trip; values inside a plain track run are one 16-B load + one 16-B store.
+// ---------------------------------------------------------------------------------
+struct TrackArgs {
+    const i64 *go_starts; const i64 *go_stops; const int *geno_v_idxs; const int *v_starts;
+    const int *ilens; i64 n_variants;
+    const int *regions; i64 regions_stride; const int *shifts; const i64 *geno_offset_idx;
+    const u8 *keep; const i64 *keep_offsets; const u8 *to_rc; const i64 *out_offsets;
+    i64 n_rows; int ploidy; int ploidy_shift; int chunk_len;
+    const float *tracks; const i64 *track_offsets;
+    double param; i64 strategy; u64 base_seed;
+    float *out;
+};
+enum : int { T_TRACK = 0, T_REPEAT = 1, T_FILL = 2, T_ZERO = 3 };
+struct TrackMirror { int out[SEG_CAP]; int kind[SEG_CAP]; int plo[SEG_CAP]; int phi[SEG_CAP]; int vlen[SEG_CAP]; };
+
+__device__ __forceinline__ u64 xorshift64_dev(u64 x) {   // src/tracks/mod.rs:31-36
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    return x;
+}
+__device__ __forceinline__ u64 hash4_dev(u64 a, u64 b, u64 c, u64 d) {   // :48-54
+    u64 h = a;
+    h = xorshift64_dev(h ^ b);
+    h = xorshift64_dev(h ^ c);
+    h = xorshift64_dev(h ^ d);
+    return h;
+}
+
+// One value of an insertion-fill region: src/tracks/mod.rs:87-190, evaluated per position.
+// `i` = offset inside the region, `pp` = output index in the row.
+__device__ float fill_value(const TrackArgs &A, const float *track, i64 tlen, i64 vrp, i64 v_len, i64 i,
+                            i64 pp, u64 query, u64 hap) {
+#pragma clang fp contract(off)
+    auto tr = [&](i64 x) -> float { return (x >= 0 && x < tlen) ? track[x] : 0.0f; };
+    if (A.strategy == GVL_FILL_REPEAT_5P) return tr(vrp);
+    if (A.strategy == GVL_FILL_REPEAT_5P_NORM) return tr(vrp) / (float)v_len;
+    if (A.strategy == GVL_FILL_CONSTANT) return (float)A.param;
+    if (A.strategy == GVL_FILL_FLANK_SAMPLE) {
+        const i64 width = (i64)A.param;
+        const i64 lo = imax(vrp - width, 0), hi = imin(vrp + width, tlen - 1);
+        const u64 pool = (u64)(hi - lo + 1);
+        const u64 seed = hash4_dev(A.base_seed, query, hap, (u64)pp);
+        return tr(lo + (i64)(pool ? seed % pool : 0));
+    }
+    if (A.strategy == GVL_FILL_INTERPOLATE) {
+        const i64 order = (i64)A.param;
+        const i64 k = (order + 1 + 1) / 2;
+        const i64 n = 2 * k;
+        auto xs = [&](i64 j) -> double { return j < k ? -(double)j : (double)v_len + (double)(j - k); };
+        auto ys = [&](i64 j) -> double {
+            return j < k ? (double)tr(imax(vrp - j, 0)) : (double)tr(imin(vrp + 1 + (j - k), tlen - 1));
+        };
+        const double x = (double)i;
+        double acc = 0.0;
+        for (i64 a = 0; a < n; ++a) {
+            double term = ys(a);
+            const double xa = xs(a);
+            for (i64 b = 0; b < n; ++b) {
+                if (b == a) continue;
+                const double xb = xs(b);
+                term = term * ((x - xb) / (xa - xb));
+            }
+            acc = acc + term;
+        }
+        return (float)acc;
+    }
+    return 0.0f;
+}
+
+__global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A) {
+    __shared__ TrackMirror mirror[4];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = rfl((int)(threadIdx.x >> 6));
+    TrackMirror &M = mirror[wave];
+    const i64 k = (i64)blockIdx.x * 4 + wave;
+    if (k >= A.n_rows) return;
+    const int chunk = blockIdx.y;
+    const i64 query = A.ploidy_shift >= 0 ? (k >> A.ploidy_shift) : (i64)((u32)k / (u32)A.ploidy);
+    const i64 hap = k - query * A.ploidy;
+    const i64 row_base = rfl64(A.out_offsets[k]);
+    const int L = (int)(rfl64(A.out_offsets[k + 1]) - row_base);
+    const int lo_clip = chunk * A.chunk_len;
+    if (lo_clip >= L) return;
+    const int hi_clip = (L - lo_clip > A.chunk_len) ? lo_clip + A.chunk_len : L;
+    const i64 t_s = rfl64(A.track_offsets[query]);
+    const i64 tlen = rfl64(A.track_offsets[query + 1]) - t_s;
+    const float *track = A.tracks + t_s;
+    const i64 q_start = rfl(A.regions[query * A.regions_stride + 1]);
+    const i64 shift = rfl(A.shifts[k]);
+    const i64 o_idx = rfl64(A.geno_offset_idx[k]);
+    const i64 o_s = rfl64(A.go_starts[o_idx]);
+    const i64 nv64 = rfl64(A.go_stops[o_idx]) - o_s;
+    const int n_var = nv64 < 0 ? 0 : (nv64 > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)nv64);
+    const bool has_keep = A.keep && A.keep_offsets;
+    const i64 keep_off = has_keep ? rfl64(A.keep_offsets[k]) : 0;
+    const bool rc = A.to_rc ? (rfl((int)A.to_rc[k]) != 0) : false;
+    float *out_row = A.out + row_base;
+
+    int s_out = 0, s_kind = 0, s_plo = 0, s_phi = 0, s_vlen = 0;
+    int nseg = 0;
+    int last_kind = -1; i64 last_p = 0;
+    auto push = [&](int kind, int o_start, int len, i64 pval, int vlen) {
+        if (len <= 0 || o_start + len <= lo_clip || o_start >= hi_clip) return;
+        if (kind == T_TRACK && last_kind == T_TRACK && pval == last_p) return;   // run continues
+        if (lane == nseg) {
+            s_out = o_start; s_kind = kind; s_plo = (int)(u32)(u64)pval; s_phi = (int)(u32)((u64)pval >> 32);
+            s_vlen = vlen;
+            M.out[lane] = o_start; M.kind[lane] = kind; M.plo[lane] = s_plo; M.phi[lane] = s_phi; M.vlen[lane] = vlen;
+        }
+        last_kind = kind; last_p = pval; ++nseg;
+    };
+
+    i64 track_idx = 0, shifted = 0;
+    int out_idx = 0;
+    int r_pos = 0, r_ilen = 0, r_keep = 1;
+    int vi = 0, vb = -WAVE;
+    bool walk_done = false;
+    int emit_pos = lo_clip;
+    if (n_var == 0) {   // src/tracks/mod.rs:240-246: out[:] = track[:length]
+        push(T_TRACK, 0, L, 0, 0);
+        out_idx = L;
+        walk_done = true;
+    }
+
+    for (;;) {
+        while (!walk_done && nseg <= SEG_FLUSH) {
+            bool stop = (vi >= n_var) || (out_idx >= hi_clip);
+            if (!stop) {
+                if (vi - vb >= WAVE) {
+                    vb = vi;
+                    const int j = vb + lane;
+                    if (j < n_var) {
+                        int v = A.geno_v_idxs[o_s + j];
+                        v = v < 0 ? 0 : ((i64)v >= A.n_variants ? (int)(A.n_variants - 1) : v);
+                        r_pos = A.v_starts[v]; r_ilen = A.ilens[v];
+                        r_keep = has_keep ? (int)A.keep[keep_off + j] : 1;
+                    }
+                }
+                const int i = vi - vb;
+                ++vi;
+                if (has_keep && rdl(r_keep, i) == 0) continue;
+                const i64 vrp = (i64)rdl(r_pos, i) - q_start;           // mod.rs:264
+                const i64 d = rdl(r_ilen, i);
+                const i64 vre = vrp - (d < 0 ? d : 0) + 1;               // :267
+                if (d < 0 && vrp < 0 && vre >= 0) { track_idx = vre; continue; }   // :271-274
+                if (vrp < track_idx) continue;                          // :277-279
+                i64 v_len = (d > 0 ? d : 0) + 1;                         // :282
+                if (shifted < shift) {                                   // :285-308
+                    const i64 dist = vrp - track_idx;
+                    if (shifted + dist + v_len < shift) continue;
+                    if (shifted + dist >= shift) {
+                        track_idx += shift - shifted;
+                        shifted = shift;
+                    } else {
+                        const i64 a0 = shift - shifted - dist;
+                        shifted = shift;
+                        if (a0 == v_len) { track_idx = vre; continue; }
+                        track_idx = vrp;
+                        v_len -= a0;
+                    }
+                }
+                if (d == 0) continue;                                    // :312-314 SNPs do not move tracks
+                const i64 n64 = vrp - track_idx;
+                if (n64 >= (i64)(L - out_idx)) {                          // :319-321
+                    stop = true;
+                } else {
+                    const int n = (int)n64;
+                    push(T_TRACK, out_idx, n, track_idx - out_idx, 0);
+                    out_idx += n;
+                    const int w = (int)imin(v_len, (i64)(L - out_idx));  // :329
+                    const int vl = (int)imin(v_len, 0x7FFFFFFFll);
+                    if (d > 0 && A.strategy != GVL_FILL_REPEAT_5P) push(T_FILL, out_idx, w, vrp, vl);   // :333-346
+                    else push(T_REPEAT, out_idx, w, vrp, vl);            // :347-354
+                    out_idx += w;
+                    track_idx = vre;
+                    if (out_idx >= L) stop = true;
+                }
+            }
+            if (stop) {
+                if (shifted < shift) track_idx = imin(track_idx + (shift - shifted), tlen);   // :365-369
+                const int u = L - out_idx;
+                if (u > 0) {
+                    const int w = (int)imin((i64)u, tlen - track_idx);
+                    int end = out_idx;
+                    if (w > 0) { push(T_TRACK, out_idx, w, track_idx - out_idx, 0); end += w; }
+                    if (end < L) push(T_ZERO, end, L - end, 0, 0);
+                }
+                out_idx = out_idx > L ? out_idx : L;
+                walk_done = true;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        const int cov = out_idx < lo_clip ? lo_clip : (out_idx > hi_clip ? hi_clip : out_idx);
+        const int limit = walk_done ? hi_clip : (cov & ~3);
+        for (int p0 = emit_pos; p0 < limit; p0 += TRIP) {
+            const int p = p0 + GROUP * lane;
+            if (p < limit) {
+                // segment holding p (binary search in the LDS mirror; nseg <= 64)
+                int li = 0;
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) {
+                    const int t = li + step;
+                    if (t < nseg && M.out[t] <= p) li = t;
+                }
+                const int nx = li + 1 < nseg ? M.out[li + 1] : cov;
+                float v4[GROUP];
+                const i64 pv0 = (i64)(((u64)(u32)M.phi[li] << 32) | (u32)M.plo[li]);
+                if (M.kind[li] == T_TRACK && p + GROUP <= nx && p + GROUP <= limit && pv0 + p >= 0 &&
+                    pv0 + p + GROUP <= tlen) {
+                    const float *src = track + pv0 + p;
+                    v4[0] = src[0]; v4[1] = src[1]; v4[2] = src[2]; v4[3] = src[3];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < GROUP; ++i) {
+                        const int pp = p + i;
+                        float v = 0.0f;
+                        if (pp < limit) {
+                            while (li + 1 < nseg && M.out[li + 1] <= pp) ++li;
+                            const int kd = M.kind[li];
+                            const i64 pv = (i64)(((u64)(u32)M.phi[li] << 32) | (u32)M.plo[li]);
+                            if (kd == T_TRACK) { const i64 x = pv + pp; v = (x >= 0 && x < tlen) ? track[x] : 0.0f; }
+                            else if (kd == T_REPEAT) { v = (pv >= 0 && pv < tlen) ? track[pv] : 0.0f; }
+                            else if (kd == T_FILL) { v = fill_value(A, track, tlen, pv, (i64)M.vlen[li], (i64)(pp - M.out[li]), (i64)pp, (u64)query, (u64)hap); }
+                        }
+                        v4[i] = v;
+                    }
+                }
+                if (p + GROUP <= limit) {
+                    if (!rc) {
+                        float *dst = out_row + p;
+                        dst[0] = v4[0]; dst[1] = v4[1]; dst[2] = v4[2]; dst[3] = v4[3];
+                    } else {
+                        float *dst = out_row + (L - GROUP - p);
+                        dst[0] = v4[3]; dst[1] = v4[2]; dst[2] = v4[1]; dst[3] = v4[0];
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < GROUP; ++i)
+                        if (p + i < limit) out_row[rc ? (L - 1 - (p + i)) : (p + i)] = v4[i];
+                }
+            }
+        }
+        emit_pos = limit;
+        if (walk_done || emit_pos >= hi_clip) break;
+        {   // compact: keep the segment that holds emit_pos and everything after it
+            int cnt = 0;
+            for (int s2 = 0; s2 < nseg; ++s2) cnt += (rdl(s_out, s2) <= emit_pos) ? 1 : 0;
+            const int s0 = cnt > 0 ? cnt - 1 : 0;
+            if (s0 > 0) {
+                const int srcl = lane + s0 < SEG_CAP ? lane + s0 : SEG_CAP - 1;
+                s_out = bperm(srcl, s_out); s_kind = bperm(srcl, s_kind); s_plo = bperm(srcl, s_plo);
+                s_phi = bperm(srcl, s_phi); s_vlen = bperm(srcl, s_vlen);
+                nseg -= s0;
+            }
+            M.out[lane] = s_out; M.kind[lane] = s_kind; M.plo[lane] = s_plo; M.phi[lane] = s_phi; M.vlen[lane] = s_vlen;
+        }
+    }
+}
+
+// src/intervals.rs:19-126.  One thread per output value: the value is that of the LAST
+// interval (in order) that covers the position -- what sequential painting leaves behind.
+__global__ __launch_bounds__(256) void intervals_to_tracks_kernel(
+    const i64 *offset_idxs, const int *starts, i64 starts_stride, i64 n_queries, const int *itv_starts,
+    const int *itv_ends, const float *itv_values, const i64 *itv_offsets, float *out, const i64 *out_offsets) {
+    const i64 q = blockIdx.y;
+    if (q >= n_queries) return;
+    const i64 o0 = out_offsets[q];
+    const i64 length = out_offsets[q + 1] - o0;
+    const i64 idx = offset_idxs[q];
+    const i64 s0 = itv_offsets[idx], e0 = itv_offsets[idx + 1];
+    const i64 qs = starts[q * starts_stride];
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < length; j += (i64)gridDim.x * blockDim.x) {
+        // c = last interval with start - qs <= j  (intervals are sorted by start)
+        i64 lo = s0, hi = e0;   // first interval with start - qs > j
+        while (lo < hi) {
+            const i64 mid = (lo + hi) >> 1;
+            if ((i64)itv_starts[mid] - qs <= j) lo = mid + 1; else hi = mid;
+        }
+        float v = 0.0f;
+        for (i64 c = lo - 1; c >= s0; --c) {
+            if ((i64)itv_ends[c] - qs > j) { v = itv_values[c]; break; }
+        }
+        out[o0 + j] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // host side of the C-ABI
 // ---------------------------------------------------------------------------
@@ -1666,6 +1960,56 @@ int gvl_onehot(const uint8_t *in, int64_t n, uint8_t *out, void *stream) {
     if (groups > 8192) groups = 8192;
     hipLaunchKernelGGL(onehot_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, in, (i64)n, out);
     return check_launch("gvl_onehot");
+}
+
+
+int gvl_intervals_to_tracks(const int64_t *offset_idxs, const int32_t *starts, int64_t starts_stride,
+                            int64_t n_queries, const int32_t *itv_starts, const int32_t *itv_ends,
+                            const float *itv_values, const int64_t *itv_offsets, float *out,
+                            const int64_t *out_offsets, int64_t max_row_len, void *stream) {
+    if (n_queries < 0 || max_row_len < 0) return fail(GVL_ERR_INVALID, "%s", "gvl_intervals_to_tracks: negative size");
+    if (n_queries == 0 || max_row_len == 0) return GVL_OK;
+    if (!offset_idxs || !starts || !itv_offsets || !out || !out_offsets || starts_stride < 1)
+        return fail(GVL_ERR_INVALID, "%s", "gvl_intervals_to_tracks: NULL/invalid array");
+    if (n_queries > 65535) return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_intervals_to_tracks: more than 65535 queries per call");
+    i64 gx = (max_row_len + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    intervals_to_tracks_kernel<<<dim3((unsigned)gx, (unsigned)n_queries), dim3(256), 0, (hipStream_t)stream>>>(
+        (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
+        (const i64 *)itv_offsets, out, (const i64 *)out_offsets);
+    return check_launch("gvl_intervals_to_tracks");
+}
+
+int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *tracks,
+                       const int64_t *track_offsets, const double *params, int64_t strategy_id,
+                       uint64_t base_seed, float *out, void *stream) {
+    if (!st || !bt) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: NULL struct");
+    if (bt->batch < 0 || bt->ploidy <= 0) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: bad batch/ploidy");
+    if (bt->batch == 0) return GVL_OK;
+    if (!bt->regions || !bt->shifts || !bt->geno_offset_idx || !bt->out_offsets || bt->regions_stride < 3 ||
+        !st->geno_o_starts || !st->geno_o_stops || !tracks || !track_offsets || !out || !params)
+        return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: NULL/invalid array");
+    if (st->n_geno > 0 && (!st->geno_v_idxs || !st->v_starts || !st->ilens))
+        return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: NULL variant table");
+    if (strategy_id < 0 || strategy_id > GVL_FILL_INTERPOLATE) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: bad strategy_id");
+    if (bt->max_row_len < 0 || bt->max_row_len > 0x7FFFFF00ll) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: bad max_row_len");
+    TrackArgs A;
+    memset(&A, 0, sizeof(A));
+    A.go_starts = (const i64 *)st->geno_o_starts; A.go_stops = (const i64 *)st->geno_o_stops;
+    A.geno_v_idxs = st->geno_v_idxs; A.v_starts = st->v_starts; A.ilens = st->ilens; A.n_variants = st->n_variants;
+    A.regions = bt->regions; A.regions_stride = bt->regions_stride; A.shifts = bt->shifts;
+    A.geno_offset_idx = (const i64 *)bt->geno_offset_idx; A.keep = bt->keep; A.keep_offsets = (const i64 *)bt->keep_offsets;
+    A.to_rc = bt->to_rc; A.out_offsets = (const i64 *)bt->out_offsets;
+    A.n_rows = bt->batch * bt->ploidy; A.ploidy = (int)bt->ploidy; A.ploidy_shift = log2_exact(bt->ploidy);
+    int chunks = 1;
+    if (pick_chunk(bt->max_row_len, &chunks, &A.chunk_len)) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: too many chunks");
+    A.tracks = tracks; A.track_offsets = (const i64 *)track_offsets;
+    A.param = params[0]; A.strategy = strategy_id; A.base_seed = base_seed;
+    A.out = out;
+    if (A.n_rows > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: batch too large");
+    const i64 grid = (A.n_rows + 3) / 4;
+    realign_tracks_kernel<<<dim3((unsigned)grid, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream>>>(A);
+    return check_launch("gvl_realign_tracks");
 }
 
 }  // extern "C"

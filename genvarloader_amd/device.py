@@ -316,3 +316,48 @@ def onehot(x: torch.Tensor) -> torch.Tensor:
     with torch.cuda.device(x.device):
         _lib.check(lib.gvl_onehot(_ptr(x), C.c_int64(x.numel()), _ptr(out), _stream_ptr()))
     return out
+
+
+# ------------------------------------------------------------------------------- tracks (a12)
+def intervals_to_tracks(offset_idxs, starts, itv_starts, itv_ends, itv_values, itv_offsets, out_offsets,
+                        device="cuda", starts_stride=1, max_row_len=None) -> torch.Tensor:
+    """intervals_to_tracks (src/intervals.rs:19-126) -> f32[out_offsets[-1]] device tensor."""
+    lib = _lib.load()
+    d = torch.device(device)
+    oi, st = _dev(offset_idxs, torch.int64, d), _dev(starts, torch.int32, d)
+    a, b = _dev(itv_starts, torch.int32, d), _dev(itv_ends, torch.int32, d)
+    v, io = _dev(itv_values, torch.float32, d), _dev(itv_offsets, torch.int64, d)
+    oo = _dev(out_offsets, torch.int64, d)
+    n = int(oi.numel())
+    total = int(oo[-1].item()) if n else 0
+    out = torch.empty(total, dtype=torch.float32, device=d)
+    if total == 0:
+        return out
+    if max_row_len is None:
+        max_row_len = int((oo[1:] - oo[:-1]).max().item())
+    with torch.cuda.device(d):
+        _lib.check(lib.gvl_intervals_to_tracks(_ptr(oi), _ptr(st), C.c_int64(starts_stride), C.c_int64(n), _ptr(a),
+                                               _ptr(b), _ptr(v), _ptr(io), _ptr(out), _ptr(oo),
+                                               C.c_int64(max_row_len), _stream_ptr()))
+    return out
+
+
+def realign_tracks(dev: "HapsDevice", regions, shifts, geno_offset_idx, out_offsets, tracks, track_offsets,
+                   params, strategy_id=0, base_seed=0, keep=None, keep_offsets=None, to_rc=None) -> torch.Tensor:
+    """shift_and_realign_tracks_sparse (src/tracks/mod.rs:495-667) + the reversal of negative-strand
+    rows (src/ffi/mod.rs:2657-2668) -> f32[out_offsets[-1]] device tensor."""
+    d = dev.device
+    with torch.cuda.device(d):
+        bt = dev.prepare_batch(regions, shifts, geno_offset_idx, -1, keep, keep_offsets, to_rc, out_offsets)
+        tr, to = _dev(tracks, torch.float32, d), _dev(track_offsets, torch.int64, d)
+        total = int(bt.out_offsets[-1].item()) if bt.n_rows else 0
+        out = torch.empty(total, dtype=torch.float32, device=d)
+        if total == 0:
+            return out
+        p = (C.c_double * 1)(float(np.asarray(params, np.float64).ravel()[0]))
+        _lib.check(dev.lib.gvl_realign_tracks(C.byref(dev.c), C.byref(bt.c), _ptr(tr), _ptr(to), p,
+                                              C.c_int64(int(strategy_id)),
+                                              C.c_uint64(int(base_seed) & 0xFFFFFFFFFFFFFFFF), _ptr(out),
+                                              _stream_ptr()))
+        out._keepalive = (bt, tr, to)
+        return out

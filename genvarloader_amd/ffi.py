@@ -13,6 +13,9 @@ here                                          reference
 ``reconstruct_annotated_haplotypes_fused``    ``src/ffi/mod.rs:2237-2397``
 ``get_diffs_sparse``                          ``src/ffi/mod.rs:143-185``
 ``get_reference``                             ``src/ffi/mod.rs:2401-2429``
+``intervals_to_tracks``                       ``src/ffi/mod.rs:188-240``
+``shift_and_realign_tracks_sparse``           ``src/tracks/mod.rs:495-667`` (in place)
+``intervals_and_realign_track_fused``         ``src/ffi/mod.rs:2551-2672`` (in place)
 ``reconstruct_haplotypes_fused_onehot``       new: fused one-hot (no counterpart;
                                               replaces the user-side ``sp.DNA.ohe``)
 ===========================================  ===================================
@@ -35,6 +38,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
+from . import device as _device
 from .device import HapsDevice, _starts_stops
 
 _STATIC_CACHE: "OrderedDict[tuple, HapsDevice]" = OrderedDict()
@@ -226,3 +230,60 @@ def _ref_static(reference, ref_offsets, pad_char) -> HapsDevice:
         while len(_REF_CACHE) > _STATIC_CACHE_MAX:
             _REF_CACHE.popitem(last=False)
     return dev
+
+
+# ------------------------------------------------------------------------------- tracks (a12)
+_TRACK_CACHE: "OrderedDict[tuple, HapsDevice]" = OrderedDict()
+
+
+def _track_static(geno_offsets, geno_v_idxs, v_starts, ilens) -> HapsDevice:
+    """Realignment reads only the genotype CSR + v_starts / ilens."""
+    arrs = tuple(np.asarray(a) for a in (geno_offsets, geno_v_idxs, v_starts, ilens))
+    geno_offsets, geno_v_idxs, v_starts, ilens = arrs
+    key = tuple(_key(a) for a in arrs)
+    dev = _TRACK_CACHE.get(key)
+    if dev is None:
+        n = len(ilens)
+        dev = HapsDevice(ref=np.zeros(1, np.uint8), ref_offsets=np.array([0, 1], np.int64),
+                         v_starts=_req(v_starts, np.int32, "v_starts", 1), ilens=_req(ilens, np.int32, "ilens", 1),
+                         alt_alleles=np.zeros(1, np.uint8), alt_offsets=np.zeros(n + 1, np.int64),
+                         geno_offsets=_starts_stops(geno_offsets),
+                         geno_v_idxs=_req(geno_v_idxs, np.int32, "geno_v_idxs", 1))
+        dev._host_refs = arrs
+        _TRACK_CACHE[key] = dev
+        while len(_TRACK_CACHE) > _STATIC_CACHE_MAX:
+            _TRACK_CACHE.popitem(last=False)
+    return dev
+
+
+def intervals_to_tracks(offset_idxs, starts, itv_starts, itv_ends, itv_values, itv_offsets, out, out_offsets,
+                        parallel=False):
+    """In place: paints `out` (src/ffi/mod.rs:188-240)."""
+    res = _device.intervals_to_tracks(offset_idxs, starts, itv_starts, itv_ends, itv_values, itv_offsets,
+                                      _req(out_offsets, np.int64, "out_offsets", 1))
+    out[...] = _np(res)
+
+
+def shift_and_realign_tracks_sparse(out, out_offsets, regions, shifts, geno_offset_idx, geno_v_idxs, geno_offsets,
+                                    v_starts, ilens, tracks, track_offsets, params, keep=None, keep_offsets=None,
+                                    strategy_id=0, base_seed=0, parallel=False):
+    """In place: argument order of the reference's wrapper (_tracks.py:42-60)."""
+    dev = _track_static(geno_offsets, geno_v_idxs, v_starts, ilens)
+    res = _device.realign_tracks(dev, regions, shifts, geno_offset_idx, _req(out_offsets, np.int64, "out_offsets", 1),
+                                 tracks, track_offsets, params, strategy_id, base_seed, keep, keep_offsets)
+    out[...] = _np(res)
+
+
+def intervals_and_realign_track_fused(out, out_offsets, regions, shifts, geno_offset_idx, geno_v_idxs, geno_offsets,
+                                      v_starts, ilens, offset_idxs, itv_starts, itv_ends, itv_values, itv_offsets,
+                                      track_offsets, params, strategy_id, base_seed, keep=None, keep_offsets=None,
+                                      to_rc=None, parallel=False):
+    """In place: paint -> realign -> reverse negative-strand rows (src/ffi/mod.rs:2551-2672).
+    The scratch track never leaves the device."""
+    dev = _track_static(geno_offsets, geno_v_idxs, v_starts, ilens)
+    regions = _req(regions, np.int32, "regions", 2)
+    scratch = _device.intervals_to_tracks(offset_idxs, np.ascontiguousarray(regions[:, 1]), itv_starts, itv_ends,
+                                          itv_values, itv_offsets, _req(track_offsets, np.int64, "track_offsets", 1))
+    res = _device.realign_tracks(dev, regions, shifts, geno_offset_idx, _req(out_offsets, np.int64, "out_offsets", 1),
+                                 scratch, track_offsets, params, strategy_id, base_seed, keep, keep_offsets, to_rc)
+    out[...] = _np(res)

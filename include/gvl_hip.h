@@ -178,6 +178,40 @@ int gvl_reverse_rows_4(void *data, const int64_t *offsets, const uint8_t *to_rc,
  * user-side sp.DNA.ohe(haps) (docs/source/index.md:114). */
 int gvl_onehot(const uint8_t *in, int64_t n, uint8_t *out, void *stream);
 
+
+/* ---- tracks (BASELINE config 4) ------------------------------------ */
+
+/* insertion-fill strategies (python/genvarloader/_dataset/_insertion_fill.py:9-13) */
+enum {
+    GVL_FILL_REPEAT_5P = 0,
+    GVL_FILL_REPEAT_5P_NORM = 1,
+    GVL_FILL_CONSTANT = 2,
+    GVL_FILL_FLANK_SAMPLE = 3,
+    GVL_FILL_INTERPOLATE = 4
+};
+
+/* Paint sorted (start, end, value) intervals into zeroed per-query f32 rows.
+ * Replaces intervals_to_tracks (src/ffi/mod.rs:188-240 -> src/intervals.rs:19-126).
+ * offset_idxs i64 (n_queries): index into itv_offsets; starts i32 read at `starts_stride`
+ * elements per query (regions + 1 with stride 4 works); out f32 (out_offsets[-1]);
+ * out_offsets i64 (n_queries + 1).  max_row_len: host bound of any row's length. */
+int gvl_intervals_to_tracks(const int64_t *offset_idxs, const int32_t *starts, int64_t starts_stride,
+                            int64_t n_queries, const int32_t *itv_starts, const int32_t *itv_ends,
+                            const float *itv_values, const int64_t *itv_offsets, float *out,
+                            const int64_t *out_offsets, int64_t max_row_len, void *stream);
+
+/* Shift and realign per-query reference-coordinate tracks to each haplotype.
+ * Replaces shift_and_realign_tracks_sparse (src/tracks/mod.rs:495-667; core :224-406,
+ * fills :87-190, PRNG :31-54) and the reversal step of intervals_and_realign_track_fused
+ * (src/ffi/mod.rs:2657-2668).  From `st` only the genotype CSR + v_starts/ilens are read;
+ * from `bt`: regions, shifts, geno_offset_idx, batch, ploidy, keep*, to_rc (reverse only,
+ * no complement), out_offsets (required: batch*ploidy + 1), max_row_len.
+ * tracks f32 with track_offsets i64 (batch + 1): one reference track per query.
+ * params: HOST pointer to the strategy's f64 parameter slot (1 value). */
+int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *tracks,
+                       const int64_t *track_offsets, const double *params, int64_t strategy_id,
+                       uint64_t base_seed, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -284,3 +284,72 @@ def onehot_numpy(x):
     """The 3-line numpy statement of the same definition (cross-check)."""
     x = np.asarray(x, np.uint8)
     return (x[..., None] == np.frombuffer(b"ACGT", np.uint8)).astype(np.uint8)
+
+
+# ----------------------------------------------------------------------------- tracks (a12)
+def xorshift64(x: int) -> int:
+    """src/tracks/mod.rs:31-36."""
+    lib().gvlo_xorshift64.restype = C.c_uint64
+    return int(lib().gvlo_xorshift64(C.c_uint64(int(x) & 0xFFFFFFFFFFFFFFFF)))
+
+
+def hash4(a: int, b: int, c: int, d: int) -> int:
+    """src/tracks/mod.rs:48-54."""
+    lib().gvlo_hash4.restype = C.c_uint64
+    m = 0xFFFFFFFFFFFFFFFF
+    return int(lib().gvlo_hash4(C.c_uint64(int(a) & m), C.c_uint64(int(b) & m), C.c_uint64(int(c) & m),
+                                C.c_uint64(int(d) & m)))
+
+
+def shift_and_realign_tracks_sparse(
+    out, out_offsets, regions, shifts, geno_offset_idx, geno_v_idxs, geno_offsets, v_starts, ilens,
+    tracks, track_offsets, params, keep=None, keep_offsets=None, strategy_id=0, base_seed=0,
+    parallel=False,
+):
+    """In place; argument order of the reference's wrapper (_tracks.py:42-60 ->
+    src/tracks/mod.rs:495-667)."""
+    assert out.dtype == np.float32 and out.flags.c_contiguous
+    oo = _c(out_offsets, np.int64)
+    regions = _c(regions, np.int32)
+    shifts = _c(shifts, np.int32)
+    goi = _c(geno_offset_idx, np.int64)
+    go = _starts_stops(geno_offsets)
+    go0, go1 = np.ascontiguousarray(go[0]), np.ascontiguousarray(go[1])
+    gv, vs, il = _c(geno_v_idxs, np.int32), _c(v_starts, np.int32), _c(ilens, np.int32)
+    tr, to = _c(tracks, np.float32), _c(track_offsets, np.int64)
+    pr = _c(params, np.float64)
+    kp, ko = _c(keep, np.bool_), _c(keep_offsets, np.int64)
+    batch, ploidy = goi.shape
+    lib().gvlo_realign_tracks_batch(
+        _p(out), _p(oo), _p(regions), C.c_int64(regions.shape[1]), C.c_int64(batch), C.c_int64(ploidy),
+        _p(shifts), _p(goi), _p(gv), _p(go0), _p(go1), _p(vs), _p(il), _p(tr), _p(to), _p(pr), _p(kp),
+        _p(ko), C.c_int64(int(strategy_id)), C.c_uint64(int(base_seed) & 0xFFFFFFFFFFFFFFFF))
+
+
+def intervals_to_tracks(offset_idxs, starts, itv_starts, itv_ends, itv_values, itv_offsets, out,
+                        out_offsets, parallel=False):
+    """In place (src/intervals.rs:19-126); `out` is zeroed first like the reference."""
+    assert out.dtype == np.float32 and out.flags.c_contiguous
+    oi, st = _c(offset_idxs, np.int64), _c(starts, np.int32)
+    a, b, v = _c(itv_starts, np.int32), _c(itv_ends, np.int32), _c(itv_values, np.float32)
+    io, oo = _c(itv_offsets, np.int64), _c(out_offsets, np.int64)
+    lib().gvlo_intervals_to_tracks(_p(oi), _p(st), C.c_int64(len(st)), _p(a), _p(b), _p(v), _p(io),
+                                   _p(out), _p(oo))
+
+
+def intervals_and_realign_track_fused(
+    out, out_offsets, regions, shifts, geno_offset_idx, geno_v_idxs, geno_offsets, v_starts, ilens,
+    offset_idxs, itv_starts, itv_ends, itv_values, itv_offsets, track_offsets, params, strategy_id,
+    base_seed, keep=None, keep_offsets=None, to_rc=None, parallel=False,
+):
+    """src/ffi/mod.rs:2551-2672: paint -> realign -> optional reversal (no complement)."""
+    regions = _c(regions, np.int32)
+    to = _c(track_offsets, np.int64)
+    scratch = np.zeros(int(to[-1]), np.float32)
+    intervals_to_tracks(offset_idxs, np.ascontiguousarray(regions[:, 1]), itv_starts, itv_ends,
+                        itv_values, itv_offsets, scratch, to)
+    shift_and_realign_tracks_sparse(out, out_offsets, regions, shifts, geno_offset_idx, geno_v_idxs,
+                                    geno_offsets, v_starts, ilens, scratch, to, params, keep,
+                                    keep_offsets, strategy_id, base_seed)
+    if to_rc is not None:
+        reverse_flat_rows_inplace(out, out_offsets, to_rc)
