@@ -597,7 +597,10 @@ __device__ __forceinline__ int wave_scan_exclusive(int v) {
 // Planned path.  A workgroup = 8 waves = 8 rows of one chunk index; wave w owns row w.
 //   P1  lanes 0..7 of wave 0 load the 8 rows' parameters (one lane per row), one barrier
 //   P2  the wave gathers its row's variant records, lane j = variant j
-//   P3  the reference's sequential walk, restated as wave-wide scans (shift == 0):
+//   P3  the reference's sequential walk, restated as wave-wide scans:
+//         * shift: the lead pad absorbs it first; while it is open ref_idx does not move, so
+//           the variants in front of the one that completes it are dropped and that one is
+//           kept / cut at the front / consumed (a ballot + ctz)
 //         * "first ALT wins": variant i is applied iff pos_i >= max(ref_idx0, v_end of every
 //           applied variant before it) -- an exclusive prefix-max, iterated to its (unique)
 //           fixed point when deletions knock out later variants
@@ -609,8 +612,8 @@ __device__ __forceinline__ int wave_scan_exclusive(int v) {
 //   P3b lanes 0..7, one per trip, turn the table into trip descriptors: "uniform" trips
 //       (inside ONE reference run) carry the source offset; plus the trip's patch slice
 //   P4  the wave streams its row from the descriptors, all reference loads issued first
-// Rows the scans do not take (shift != 0, > 64 variants, table overflow, extreme
-// coordinates, no fixed point in 4 rounds) run recon_wave_scalar instead.
+// Rows the scans do not take (> 64 variants, table overflow, coordinates >= 2^30, negative
+// shift, no fixed point in 4 rounds) run recon_wave_scalar instead.
 // ---------------------------------------------------------------------------------
 struct RowIn {
     i64 c_s, R, ref_start, shift, o_s, keep_off, row_base;
@@ -697,7 +700,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
                     if (A.dbg & 1) ri.n_var = 0;
                     if (has_keep) ri.keep_off = A.keep_offsets[k];
                 }
-                if (ri.n_var > WAVE || ri.shift != 0 || !planned_ok) fl |= 2;
+                if (ri.n_var > WAVE || ri.shift < 0 || ri.shift >= (1 << 30) || !planned_ok) fl |= 2;
             }
             ri.flags = fl;
         }
@@ -735,18 +738,53 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             if (has_keep) valid = A.keep[rfl64(ri.keep_off) + lane] != 0;
         }
         GVL_STAMP(3);
-        // ---- P3: the walk as scans (reconstruct/mod.rs:61-255 with shift == 0) ------------------
+        // ---- P3: the walk as scans (reconstruct/mod.rs:61-255) -----------------------------------
         // coordinates beyond 2^30 (or nonsense) go to the scalar path: everything below is i32
         const bool weird = valid && (pos < 0 || pos >= (1 << 30) || d <= -(1 << 30) || d >= (1 << 30) ||
                                      alen < 0 || alen >= (1 << 30));
         bool ok = __builtin_amdgcn_ballot_w64(weird) == 0 && ref_start > -(1 << 30) && ref_start < (1 << 30);
         const int E = pos - (d < 0 ? d : 0) + 1;                        // v_ref_end, :96
-        const int n_lead = ref_start < 0 ? ((-ref_start < L) ? -ref_start : L) : 0;   // :68-83
+        const bool is_snp = d == 0 && alen == 1;
+        // leading pad absorbs the shift first (:68-83)
+        const int shift_i = (int)rfl64(ri.shift);
+        const int raw = ref_start < 0 ? -ref_start : 0;
+        const int shifted0 = shift_i < raw ? shift_i : raw;
+        const int n_lead = (raw - shifted0 < L) ? raw - shifted0 : L;
         int ref_idx0 = ref_start < 0 ? 0 : ref_start;
         // DEL spanning the window start (:99-102): the last one in order sets ref_idx
         const u64 m_span = __builtin_amdgcn_ballot_w64(valid && pos < ref_start && d < 0 && E >= ref_start);
         if (m_span) ref_idx0 = rdl(E, 63 - __builtin_clzll(m_span));
-        const bool cand = valid && pos >= ref_start;
+        bool cand = valid && pos >= ref_start;
+        // shift consumption (:115-146).  While the shift is open ref_idx stays put, so the
+        // variants in front of the one that completes it are simply dropped; that one (lane f)
+        // either starts after the shifted origin, or loses the first `skip` bytes of its allele,
+        // or is consumed entirely.
+        const int rem = shift_i - shifted0;
+        if (rem > 0) {
+            const int base = ref_idx0;
+            const u64 m_t = __builtin_amdgcn_ballot_w64(cand && pos >= base && (pos - base) + alen >= rem);
+            if (m_t == 0) {
+                ref_idx0 = (int)imin((i64)base + rem, R);                 // :200-205
+                cand = false;
+            } else {
+                const int f = __builtin_ctzll(m_t);
+                const int dist = rdl(pos, f) - base;
+                if (dist >= rem) {
+                    ref_idx0 = base + rem;
+                    cand = cand && lane >= f;
+                } else {
+                    const int skip = rem - dist;
+                    if (skip == rdl(alen, f)) {
+                        ref_idx0 = rdl(E, f);
+                        cand = cand && lane > f;
+                    } else {
+                        ref_idx0 = rdl(pos, f);
+                        cand = cand && lane >= f;
+                        if (lane == f) { alen -= skip; a0 += skip; }
+                    }
+                }
+            }
+        }
         // first ALT wins (:108-110): fixed point of B = {i : pos_i >= max(ref_idx0, max E over B before i)}
         bool inB = cand;
         int PM = 0;
@@ -770,7 +808,6 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         const int allele_out = OpSat::f(OpSat::f(n_lead, X), n_i);
         const bool applied = inB && allele_out < L;                       // :154-158 break
         const int w_i = applied ? ((alen < L - allele_out) ? alen : L - allele_out) : 0;   // :178
-        const bool is_snp = d == 0 && alen == 1;
         const bool nonsnp = applied && !is_snp;
         const bool snp = applied && is_snp;
         // state after the loop
@@ -1768,6 +1805,14 @@ int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
     return 0;
 }
 
+// GVL_DBG (read once): test/diagnostic switches.  8 = force the scalar per-wave path for every
+// row (the GPU suite runs once this way); 1/2/4 = ablations (no variants / no stores / no loads)
+// that only make sense for timing.
+int debug_flags() {
+    static const int flags = [] { const char *e = getenv("GVL_DBG"); return e ? atoi(e) : 0; }();
+    return flags;
+}
+
 int log2_exact(i64 v) {
     for (int s = 0; s < 31; ++s) if ((1ll << s) == v) return s;
     return -1;
@@ -1838,7 +1883,7 @@ int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *ou
     int chunks = 1;
     if (pick_chunk(ml, &chunks, &A.chunk_len)) return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: too many chunks");
     A.ref_only = 0;
-    { const char *e = getenv("GVL_DBG"); A.dbg = e ? atoi(e) : 0; }
+    A.dbg = debug_flags();
     A.pad = st->pad_char;
     A.haps = out->haps; A.onehot = out->onehot;
     A.av = out->annot_v_idxs; A.ap = out->annot_ref_pos; A.out_offsets_w = (i64 *)out->out_offsets;

@@ -184,7 +184,7 @@ def _synth(seed, contigs, q, L, **kw):
     from genvarloader_amd import synth
 
     rng = np.random.default_rng(seed)
-    skw = {k: kw.pop(k) for k in ("indel_frac", "density", "af_beta", "n_frac") if k in kw}
+    skw = {k: kw.pop(k) for k in ("indel_frac", "density", "af_beta", "n_frac", "max_indel") if k in kw}
     st = synth.make_static(rng, contigs, **skw)
     bt = synth.make_batch(rng, st, q, 2, L, **kw)
     return st, bt
@@ -372,3 +372,18 @@ def test_empty_and_errors(gpu):
         dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, 100, haps=False, onehot=False)
     with pytest.raises(ValueError):  # channel-major one-hot is fixed-length only
         dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, -1, onehot=True, layout="cl")
+
+
+@pytest.mark.parametrize("seed", [71, 72, 73])
+def test_shift_stress_scan_path(gpu, oracle, seed):
+    """Large shifts (far beyond the reference's max_shift) on insertion-rich rows with <= 64
+    variants, so that the scan path's shift logic (drop / cut-into-allele / consume) is hit in
+    every sub-case, with and without leading pad and DELs spanning the window start."""
+    st, bt = _synth(seed, (30_000, 20_000), 96, 600, indel_frac=0.6, density=1 / 25, rc_frac=0.5,
+                    edge_frac=0.3, slack=60, lookback=80)
+    rng = np.random.default_rng(seed)
+    bt.shifts = rng.integers(0, 300, bt.shifts.shape).astype(np.int32)
+    bt.shifts[rng.random(bt.shifts.shape) < 0.2] = 0
+    idx = bt.geno_offset_idx.ravel()
+    assert (bt.geno_offsets[1, idx] - bt.geno_offsets[0, idx]).max() <= 64
+    check_batch(gpu, oracle, st, bt, annotate=True)

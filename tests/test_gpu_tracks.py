@@ -103,3 +103,54 @@ def test_tracks_long_rows_chunked(ffi, oracle):
     got = np.zeros(B * P * L, np.float32)
     ffi.intervals_and_realign_track_fused(got, *args)
     np.testing.assert_array_equal(bits(got), bits(exp))
+
+
+def test_cfg4_full_haps_and_track(ffi, oracle):
+    """BASELINE configs[3]: 256 windows x 131072 bp, SNP+indel, haplotype one-hot + one
+    realigned track (Repeat5p), full size."""
+    import time
+
+    import torch
+
+    from genvarloader_amd import HapsDevice, device, synth
+
+    st, bt = synth.make_config("cfg4", contig=32 << 20)
+    B, P = bt.geno_offset_idx.shape
+    L = bt.output_length
+    assert B * P == 256 and L == 131072
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=bt.geno_offsets,
+                     geno_v_idxs=bt.geno_v_idxs, pad_char=st.pad_char)
+    out = dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, L, to_rc=bt.to_rc, haps=True, onehot=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, L, to_rc=bt.to_rc, haps=True, onehot=True)
+    torch.cuda.synchronize()
+    t_h = time.perf_counter() - t0
+    exp, exp_off, exp_oh = oracle.reconstruct_haplotypes_fused(
+        bt.regions, bt.shifts, bt.geno_offset_idx, bt.geno_offsets, bt.geno_v_idxs, st.v_starts, st.ilens,
+        st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, L, None, None, bt.to_rc, True,
+        onehot=True, n_threads=8)
+    np.testing.assert_array_equal(out.haps.cpu().numpy(), exp)
+    np.testing.assert_array_equal(out.onehot.cpu().numpy(), exp_oh)
+    # one track per query: value changes every ~25 bp
+    rng = np.random.default_rng(5)
+    tlen = (bt.regions[:, 2] - bt.regions[:, 1]).astype(np.int64) + 4096
+    track_offsets = np.concatenate([[0], np.cumsum(tlen)]).astype(np.int64)
+    tracks = np.repeat(rng.random(int(track_offsets[-1]) // 25 + 1).astype(np.float32) * 8, 25)[: int(track_offsets[-1])]
+    out_offsets = np.arange(B * P + 1, dtype=np.int64) * L
+    exp_t = np.zeros(B * P * L, np.float32)
+    oracle.shift_and_realign_tracks_sparse(exp_t, out_offsets, bt.regions, bt.shifts, bt.geno_offset_idx,
+                                           bt.geno_v_idxs, bt.geno_offsets, st.v_starts, st.ilens, tracks,
+                                           track_offsets, np.array([0.0]), None, None, 0, 0)
+    dtracks = torch.from_numpy(tracks).cuda()
+    got = device.realign_tracks(dev, bt.regions, bt.shifts, bt.geno_offset_idx, out_offsets, dtracks,
+                                track_offsets, np.array([0.0]), 0, 0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = device.realign_tracks(dev, bt.regions, bt.shifts, bt.geno_offset_idx, out_offsets, dtracks,
+                                track_offsets, np.array([0.0]), 0, 0)
+    torch.cuda.synchronize()
+    t_t = time.perf_counter() - t0
+    np.testing.assert_array_equal(bits(got.cpu().numpy()), bits(exp_t))
+    print(f"\ncfg4: V/row={bt.mean_variants:.0f}  haps+onehot {t_h*1e3:.2f} ms  track {t_t*1e3:.2f} ms (host-timed, incl. upload)")
