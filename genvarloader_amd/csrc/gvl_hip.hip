@@ -592,6 +592,11 @@ template <typename Op>
 __device__ __forceinline__ int wave_scan_exclusive(int v) {
     return dpp_mov<0x138, 0xf>(Op::identity, wave_scan_inclusive<Op>(v));   // wave_shr:1
 }
+template <typename Op>
+__device__ __forceinline__ int wave_scan_exclusive(int v, int &inclusive) {
+    inclusive = wave_scan_inclusive<Op>(v);
+    return dpp_mov<0x138, 0xf>(Op::identity, inclusive);
+}
 
 // ---------------------------------------------------------------------------------
 // Planned path.  A workgroup = 8 waves = 8 rows of one chunk index; wave w owns row w.
@@ -700,7 +705,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
                     if (A.dbg & 1) ri.n_var = 0;
                     if (has_keep) ri.keep_off = A.keep_offsets[k];
                 }
-                if (ri.n_var > WAVE || ri.shift < 0 || ri.shift >= (1 << 30) || !planned_ok) fl |= 2;
+                if (ri.shift < 0 || ri.shift >= (1 << 30) || !planned_ok) fl |= 2;
             }
             ri.flags = fl;
         }
@@ -722,183 +727,201 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     int nseg = 0, npatch = 0;
 
     if (!(flags & 2)) {
-        // ---- P2: variant records (lane j = variant j) --------------------------------------
+        // ---- P2 + P3, 64 variants per trip with carries between trips ------------------------
         const int n_var = rfl(ri.n_var);
         const i64 o_s = rfl64(ri.o_s);
         const int ref_start = (int)rfl64(ri.ref_start);
         const i64 R = rfl64(ri.R);
-        int pos = 0, d = 0, alen = 0, inl = 0, vi = 0; i64 a0 = 0;
-        bool valid = lane < n_var;
-        if (valid) {
-            int v = A.geno_v_idxs[o_s + lane];
-            v = v < 0 ? 0 : ((i64)v >= A.n_variants ? (int)(A.n_variants - 1) : v);
-            const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.vrec + v);
-            a0 = A.alt_offsets[v];
-            pos = rec.x; d = rec.y; alen = rec.z; inl = rec.w; vi = v;
-            if (has_keep) valid = A.keep[rfl64(ri.keep_off) + lane] != 0;
-        }
-        GVL_STAMP(3);
-        // ---- P3: the walk as scans (reconstruct/mod.rs:61-255) -----------------------------------
-        // coordinates beyond 2^30 (or nonsense) go to the scalar path: everything below is i32
-        const bool weird = valid && (pos < 0 || pos >= (1 << 30) || d <= -(1 << 30) || d >= (1 << 30) ||
-                                     alen < 0 || alen >= (1 << 30));
-        bool ok = __builtin_amdgcn_ballot_w64(weird) == 0 && ref_start > -(1 << 30) && ref_start < (1 << 30);
-        const int E = pos - (d < 0 ? d : 0) + 1;                        // v_ref_end, :96
-        const bool is_snp = d == 0 && alen == 1;
+        const i64 keep_off = has_keep ? rfl64(ri.keep_off) : 0;
+        bool ok = ref_start > -(1 << 30) && ref_start < (1 << 30);
         // leading pad absorbs the shift first (:68-83)
         const int shift_i = (int)rfl64(ri.shift);
         const int raw = ref_start < 0 ? -ref_start : 0;
         const int shifted0 = shift_i < raw ? shift_i : raw;
         const int n_lead = (raw - shifted0 < L) ? raw - shifted0 : L;
-        int ref_idx0 = ref_start < 0 ? 0 : ref_start;
-        // DEL spanning the window start (:99-102): the last one in order sets ref_idx
-        const u64 m_span = __builtin_amdgcn_ballot_w64(valid && pos < ref_start && d < 0 && E >= ref_start);
-        if (m_span) ref_idx0 = rdl(E, 63 - __builtin_clzll(m_span));
-        bool cand = valid && pos >= ref_start;
-        // shift consumption (:115-146).  While the shift is open ref_idx stays put, so the
-        // variants in front of the one that completes it are simply dropped; that one (lane f)
-        // either starts after the shifted origin, or loses the first `skip` bytes of its allele,
-        // or is consumed entirely.
-        const int rem = shift_i - shifted0;
-        if (rem > 0) {
-            const int base = ref_idx0;
-            const u64 m_t = __builtin_amdgcn_ballot_w64(cand && pos >= base && (pos - base) + alen >= rem);
-            if (m_t == 0) {
-                ref_idx0 = (int)imin((i64)base + rem, R);                 // :200-205
-                cand = false;
-            } else {
-                const int f = __builtin_ctzll(m_t);
-                const int dist = rdl(pos, f) - base;
-                if (dist >= rem) {
-                    ref_idx0 = base + rem;
-                    cand = cand && lane >= f;
-                } else {
-                    const int skip = rem - dist;
-                    if (skip == rdl(alen, f)) {
-                        ref_idx0 = rdl(E, f);
-                        cand = cand && lane > f;
-                    } else {
-                        ref_idx0 = rdl(pos, f);
-                        cand = cand && lane >= f;
-                        if (lane == f) { alen -= skip; a0 += skip; }
-                    }
-                }
-            }
-        }
-        // first ALT wins (:108-110): fixed point of B = {i : pos_i >= max(ref_idx0, max E over B before i)}
-        bool inB = cand;
-        int PM = 0;
-        {
-            u64 mB = __builtin_amdgcn_ballot_w64(inB);
-            bool stable = false;
-#pragma unroll 1
-            for (int it = 0; it < 4 && !stable; ++it) {
-                PM = wave_scan_exclusive<OpMaxU>(inB ? E : 0);
-                PM = PM > ref_idx0 ? PM : ref_idx0;
-                inB = cand && pos >= PM;
-                const u64 m2 = __builtin_amdgcn_ballot_w64(inB);
-                stable = m2 == mB;
-                mB = m2;
-            }
-            ok = ok && stable;
-        }
-        // output offsets: exclusive prefix sum of (reference run + allele)      (the indel shift)
-        const int n_i = inB ? pos - PM : 0;
-        const int X = wave_scan_exclusive<OpSat>(inB ? OpSat::f(n_i, alen) : 0);
-        const int allele_out = OpSat::f(OpSat::f(n_lead, X), n_i);
-        const bool applied = inB && allele_out < L;                       // :154-158 break
-        const int w_i = applied ? ((alen < L - allele_out) ? alen : L - allele_out) : 0;   // :178
-        const bool nonsnp = applied && !is_snp;
-        const bool snp = applied && is_snp;
-        // state after the loop
-        const u64 m_app = __builtin_amdgcn_ballot_w64(applied);
-        int ref_idx_end = ref_idx0, out_idx_end = n_lead;
-        if (m_app) {
-            const int last = 63 - __builtin_clzll(m_app);
-            ref_idx_end = rdl(E, last);
-            out_idx_end = rdl(allele_out, last) + rdl(w_i, last);
-        }
-        // the reference run in front of each applied indel starts after the previous applied indel
-        const int prevNS = wave_scan_exclusive<OpMaxI>(nonsnp ? lane : -1);
-        const int pidx = prevNS < 0 ? 0 : prevNS;
-        const int p_end = bperm(pidx, allele_out + alen);                 // not truncated: it has a successor
-        const int p_E = bperm(pidx, E);
-        const int run_start = prevNS < 0 ? n_lead : p_end;
-        const i64 run_src = c_s + (prevNS < 0 ? ref_idx0 : p_E);
-        const bool e_ref = nonsnp && allele_out > run_start && allele_out > lo_clip && run_start < hi_clip;
-        const bool e_all = nonsnp && w_i > 0 && allele_out + w_i > lo_clip && allele_out < hi_clip;
+        int rem = shift_i - shifted0;                  // shift still open
+        int ref_idx0 = ref_start < 0 ? 0 : ref_start;  // ref_idx before the first applied variant
+        int pm_carry = ref_idx0;                       // max(ref_idx0, v_end of every applied variant so far)
+        int x_carry = 0;                               // output bases produced by the applied variants so far
+        bool ended = false;                            // the ">= L" break has happened
+        bool have_ns = false; int ns_end = 0, ns_E = 0;   // last applied indel: allele end (out), v_end (ref)
+        int ref_idx_end = ref_idx0, out_idx_end = n_lead; // walk state after the last applied variant
+        bool any_applied = false;
         const int lead_kept = (n_lead > 0 && n_lead > lo_clip && 0 < hi_clip) ? 1 : 0;
-        const int slot0 = lead_kept + wave_scan_exclusive<OpAdd>((e_ref ? 1 : 0) + (e_all ? 1 : 0));
-        const u64 m_ns = __builtin_amdgcn_ballot_w64(nonsnp);
         int n_ent = lead_kept;
-        {
-            const u64 m1 = __builtin_amdgcn_ballot_w64(e_ref), m2 = __builtin_amdgcn_ballot_w64(e_all);
-            n_ent += __builtin_popcountll(m1) + __builtin_popcountll(m2);
-        }
-        // tail: the run after the last applied indel (through any SNPs) + contig end + right pad (:200-255)
-        int t_start = n_lead; i64 t_src = c_s + ref_idx0;
-        if (m_ns) {
-            const int last = 63 - __builtin_clzll(m_ns);
-            t_start = rdl(allele_out, last) + rdl(alen, last);
-            t_src = c_s + rdl(E, last);
-        }
-        int t_end = out_idx_end;
-        {
-            const int u = L - out_idx_end;
-            if (u > 0) {
-                const i64 avail = R - ref_idx_end;
-                const int w = (int)imin((i64)u, avail);
-                if (w > 0) t_end = out_idx_end + w;
+        bool past_chunk = false;                       // every later variant lands at or after hi_clip
+        auto enc = [](u32 kind, i64 delta, u32 &lo, u32 &hi) {
+            const u64 e = (u64)(delta + DELTA_BIAS) | ((u64)kind << 62);
+            lo = (u32)e; hi = (u32)(e >> 32);
+        };
+        auto put = [&](int q, u32 kind, int o_start, i64 delta, int id, int vpos) {
+            if (q < SEG_CAP) {
+                u32 lo, hi; enc(kind, delta, lo, hi);
+                pl.s_out[q] = o_start; pl.s_lo[q] = lo; pl.s_hi[q] = hi;
+                if (ANNOT) { pl.s_a[q] = id; pl.s_b[q] = vpos; }
             }
+        };
+
+        for (int tb = 0; tb < n_var && ok && !ended && !past_chunk; tb += WAVE) {
+            int pos = 0, d = 0, alen = 0, inl = 0, vi = 0; i64 a0 = 0;
+            bool valid = tb + lane < n_var;
+            if (valid) {
+                int v = A.geno_v_idxs[o_s + tb + lane];
+                v = v < 0 ? 0 : ((i64)v >= A.n_variants ? (int)(A.n_variants - 1) : v);
+                const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.vrec + v);
+                a0 = A.alt_offsets[v];
+                pos = rec.x; d = rec.y; alen = rec.z; inl = rec.w; vi = v;
+                if (has_keep) valid = A.keep[keep_off + tb + lane] != 0;
+            }
+            // coordinates beyond 2^30 (or nonsense) go to the scalar path: everything below is i32
+            const bool weird = valid && (pos < 0 || pos >= (1 << 30) || d <= -(1 << 30) || d >= (1 << 30) ||
+                                         alen < 0 || alen >= (1 << 30));
+            ok = ok && __builtin_amdgcn_ballot_w64(weird) == 0;
+            const int E = pos - (d < 0 ? d : 0) + 1;                        // v_ref_end, :96
+            const bool is_snp = d == 0 && alen == 1;
+            // DEL spanning the window start (:99-102): the last one in order sets ref_idx.  Such
+            // variants precede every candidate (sorted by position), so nothing is applied yet.
+            const u64 m_span = __builtin_amdgcn_ballot_w64(valid && pos < ref_start && d < 0 && E >= ref_start);
+            if (m_span) { ref_idx0 = rdl(E, 63 - __builtin_clzll(m_span)); pm_carry = ref_idx0; ref_idx_end = ref_idx0; }
+            bool cand = valid && pos >= ref_start;
+            // shift consumption (:115-146).  While the shift is open ref_idx stays put, so the
+            // variants in front of the one that completes it are simply dropped; that one (lane f)
+            // either starts after the shifted origin, or loses the first `skip` bytes of its
+            // allele, or is consumed entirely.
+            if (rem > 0) {
+                const int base = ref_idx0;
+                const u64 m_t = __builtin_amdgcn_ballot_w64(cand && pos >= base && (pos - base) + alen >= rem);
+                if (m_t == 0) {
+                    cand = false;                      // still open after this trip
+                } else {
+                    const int f = __builtin_ctzll(m_t);
+                    const int dist = rdl(pos, f) - base;
+                    if (dist >= rem) {
+                        ref_idx0 = base + rem;
+                        cand = cand && lane >= f;
+                    } else {
+                        const int skip = rem - dist;
+                        if (skip == rdl(alen, f)) {
+                            ref_idx0 = rdl(E, f);
+                            cand = cand && lane > f;
+                        } else {
+                            ref_idx0 = rdl(pos, f);
+                            cand = cand && lane >= f;
+                            if (lane == f) { alen -= skip; a0 += skip; }
+                        }
+                    }
+                    rem = 0;
+                    pm_carry = ref_idx0; ref_idx_end = ref_idx0;
+                }
+            }
+            // first ALT wins (:108-110): fixed point of B = {i : pos_i >= max(carry, max E over B before i)}
+            bool inB = cand;
+            int PM = 0, pm_incl = 0;
+            {
+                u64 mB = __builtin_amdgcn_ballot_w64(inB);
+                bool stable = false;
+#pragma unroll 1
+                for (int it = 0; it < 4 && !stable; ++it) {
+                    PM = wave_scan_exclusive<OpMaxU>(inB ? E : 0, pm_incl);
+                    PM = PM > pm_carry ? PM : pm_carry;
+                    inB = cand && pos >= PM;
+                    const u64 m2 = __builtin_amdgcn_ballot_w64(inB);
+                    stable = m2 == mB;
+                    mB = m2;
+                }
+                ok = ok && stable;
+            }
+            // output offsets: exclusive prefix sum of (reference run + allele)      (the indel shift)
+            const int n_i = inB ? pos - PM : 0;
+            const int S_i = inB ? OpSat::f(n_i, alen) : 0;
+            int x_incl;
+            const int X = OpSat::f(x_carry, wave_scan_exclusive<OpSat>(S_i, x_incl));
+            const int allele_out = OpSat::f(OpSat::f(n_lead, X), n_i);
+            const bool applied = inB && allele_out < L;                       // :154-158 break
+            const int w_i = applied ? ((alen < L - allele_out) ? alen : L - allele_out) : 0;   // :178
+            const bool nonsnp = applied && !is_snp;
+            const bool snp = applied && is_snp;
+            const u64 m_inB = __builtin_amdgcn_ballot_w64(inB);
+            const u64 m_app = __builtin_amdgcn_ballot_w64(applied);
+            if (m_inB != m_app) ended = true;
+            if (m_app) {
+                const int last = 63 - __builtin_clzll(m_app);
+                ref_idx_end = rdl(E, last);
+                out_idx_end = rdl(allele_out, last) + rdl(w_i, last);
+                any_applied = true;
+                if (rdl(allele_out, last) >= hi_clip) past_chunk = true;
+            }
+            // the reference run in front of each applied indel starts after the previous applied indel
+            const int prevNS = wave_scan_exclusive<OpMaxI>(nonsnp ? lane : -1);
+            const int pidx = prevNS < 0 ? 0 : prevNS;
+            const int p_end = bperm(pidx, allele_out + alen);                 // not truncated: it has a successor
+            const int p_E = bperm(pidx, E);
+            const int run_start = prevNS < 0 ? (have_ns ? ns_end : n_lead) : p_end;
+            const i64 run_src = c_s + (prevNS < 0 ? (have_ns ? ns_E : ref_idx0) : p_E);
+            const bool e_ref = nonsnp && allele_out > run_start && allele_out > lo_clip && run_start < hi_clip;
+            const bool e_all = nonsnp && w_i > 0 && allele_out + w_i > lo_clip && allele_out < hi_clip;
+            const int slot0 = n_ent + wave_scan_exclusive<OpAdd>((e_ref ? 1 : 0) + (e_all ? 1 : 0));
+            const u64 m_ns = __builtin_amdgcn_ballot_w64(nonsnp);
+            const u64 m_snp = __builtin_amdgcn_ballot_w64(snp && allele_out >= lo_clip && allele_out < hi_clip);
+            const int add_ent = __builtin_popcountll(__builtin_amdgcn_ballot_w64(e_ref)) +
+                                __builtin_popcountll(__builtin_amdgcn_ballot_w64(e_all));
+            const int add_pat = __builtin_popcountll(m_snp);
+            if (n_ent + add_ent + 2 > SEG_CAP || npatch + add_pat > WAVE) ok = false;
+            if (ok) {
+                int q = slot0;
+                if (e_ref) { put(q, K_REF, run_start, run_src - run_start, -1, -1); ++q; }
+                if (e_all) put(q, K_ALLELE, allele_out, a0 - allele_out, vi, pos);
+                if ((m_snp >> lane) & 1ull) {
+                    const int ps = npatch + __builtin_popcountll(m_snp & ((1ull << lane) - 1ull));
+                    pl.p_out[ps] = allele_out; pl.p_val[ps] = inl & 0xFF;
+                    if (ANNOT) pl.p_id[ps] = vi;
+                }
+            }
+            // carries
+            if (tb + WAVE < n_var) {
+                // pm_incl is the scan of the last fixed-point round, whose input mask equals
+                // the final one (that is what "stable" means)
+                const int mx = rdl(pm_incl, 63);
+                pm_carry = mx > pm_carry ? mx : pm_carry;
+                x_carry = OpSat::f(x_carry, rdl(x_incl, 63));
+            }
+            if (m_ns) {
+                const int last = 63 - __builtin_clzll(m_ns);
+                ns_end = rdl(allele_out, last) + rdl(alen, last);
+                ns_E = rdl(E, last);
+                have_ns = true;
+            }
+            n_ent += add_ent;
+            npatch += add_pat;
         }
-        const bool tail_ref = t_end > t_start && t_end > lo_clip && t_start < hi_clip;
-        const bool tail_pad = t_end < L && L > lo_clip && t_end < hi_clip;
-        const int n_total = n_ent + (tail_ref ? 1 : 0) + (tail_pad ? 1 : 0);
-        const u64 m_snp = __builtin_amdgcn_ballot_w64(snp && allele_out >= lo_clip && allele_out < hi_clip);
-        ok = ok && n_total <= SEG_CAP;
+        GVL_STAMP(3);
         if (ok) {
-            auto enc = [](u32 kind, i64 delta, u32 &lo, u32 &hi) {
-                const u64 e = (u64)(delta + DELTA_BIAS) | ((u64)kind << 62);
-                lo = (u32)e; hi = (u32)(e >> 32);
-            };
+            // the run after the last applied indel (through any SNPs), then -- if the walk ran to
+            // its end -- the rest of the contig and the right pad (:200-255)
+            if (rem > 0) ref_idx_end = (int)imin((i64)ref_idx0 + rem, R);     // shift never completed
+            const int t_start = have_ns ? ns_end : n_lead;
+            const i64 t_src = c_s + (have_ns ? ns_E : ((rem > 0 && !any_applied) ? ref_idx_end : ref_idx0));
+            int t_end = out_idx_end;
+            bool tail_pad = false;
+            if (past_chunk && !ended) {
+                t_end = hi_clip;                        // open run: covers the rest of this chunk
+            } else {
+                const int u = L - out_idx_end;
+                if (u > 0) {
+                    const i64 avail = R - ref_idx_end;
+                    const int w = (int)imin((i64)u, avail);
+                    if (w > 0) t_end = out_idx_end + w;
+                }
+                tail_pad = t_end < L && L > lo_clip && t_end < hi_clip;
+            }
+            const bool tail_ref = t_end > t_start && t_end > lo_clip && t_start < hi_clip;
             if (lane == 0) {
-                if (lead_kept) {
-                    u32 lo, hi; enc(K_PAD_LEAD, 0, lo, hi);
-                    pl.s_out[0] = 0; pl.s_lo[0] = lo; pl.s_hi[0] = hi;
-                    if (ANNOT) { pl.s_a[0] = -1; pl.s_b[0] = -1; }
-                }
+                if (lead_kept) put(0, K_PAD_LEAD, 0, 0, -1, -1);
                 int q = n_ent;
-                if (tail_ref) {
-                    u32 lo, hi; enc(K_REF, t_src - t_start, lo, hi);
-                    pl.s_out[q] = t_start; pl.s_lo[q] = lo; pl.s_hi[q] = hi;
-                    if (ANNOT) { pl.s_a[q] = -1; pl.s_b[q] = -1; }
-                    ++q;
-                }
-                if (tail_pad) {
-                    u32 lo, hi; enc(K_PAD_TRAIL, 0, lo, hi);
-                    pl.s_out[q] = t_end; pl.s_lo[q] = lo; pl.s_hi[q] = hi;
-                    if (ANNOT) { pl.s_a[q] = -1; pl.s_b[q] = -1; }
-                }
+                if (tail_ref) { put(q, K_REF, t_start, t_src - t_start, -1, -1); ++q; }
+                if (tail_pad) put(q, K_PAD_TRAIL, t_end, 0, -1, -1);
             }
-            int q = slot0;
-            if (e_ref) {
-                u32 lo, hi; enc(K_REF, run_src - run_start, lo, hi);
-                pl.s_out[q] = run_start; pl.s_lo[q] = lo; pl.s_hi[q] = hi;
-                if (ANNOT) { pl.s_a[q] = -1; pl.s_b[q] = -1; }
-                ++q;
-            }
-            if (e_all) {
-                u32 lo, hi; enc(K_ALLELE, a0 - allele_out, lo, hi);
-                pl.s_out[q] = allele_out; pl.s_lo[q] = lo; pl.s_hi[q] = hi;
-                if (ANNOT) { pl.s_a[q] = vi; pl.s_b[q] = pos; }
-            }
-            if ((m_snp >> lane) & 1ull) {
-                const int ps = __builtin_popcountll(m_snp & ((1ull << lane) - 1ull));
-                pl.p_out[ps] = allele_out; pl.p_val[ps] = inl & 0xFF;
-                if (ANNOT) pl.p_id[ps] = vi;
-            }
-            nseg = n_total;
-            npatch = __builtin_popcountll(m_snp);
+            nseg = n_ent + (tail_ref ? 1 : 0) + (tail_pad ? 1 : 0);
         } else {
             flags |= 2;
         }
@@ -928,8 +951,17 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         const int p0 = lo_clip + lane * TRIP;
         if (p0 < limit) {
             const int t_end = (limit - p0 > TRIP) ? p0 + TRIP : limit;
+            // entry holding p0 = (#entries starting at or before p0) - 1.  The first 8 starts are
+            // read in one go (independent LDS reads); longer tables continue with a loop.
             int idx = 0;
-            for (int s2 = 1; s2 < nseg; ++s2) idx += (pl.s_out[s2] <= p0) ? 1 : 0;
+            {
+                int so[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) so[j] = pl.s_out[j];
+#pragma unroll
+                for (int j = 1; j < 8; ++j) idx += (j < nseg && so[j] <= p0) ? 1 : 0;
+                for (int s2 = 8; s2 < nseg; ++s2) idx += (pl.s_out[s2] <= p0) ? 1 : 0;
+            }
             auto at = [&](int i) { return i < SEG_CAP ? i : SEG_CAP - 1; };
             const int b1 = idx + 1 < nseg ? pl.s_out[at(idx + 1)] : limit;
             const int b2 = idx + 2 < nseg ? pl.s_out[at(idx + 2)] : limit;
@@ -952,10 +984,20 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             if (cls >= 1 && cls < 3) okb = okb && in_bounds(d_lo1, d_hi1, b1, b2 < t_end ? b2 : t_end);
             if (cls == 2) okb = okb && in_bounds(d_lo2, d_hi2, b2, t_end);
             if (!okb || ((t_end - p0) & 3) != 0 || ref_zero_fill) cls = 3;
-            for (int q = 0; q < npatch; ++q) {
-                const int pp = pl.p_out[q];
-                d_pc0 += pp < p0 ? 1 : 0;
-                d_pcn += pp < t_end ? 1 : 0;
+            {
+                int po[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) po[j] = pl.p_out[j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    d_pc0 += (j < npatch && po[j] < p0) ? 1 : 0;
+                    d_pcn += (j < npatch && po[j] < t_end) ? 1 : 0;
+                }
+                for (int q = 8; q < npatch; ++q) {
+                    const int pp = pl.p_out[q];
+                    d_pc0 += pp < p0 ? 1 : 0;
+                    d_pcn += pp < t_end ? 1 : 0;
+                }
             }
             d_cls = cls; d_b1 = b1; d_b2 = b2; d_idx = idx;
         }
