@@ -1,0 +1,113 @@
+"""Device-side request prep + loader surface."""
+
+import numpy as np
+import pytest
+import torch
+
+from genvarloader_amd import synth
+from genvarloader_amd.loader import build_request
+
+
+def _grid_dataset(seed, R, S, P, L, contig=200_000, **kw):
+    """Regions x samples x ploidy genotype grid laid out like the reference's sparse genotypes."""
+    rng = np.random.default_rng(seed)
+    st = synth.make_static(rng, (contig,), indel_frac=kw.pop("indel_frac", 0.2), density=1 / 80)
+    base = synth.make_batch(rng, st, R, 1, L, rc_frac=0.5, slack=kw.pop("slack", 40))
+    full_regions = base.regions                                     # (R, 4)
+    # genotype CSR for every (region, sample, ploid): reuse make_batch's sampler per sample
+    lists = []
+    for r in range(R):
+        lo = np.searchsorted(st.v_starts, full_regions[r, 1] - 40)
+        hi = np.searchsorted(st.v_starts, full_regions[r, 2])
+        cand = np.arange(lo, hi)
+        for s in range(S):
+            for p in range(P):
+                lists.append(cand[rng.random(len(cand)) < st.af[cand]].astype(np.int32))
+    lens = np.array([len(x) for x in lists])
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    geno_offsets = np.ascontiguousarray(np.stack([offs[:-1], offs[1:]]))
+    geno_v_idxs = np.concatenate(lists) if lists else np.zeros(0, np.int32)
+    return st, full_regions, geno_offsets, geno_v_idxs
+
+
+def test_build_request_matches_reference_index_math():
+    R, S, P = 7, 5, 2
+    rng = np.random.default_rng(0)
+    full = np.stack([np.zeros(R), rng.integers(0, 1000, R), np.zeros(R), rng.choice([-1, 1], R)], 1).astype(np.int32)
+    full[:, 2] = full[:, 1] + 100
+    idx = rng.permutation(R * S)[:11]
+    regions, goi, to_rc, lengths = build_request(torch.from_numpy(idx), torch.from_numpy(full), S, P)
+    r_idx, s_idx = np.unravel_index(idx, (R, S))                   # _torch.py:299, _query.py:161
+    np.testing.assert_array_equal(regions.numpy(), full[r_idx])
+    exp_goi = np.ravel_multi_index((r_idx[:, None], s_idx[:, None], np.arange(P)), (R, S, P))   # _haps.py:757-768
+    np.testing.assert_array_equal(goi.numpy(), exp_goi)
+    np.testing.assert_array_equal(to_rc.numpy().astype(bool), np.repeat(full[r_idx, 3] == -1, P))   # _haps.py:838-843
+    np.testing.assert_array_equal(lengths.numpy(), 100)
+    # jitter keeps the region length and stays within +-j (_query.py:166-171)
+    g = torch.Generator().manual_seed(1)
+    rj, _, _, _ = build_request(torch.from_numpy(idx), torch.from_numpy(full), S, P, jitter=5, generator=g)
+    d = rj[:, 1].numpy() - full[r_idx, 1]
+    assert (np.abs(d) <= 5).all() and len(set(d.tolist())) > 1
+    np.testing.assert_array_equal(rj[:, 2].numpy() - rj[:, 1].numpy(), 100)
+
+
+@pytest.mark.gpu
+def test_loader_deterministic_matches_oracle(oracle):
+    from genvarloader_amd import HapsDevice
+    from genvarloader_amd.loader import DeviceHapsDataset
+
+    R, S, P, L = 6, 9, 2, 777
+    st, full_regions, go, gv = _grid_dataset(3, R, S, P, L)
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+    ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, onehot=True, haps=True)
+    assert len(ds) == R * S and ds.shape == (R, S)
+    seen = 0
+    for batch in ds.to_dataloader(batch_size=8, shuffle=False, in_flight=3):
+        idx = batch.idx.cpu().numpy()
+        r_idx, s_idx = np.unravel_index(idx, (R, S))
+        regions = full_regions[r_idx]
+        goi = np.ravel_multi_index((r_idx[:, None], s_idx[:, None], np.arange(P)), (R, S, P))
+        to_rc = np.repeat(regions[:, 3] == -1, P)
+        exp, _, exp_oh = oracle.reconstruct_haplotypes_fused(
+            regions, np.zeros_like(goi, dtype=np.int32), goi, go, gv, st.v_starts, st.ilens, st.alt_alleles,
+            st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, L, None, None, to_rc, False, onehot=True)
+        assert batch.onehot.shape == (len(idx), P, L, 4) and batch.haps.shape == (len(idx), P, L)
+        np.testing.assert_array_equal(batch.haps.cpu().numpy().ravel(), exp)
+        np.testing.assert_array_equal(batch.onehot.cpu().numpy().reshape(-1, 4), exp_oh)
+        seen += len(idx)
+    assert seen == R * S
+
+
+@pytest.mark.gpu
+def test_loader_random_shifts_and_jitter(oracle):
+    from genvarloader_amd import HapsDevice
+    from genvarloader_amd.loader import DeviceHapsDataset
+
+    R, S, P, L = 5, 8, 2, 500
+    st, full_regions, go, gv = _grid_dataset(4, R, S, P, L + 80, indel_frac=0.5, slack=0)
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+    ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, jitter=3, deterministic=False, seed=7,
+                           onehot=True, haps=True)
+    all_shifts = []
+    for batch in ds.to_dataloader(batch_size=10, shuffle=True, generator=torch.Generator().manual_seed(0)):
+        regions = batch.regions.cpu().numpy()
+        shifts = batch.shifts.cpu().numpy()
+        goi = batch.geno_offset_idx.cpu().numpy()
+        # the request is internally consistent: shifts in [0, max_shift] (_haps.py:728-730)
+        diffs = oracle.get_diffs_sparse(goi, gv, go, st.ilens, None, None, regions[:, 1], regions[:, 2], st.v_starts)
+        max_shift = np.clip(diffs, 0, None) + np.clip((regions[:, 2] - regions[:, 1]) - L, 0, None)[:, None]
+        assert (shifts >= 0).all() and (shifts <= max_shift).all()
+        all_shifts.append(shifts.ravel())
+        # and the output is the reference's for exactly that request
+        to_rc = None if batch.to_rc is None else batch.to_rc.cpu().numpy().astype(bool)
+        exp, _, exp_oh = oracle.reconstruct_haplotypes_fused(
+            regions, shifts, goi, go, gv, st.v_starts, st.ilens, st.alt_alleles, st.alt_offsets, st.ref,
+            st.ref_offsets, st.pad_char, L, None, None, to_rc, False, onehot=True)
+        np.testing.assert_array_equal(batch.haps.cpu().numpy().ravel(), exp)
+        np.testing.assert_array_equal(batch.onehot.cpu().numpy().reshape(-1, 4), exp_oh)
+    s = np.concatenate(all_shifts)
+    assert s.max() > 0 and len(s) == R * S * P
