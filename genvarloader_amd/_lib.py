@@ -30,6 +30,7 @@ SYMBOLS = (
     "gvl_onehot",
     "gvl_intervals_to_tracks",
     "gvl_realign_tracks",
+    "gvl_prepare_request",
 )
 
 GVL_ONEHOT_LC = 0

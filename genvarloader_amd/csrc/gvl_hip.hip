@@ -1809,6 +1809,54 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------
+// Device-side request prep: one thread per query (see gvl_prepare_request in gvl_hip.h).
+// ---------------------------------------------------------------------------------
+struct PrepArgs {
+    DiffArgs D;               // CSR + ilens / v_starts for the shift bound
+    const i64 *idx; i64 batch; const int *full_regions; i64 n_regions; i64 n_samples; int ploidy;
+    int jitter; int rc_neg; int deterministic; i64 output_length; u64 seed; u64 counter;
+    int *regions; i64 *goi; u8 *to_rc; int *shifts;
+};
+
+__global__ __launch_bounds__(256) void prepare_request_kernel(const PrepArgs A) {
+    const i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= A.batch) return;
+    i64 id = A.idx[b];
+    const i64 n = A.n_regions * A.n_samples;
+    id = id < 0 ? 0 : (id >= n ? n - 1 : id);
+    const i64 r = id / A.n_samples, s = id - r * A.n_samples;       // np.unravel_index(idx, (R, S))
+    const int *src = A.full_regions + r * 4;
+    int start = src[1], end = src[2];
+    const int len = end - start;
+    if (A.jitter > 0) {                                              // _query.py:166-171
+        const u64 h = hash4_dev(A.seed, A.counter, (u64)b, 0x6a69747465ull);
+        start += (int)(h % (u64)(2 * A.jitter + 1)) - A.jitter;
+        end = start + len;
+    }
+    int *dst = A.regions + b * 4;
+    dst[0] = src[0]; dst[1] = start; dst[2] = end; dst[3] = src[3];
+    const u8 rc = (A.rc_neg && src[3] == -1) ? 1 : 0;               // _query.py:173-175
+    for (int p = 0; p < A.ploidy; ++p) {
+        const i64 k = b * A.ploidy + p;
+        A.goi[k] = (r * A.n_samples + s) * A.ploidy + p;            // _haps.py:757-768
+        A.to_rc[k] = rc;
+        int shift = 0;
+        if (!A.deterministic) {                                     // _haps.py:723-730
+            // length delta of this haplotype inside the (jittered) window: genotypes/mod.rs:48-85
+            DiffArgs D = A.D;
+            D.geno_offset_idx = A.goi; D.ploidy = A.ploidy;
+            D.q_starts = A.regions + 1; D.q_ends = A.regions + 2; D.q_stride = 4;
+            const i64 diff = (i64)(int)row_diff(D, k);
+            const i64 max_shift = (diff > 0 ? diff : 0) + ((i64)len - A.output_length > 0 ? (i64)len - A.output_length : 0);
+            const u64 h = hash4_dev(A.seed, A.counter, (u64)k, 0x7368696674ull);
+            shift = (int)(h % (u64)(max_shift + 1));
+        }
+        A.shifts[k] = shift;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // host side of the C-ABI
 // ---------------------------------------------------------------------------
@@ -2097,6 +2145,37 @@ int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *t
     const i64 grid = (A.n_rows + 3) / 4;
     realign_tracks_kernel<<<dim3((unsigned)grid, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream>>>(A);
     return check_launch("gvl_realign_tracks");
+}
+
+
+int gvl_prepare_request(const gvl_static *st, const int64_t *idx, int64_t batch,
+                        const int32_t *full_regions, int64_t n_regions, int64_t n_samples,
+                        int64_t ploidy, int64_t jitter, int32_t rc_neg, int32_t deterministic,
+                        int64_t output_length, uint64_t seed, uint64_t counter,
+                        int32_t *regions_out, int64_t *geno_offset_idx_out, uint8_t *to_rc_out,
+                        int32_t *shifts_out, void *stream) {
+    if (batch < 0 || n_regions <= 0 || n_samples <= 0 || ploidy <= 0 || ploidy > 64 || jitter < 0 || jitter > (1 << 20))
+        return fail(GVL_ERR_INVALID, "%s", "gvl_prepare_request: bad sizes");
+    if (batch == 0) return GVL_OK;
+    if (!idx || !full_regions || !regions_out || !geno_offset_idx_out || !to_rc_out || !shifts_out)
+        return fail(GVL_ERR_INVALID, "%s", "gvl_prepare_request: NULL array");
+    PrepArgs P;
+    memset(&P, 0, sizeof(P));
+    if (!deterministic) {
+        if (!st || !st->geno_o_starts || !st->geno_o_stops || (st->n_geno > 0 && (!st->geno_v_idxs || !st->ilens || !st->v_starts)))
+            return fail(GVL_ERR_INVALID, "%s", "gvl_prepare_request: random shifts need the genotype CSR + variant table");
+        P.D.geno_v_idxs = st->geno_v_idxs; P.D.go_starts = (const i64 *)st->geno_o_starts;
+        P.D.go_stops = (const i64 *)st->geno_o_stops; P.D.ilens = st->ilens; P.D.v_starts = st->v_starts;
+        P.D.n_variants = st->n_variants; P.D.n_rows = batch * ploidy;
+    }
+    P.idx = (const i64 *)idx; P.batch = batch; P.full_regions = full_regions; P.n_regions = n_regions;
+    P.n_samples = n_samples; P.ploidy = (int)ploidy; P.jitter = (int)jitter; P.rc_neg = rc_neg;
+    P.deterministic = deterministic; P.output_length = output_length; P.seed = seed; P.counter = counter;
+    P.regions = regions_out; P.goi = (i64 *)geno_offset_idx_out; P.to_rc = to_rc_out; P.shifts = shifts_out;
+    const i64 grid = (batch + 255) / 256;
+    if (grid > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_prepare_request: batch too large");
+    prepare_request_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(P);
+    return check_launch("gvl_prepare_request");
 }
 
 }  // extern "C"

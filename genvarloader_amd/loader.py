@@ -11,9 +11,10 @@ is fused, nothing returns to the host, and ``DeviceLoader`` keeps several batche
 separate HIP streams (the role of the reference's ``buffered`` / ``double_buffered`` modes,
 ``_torch.py:94-211``, without shared memory or a producer process).
 
-Randomness: jitter and shifts use a ``torch.Generator`` on the device; the *distribution* is
-the reference's (``rng.integers(-j, j + 1)``, ``rng.integers(0, max_shift + 1)``), the stream
-of numbers is not (numpy's PCG64 is not reproducible on a GPU).  ``deterministic=True``
+Randomness: jitter and shifts are drawn inside ``gvl_prepare_request`` from a counter-based
+hash keyed by (seed, batch counter, row); the *distribution* is the reference's
+(``rng.integers(-j, j + 1)``, ``rng.integers(0, max_shift + 1)``), the stream of numbers is
+not (numpy's PCG64 is not reproducible on a GPU).  ``deterministic=True`` with ``jitter=0``
 involves no randomness and is bit-exact.
 """
 
@@ -84,8 +85,8 @@ class DeviceHapsDataset:
             raise ValueError("output_length must be >= 1 (fixed-length output)")
         self.jitter, self.rc_neg, self.deterministic = int(jitter), bool(rc_neg), bool(deterministic)
         self.onehot, self.haps, self.layout = bool(onehot), bool(haps), layout
-        self.generator = torch.Generator(device=d)
-        self.generator.manual_seed(0 if seed is None else int(seed))
+        self.seed = (0 if seed is None else int(seed)) & 0xFFFFFFFFFFFFFFFF
+        self._counter = 0
 
     @property
     def shape(self):
@@ -95,32 +96,88 @@ class DeviceHapsDataset:
         return self.n_regions * self.n_samples
 
     def request(self, idx):
-        """Device-side ``_prepare_request``: everything the kernel needs, no host round trip."""
+        """Device-side ``_prepare_request`` (one launch of ``gvl_prepare_request``): everything
+        the kernel needs, no host round trip.  :func:`build_request` states the same index
+        math with torch ops (tests compare the two)."""
+        import ctypes as C
+
+        from . import _lib
+        from .device import _ptr, _stream_ptr
+
         d = self.dev.device
-        idx = torch.as_tensor(np.asarray(idx) if not isinstance(idx, torch.Tensor) else idx).to(d).reshape(-1)
-        regions, goi, to_rc, lengths = build_request(idx, self.full_regions, self.n_samples, self.ploidy,
-                                                     self.jitter, self.rc_neg, self.generator)
-        if self.deterministic:                                         # _haps.py:720-722
-            shifts = torch.zeros(goi.shape, dtype=torch.int32, device=d)
-        else:                                                          # _haps.py:723-730
-            diffs = self.dev.get_diffs_sparse(goi, q_starts=regions[:, 1].contiguous(),
-                                              q_ends=regions[:, 2].contiguous())
-            max_shift = diffs.clamp(min=0).to(torch.int64) + (lengths - self.output_length).clamp(min=0)[:, None]
-            u = torch.rand(goi.shape, device=d, generator=self.generator, dtype=torch.float64)
-            shifts = torch.minimum((u * (max_shift + 1).to(torch.float64)).floor().to(torch.int64), max_shift)
-            shifts = shifts.to(torch.int32)
-        return idx, regions, shifts.contiguous(), goi, to_rc
+        idx = torch.as_tensor(np.asarray(idx) if not isinstance(idx, torch.Tensor) else idx)
+        idx = idx.to(device=d, dtype=torch.int64).reshape(-1).contiguous()
+        b, P = int(idx.numel()), self.ploidy
+        regions = torch.empty((b, 4), dtype=torch.int32, device=d)
+        goi = torch.empty((b, P), dtype=torch.int64, device=d)
+        to_rc = torch.empty(b * P, dtype=torch.uint8, device=d)
+        shifts = torch.empty((b, P), dtype=torch.int32, device=d)
+        self._counter += 1
+        with torch.cuda.device(d):
+            _lib.check(self.dev.lib.gvl_prepare_request(
+                C.byref(self.dev.c), _ptr(idx), C.c_int64(b), _ptr(self.full_regions), C.c_int64(self.n_regions),
+                C.c_int64(self.n_samples), C.c_int64(P), C.c_int64(self.jitter), C.c_int32(int(self.rc_neg)),
+                C.c_int32(int(self.deterministic)), C.c_int64(self.output_length), C.c_uint64(self.seed),
+                C.c_uint64(self._counter), _ptr(regions), _ptr(goi), _ptr(to_rc), _ptr(shifts), _stream_ptr()))
+        return idx, regions, shifts, goi, (to_rc if self.rc_neg else None)
 
     def __getitem__(self, idx) -> Batch:
-        idx, regions, shifts, goi, to_rc = self.request(idx)
-        out = self.dev.reconstruct(regions, shifts, goi, self.output_length, to_rc=to_rc, haps=self.haps,
-                                   onehot=self.onehot, layout=self.layout)
-        b, P, L = goi.shape[0], self.ploidy, self.output_length
-        oh = None
-        if out.onehot is not None:
-            oh = out.onehot.view(b, P, L, 4) if self.layout == "lc" else out.onehot.view(b, P, 4, L)
-        hp = out.haps.view(b, P, L) if out.haps is not None else None
-        return Batch(oh, hp, idx, regions, shifts, goi, to_rc)
+        """Two launches (request prep, reconstruct) on the current stream, one allocation: every
+        per-batch array is carved out of a single arena so that the host does one allocator
+        call per batch."""
+        import ctypes as C
+
+        from . import _lib
+        from ._lib import GvlBatch, GvlOut
+
+        d = self.dev.device
+        idx = torch.as_tensor(np.asarray(idx) if not isinstance(idx, torch.Tensor) else idx)
+        idx = idx.to(device=d, dtype=torch.int64).reshape(-1).contiguous()
+        b, P, L = int(idx.numel()), self.ploidy, self.output_length
+        K = b * P
+
+        def up(x):
+            return (x + 255) & ~255
+
+        sizes = [4 * K * L if self.onehot else 0, K * L if self.haps else 0, 16 * b, 8 * K, 4 * K, K, 8 * (K + 1)]
+        offs = [0]
+        for sz in sizes:
+            offs.append(offs[-1] + up(sz))
+        arena = torch.empty(offs[-1], dtype=torch.uint8, device=d)
+        base = arena.data_ptr()
+        p_oh, p_hp, p_reg, p_goi, p_sh, p_rc, p_oo = (base + o for o in offs[:-1])
+        self._counter += 1
+        lib = self.dev.lib
+        stream = C.c_void_p(torch.cuda.current_stream(d).cuda_stream)
+        with torch.cuda.device(d):
+            _lib.check(lib.gvl_prepare_request(
+                C.byref(self.dev.c), C.c_void_p(idx.data_ptr()), C.c_int64(b), C.c_void_p(self.full_regions.data_ptr()),
+                C.c_int64(self.n_regions), C.c_int64(self.n_samples), C.c_int64(P), C.c_int64(self.jitter),
+                C.c_int32(int(self.rc_neg)), C.c_int32(int(self.deterministic)), C.c_int64(L), C.c_uint64(self.seed),
+                C.c_uint64(self._counter), C.c_void_p(p_reg), C.c_void_p(p_goi), C.c_void_p(p_rc), C.c_void_p(p_sh),
+                stream))
+            bt = GvlBatch(regions=p_reg, regions_stride=4, shifts=p_sh, geno_offset_idx=p_goi, batch=b, ploidy=P,
+                          keep=None, keep_offsets=None, to_rc=p_rc if self.rc_neg else None, output_length=L,
+                          out_offsets=None, max_row_len=L)
+            oc = GvlOut(haps=p_hp if self.haps else None, onehot=p_oh if self.onehot else None,
+                        onehot_layout=_lib.GVL_ONEHOT_LC if self.layout == "lc" else _lib.GVL_ONEHOT_CL,
+                        annot_v_idxs=None, annot_ref_pos=None, out_offsets=p_oo)
+            if b:
+                _lib.check(lib.gvl_reconstruct(C.byref(self.dev.c), C.byref(bt), C.byref(oc), stream))
+
+        def view(i, dtype, shape):
+            n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+            return arena[offs[i]:offs[i] + n].view(dtype).view(shape)
+
+        oh = hp = None
+        if self.onehot:
+            oh = view(0, torch.uint8, (b, P, L, 4) if self.layout == "lc" else (b, P, 4, L))
+        if self.haps:
+            hp = view(1, torch.uint8, (b, P, L))
+        batch = Batch(oh, hp, idx, view(2, torch.int32, (b, 4)), view(4, torch.int32, (b, P)),
+                      view(3, torch.int64, (b, P)), view(5, torch.uint8, (K,)) if self.rc_neg else None)
+        batch._arena = arena
+        return batch
 
     def to_dataloader(self, batch_size: int = 1, shuffle: bool = False, sampler=None, drop_last: bool = False,
                       generator: torch.Generator | None = None, in_flight: int = 3) -> "DeviceLoader":
@@ -144,11 +201,13 @@ class DeviceLoader:
             for b in self.sampler:                      # a BatchSampler-like iterable of index lists
                 yield np.asarray(b, dtype=np.int64).reshape(-1)
             return
+        # the epoch's order goes to the device ONCE; batches are views of it (no per-batch H2D)
         n = len(self.ds)
-        order = torch.randperm(n, generator=self.generator).numpy() if self.shuffle else np.arange(n)
+        order = torch.randperm(n, generator=self.generator) if self.shuffle else torch.arange(n)
+        order = order.to(self.ds.dev.device)
         for s in range(0, n, self.batch_size):
             b = order[s:s + self.batch_size]
-            if len(b) < self.batch_size and self.drop_last:
+            if b.numel() < self.batch_size and self.drop_last:
                 return
             yield b
 
@@ -184,8 +243,6 @@ class DeviceLoader:
             batch, ev = pending.popleft()
             cur = torch.cuda.current_stream(self.ds.dev.device)
             cur.wait_event(ev)
-            for t in (batch.onehot, batch.haps):
-                if t is not None:
-                    t.record_stream(cur)
+            batch._arena.record_stream(cur)
             submit()
             yield batch

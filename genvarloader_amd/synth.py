@@ -137,6 +137,60 @@ def make_static(
     return SynthStatic(ref, ref_offsets, v_starts, ilens, alt_alleles, alt_offsets, v_contig, af)
 
 
+def sample_genotypes(rng, st: SynthStatic, contig, start, end, ploidy: int, lookback: int = 40):
+    """Sparse genotypes for len(start) queries x ploidy haplotypes: each haplotype carries each
+    variant with pos in [start - lookback, end) on its contig with that variant's AF.
+    -> (geno_offsets (2, n) i64 starts/stops, geno_v_idxs i32), rows in (query, hap) order."""
+    contig = np.asarray(contig, np.int64)
+    start = np.asarray(start, np.int64)
+    end = np.asarray(end, np.int64)
+    B, P = len(start), int(ploidy)
+    n_contigs = len(st.ref_offsets) - 1
+    c_first = np.searchsorted(st.v_contig, np.arange(n_contigs), "left")
+    c_last = np.searchsorted(st.v_contig, np.arange(n_contigs), "right")
+    lo = np.zeros(B, np.int64)
+    hi_ = np.zeros(B, np.int64)
+    for c in range(n_contigs):
+        m = contig == c
+        if not m.any():
+            continue
+        vs = st.v_starts[c_first[c] : c_last[c]]
+        lo[m] = c_first[c] + np.searchsorted(vs, start[m] - lookback, "left")
+        hi_[m] = c_first[c] + np.searchsorted(vs, end[m], "left")
+    n_cand = np.repeat(hi_ - lo, P)  # per row k
+    row_lo = np.repeat(lo, P)
+    K = B * P
+    cand_off = np.zeros(K + 1, np.int64)
+    cand_off[1:] = np.cumsum(n_cand)
+    tot = int(cand_off[-1])
+    row_of = np.repeat(np.arange(K), n_cand)
+    v_of = row_lo[row_of] + (np.arange(tot) - cand_off[row_of])
+    carried = rng.random(tot) < st.af[v_of]
+    geno_v_idxs = v_of[carried].astype(np.int32)
+    counts = np.bincount(row_of[carried], minlength=K).astype(np.int64)
+    offs = np.zeros(K + 1, np.int64)
+    offs[1:] = np.cumsum(counts)
+    return np.ascontiguousarray(np.stack([offs[:-1], offs[1:]])), geno_v_idxs
+
+
+def make_grid(rng, st: SynthStatic, n_regions: int, n_samples: int, ploidy: int = 2, length: int = 2048,
+              slack: int = 32, rc_frac: float = 0.5):
+    """A (regions x samples x ploidy) dataset laid out like the reference's sparse genotypes
+    (slot = ravel_multi_index((r, s, p), (R, S, P)), _haps.py:757-768): BASELINE config 5 is
+    200 regions x 2504 samples x 2.  -> (full_regions (R, 4) i32, geno_offsets, geno_v_idxs)."""
+    R, S = int(n_regions), int(n_samples)
+    n_contigs = len(st.ref_offsets) - 1
+    clens = np.diff(st.ref_offsets)
+    contig = rng.integers(0, n_contigs, R).astype(np.int64)
+    span = length + 2 * slack
+    start = (rng.random(R) * np.maximum(clens[contig] - span, 1)).astype(np.int64)
+    end = start + span
+    strand = np.where(rng.random(R) < rc_frac, -1, 1)
+    full_regions = np.stack([contig, start, end, strand], axis=1).astype(np.int32)
+    go, gv = sample_genotypes(rng, st, np.repeat(contig, S), np.repeat(start, S), np.repeat(end, S), ploidy)
+    return full_regions, go, gv
+
+
 def make_batch(
     rng: np.random.Generator,
     st: SynthStatic,
@@ -173,33 +227,9 @@ def make_batch(
     strand = np.where(rng.random(B) < rc_frac, -1, 1)
     regions = np.stack([contig, start, end, strand], axis=1).astype(np.int32)
 
-    # candidate variants per query: pos in [start - lookback, end) on its contig
-    # (variants are grouped by contig, sorted by position inside a contig)
-    c_first = np.searchsorted(st.v_contig, np.arange(n_contigs), "left")
-    c_last = np.searchsorted(st.v_contig, np.arange(n_contigs), "right")
-    lo = np.empty(B, np.int64)
-    hi_ = np.empty(B, np.int64)
-    for c in range(n_contigs):
-        m = contig == c
-        if not m.any():
-            continue
-        vs = st.v_starts[c_first[c] : c_last[c]]
-        lo[m] = c_first[c] + np.searchsorted(vs, start[m] - lookback, "left")
-        hi_[m] = c_first[c] + np.searchsorted(vs, end[m], "left")
-    n_cand = np.repeat(hi_ - lo, P)  # per row k
-    row_lo = np.repeat(lo, P)
+    geno_offsets, geno_v_idxs = sample_genotypes(rng, st, contig, start, end, P, lookback)
+    offs = np.concatenate([geno_offsets[0], geno_offsets[1, -1:]]) if geno_offsets.shape[1] else np.zeros(1, np.int64)
     K = B * P
-    cand_off = np.zeros(K + 1, np.int64)
-    cand_off[1:] = np.cumsum(n_cand)
-    tot = int(cand_off[-1])
-    row_of = np.repeat(np.arange(K), n_cand)
-    v_of = row_lo[row_of] + (np.arange(tot) - cand_off[row_of])
-    carried = rng.random(tot) < st.af[v_of]
-    geno_v_idxs = v_of[carried].astype(np.int32)
-    counts = np.bincount(row_of[carried], minlength=K).astype(np.int64)
-    offs = np.zeros(K + 1, np.int64)
-    offs[1:] = np.cumsum(counts)
-    geno_offsets = np.ascontiguousarray(np.stack([offs[:-1], offs[1:]]))
     geno_offset_idx = np.arange(K, dtype=np.int64).reshape(B, P)
     if permute_csr:
         # shuffle which CSR slot each row uses (geno_offset_idx is then non-trivial)

@@ -212,6 +212,27 @@ int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *t
                        const int64_t *track_offsets, const double *params, int64_t strategy_id,
                        uint64_t base_seed, float *out, void *stream);
 
+/* ---- device-side request prep -------------------------------------- */
+
+/* Turn dataset indices over the (regions x samples) grid into the per-batch arrays of a
+ * ReconstructionRequest, on the device.  Replaces, for fixed-length output:
+ *   np.unravel_index + region gather + jitter + to_rc   (_dataset/_query.py:160-175),
+ *   _get_geno_offset_idx / ravel_multi_index             (_dataset/_haps.py:757-768),
+ *   get_diffs_sparse + random shifts                      (_dataset/_haps.py:715-730).
+ * idx i64 (batch); full_regions i32 (n_regions, 4) [contig, start, end, strand].
+ * Outputs: regions i32 (batch, 4), geno_offset_idx i64 (batch, ploidy), to_rc u8
+ * (batch*ploidy; all zero when rc_neg == 0), shifts i32 (batch, ploidy).
+ * jitter > 0: start += U{-jitter..jitter}; deterministic == 0: shift ~ U{0..max_shift} with
+ * max_shift = max(diff, 0) + max(region_len - output_length, 0).  Random draws come from the
+ * counter-based hash of src/tracks/mod.rs:31-54 keyed by (seed, counter, row): reproducible,
+ * but not numpy's stream.  From `st` only the genotype CSR + v_starts / ilens are read. */
+int gvl_prepare_request(const gvl_static *st, const int64_t *idx, int64_t batch,
+                        const int32_t *full_regions, int64_t n_regions, int64_t n_samples,
+                        int64_t ploidy, int64_t jitter, int32_t rc_neg, int32_t deterministic,
+                        int64_t output_length, uint64_t seed, uint64_t counter,
+                        int32_t *regions_out, int64_t *geno_offset_idx_out, uint8_t *to_rc_out,
+                        int32_t *shifts_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,11 @@ def test_loader_deterministic_matches_oracle(oracle):
                      pad_char=st.pad_char)
     ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, onehot=True, haps=True)
     assert len(ds) == R * S and ds.shape == (R, S)
+    # the prep kernel == the torch statement of the reference's index math
+    probe = np.random.default_rng(1).permutation(R * S)[:13]
+    _, kr, ks, kg, kc = ds.request(probe)
+    tr, tg, tc, _ = build_request(torch.from_numpy(probe).cuda(), ds.full_regions, S, P)
+    assert torch.equal(kr, tr) and torch.equal(kg, tg) and torch.equal(kc, tc) and int(ks.abs().sum()) == 0
     seen = 0
     for batch in ds.to_dataloader(batch_size=8, shuffle=False, in_flight=3):
         idx = batch.idx.cpu().numpy()
@@ -95,6 +100,9 @@ def test_loader_random_shifts_and_jitter(oracle):
     all_shifts = []
     for batch in ds.to_dataloader(batch_size=10, shuffle=True, generator=torch.Generator().manual_seed(0)):
         regions = batch.regions.cpu().numpy()
+        r_idx = batch.idx.cpu().numpy() // S
+        jit = regions[:, 1] - full_regions[r_idx, 1]
+        assert (np.abs(jit) <= 3).all() and (regions[:, 2] - regions[:, 1] == full_regions[r_idx, 2] - full_regions[r_idx, 1]).all()
         shifts = batch.shifts.cpu().numpy()
         goi = batch.geno_offset_idx.cpu().numpy()
         # the request is internally consistent: shifts in [0, max_shift] (_haps.py:728-730)

@@ -1,0 +1,31 @@
+"""BASELINE config 5 on one GPU: a 1M-window epoch (200 regions x 2504 samples x 2 haplotypes,
+2048 bp, fused one-hot) through DeviceHapsDataset.to_dataloader -- index math, request prep
+and reconstruction all on the device, 3 batches in flight.  Prints windows/s for the epoch.
+(The 8-GPU form shards the batch list across ranks; no collective.)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from genvarloader_amd import HapsDevice, synth
+from genvarloader_amd.loader import DeviceHapsDataset
+
+R, S, P, L = 200, int(os.environ.get("S", 2504)), 2, 2048
+bs = int(os.environ.get("BATCH", 2048))            # (region, sample) pairs per batch = 4096 windows
+rng = np.random.default_rng(20260802 + 5)
+st = synth.make_static(rng, (64 << 20,), indel_frac=0.15)
+t0 = time.time()
+full_regions, go, gv = synth.make_grid(rng, st, R, S, P, L)
+print(f"grid: {R}x{S}x{P} = {R*S*P} windows, CSR nnz {len(gv)} ({time.time()-t0:.1f} s to generate)")
+dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens, alt_alleles=st.alt_alleles,
+                 alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv, pad_char=st.pad_char)
+for det in (True, False):
+    ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, jitter=0 if det else 16, deterministic=det, seed=1)
+    for in_flight in (1, 3):
+        dl = ds.to_dataloader(batch_size=bs, shuffle=True, generator=torch.Generator().manual_seed(0), in_flight=in_flight)
+        chk = 0
+        for rep in range(2):                        # first pass warms up
+            torch.cuda.synchronize(); t0 = time.perf_counter(); n = 0
+            for batch in dl:
+                n += batch.onehot.shape[0] * P
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"deterministic={det} in_flight={in_flight}: {n} windows in {dt*1e3:.1f} ms -> {n/dt/1e6:.1f} M windows/s "
+              f"({dt/len(dl)*1e6:.1f} us per {bs*P}-window batch)")
