@@ -922,6 +922,11 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
                 if (tail_pad) put(q, K_PAD_TRAIL, t_end, 0, -1, -1);
             }
             nseg = n_ent + (tail_ref ? 1 : 0) + (tail_pad ? 1 : 0);
+            // sentinels: P3b counts starts <= p0 over the first 8 slots without bounds checks
+            if (lane < 8) {
+                if (lane >= nseg) pl.s_out[lane] = 0x7FFFFFFF;
+                if (lane >= npatch) pl.p_out[lane] = 0x7FFFFFFF;
+            }
         } else {
             flags |= 2;
         }
@@ -946,6 +951,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     const bool ref_zero_fill = (flags & 4) != 0;
     const int limit = hi_clip;
     int d_cls = 3, d_b1 = 0, d_b2 = 0, d_pc0 = 0, d_pcn = 0, d_idx = 0;
+    u32 d_ldlo = 0, d_ldhi = 0;     // class 0: address of the trip's first source byte
     u32 d_lo0 = 0, d_hi0 = 0, d_lo1 = 0, d_hi1 = 0, d_lo2 = 0, d_hi2 = 0;
     if (lane < CHUNK_TRIPS) {
         const int p0 = lo_clip + lane * TRIP;
@@ -959,7 +965,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
 #pragma unroll
                 for (int j = 0; j < 8; ++j) so[j] = pl.s_out[j];
 #pragma unroll
-                for (int j = 1; j < 8; ++j) idx += (j < nseg && so[j] <= p0) ? 1 : 0;
+                for (int j = 1; j < 8; ++j) idx += (so[j] <= p0) ? 1 : 0;
                 for (int s2 = 8; s2 < nseg; ++s2) idx += (pl.s_out[s2] <= p0) ? 1 : 0;
             }
             auto at = [&](int i) { return i < SEG_CAP ? i : SEG_CAP - 1; };
@@ -984,14 +990,23 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             if (cls >= 1 && cls < 3) okb = okb && in_bounds(d_lo1, d_hi1, b1, b2 < t_end ? b2 : t_end);
             if (cls == 2) okb = okb && in_bounds(d_lo2, d_hi2, b2, t_end);
             if (!okb || ((t_end - p0) & 3) != 0 || ref_zero_fill) cls = 3;
+            if (cls == 0) {
+                const u32 kind = d_hi0 >> 30;
+                if (kind == K_REF || kind == K_ALLELE) {
+                    const u64 ad = (u64)(kind == K_REF ? A.ref : A.alt_alleles) + (u64)(seg_delta(d_lo0, d_hi0) + p0);
+                    d_ldlo = (u32)ad; d_ldhi = (u32)(ad >> 32);
+                } else {
+                    cls = 3;    // a trip of pure padding: rare, the general path writes it
+                }
+            }
             {
                 int po[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) po[j] = pl.p_out[j];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    d_pc0 += (j < npatch && po[j] < p0) ? 1 : 0;
-                    d_pcn += (j < npatch && po[j] < t_end) ? 1 : 0;
+                    d_pc0 += (po[j] < p0) ? 1 : 0;
+                    d_pcn += (po[j] < t_end) ? 1 : 0;
                 }
                 for (int q = 8; q < npatch; ++q) {
                     const int pp = pl.p_out[q];
@@ -1174,14 +1189,15 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     u32 wa[3] = {0, 0, 0}, wb[3] = {0, 0, 0};
     if (mmask) { mu_a = __builtin_ctz(mmask); mmask &= mmask - 1; multi_issue(mu_a, wa); }
     if (mmask) { mu_b = __builtin_ctz(mmask); mmask &= mmask - 1; multi_issue(mu_b, wb); }
-    // pass A: class-0 trips, 4 bytes per lane from one scalar base
+    // pass A: class-0 trips, 4 bytes per lane from one scalar base (computed in P3b)
     u32 wq[CHUNK_TRIPS];
+    const int lane4 = GROUP * lane;
 #pragma unroll
     for (int u = 0; u < CHUNK_TRIPS; ++u) {
         wq[u] = 0;
         if ((umask >> u) & 1u) {
-            const int p = lo_clip + u * TRIP + GROUP * lane;
-            wq[u] = entry_load((u32)rdl((int)d_lo0, u), (u32)rdl((int)d_hi0, u), p, p < limit);
+            const u8 *src = reinterpret_cast<const u8 *>(((u64)(u32)rdl((int)d_ldhi, u) << 32) | (u32)rdl((int)d_ldlo, u));
+            if (lane4 < limit - (lo_clip + u * TRIP) && !(A.dbg & 4)) wq[u] = load_u32_unaligned(src + (u32)lane4);
         }
     }
     if (mu_a >= 0) multi_finish(mu_a, wa);
@@ -1291,25 +1307,76 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         finish_partial(p0, wv, av4, ap4);
     }
     GVL_STAMP(7);
-    // pass B: finish the class-0 trips
+    // pass B: finish the class-0 trips.  Store addresses are a scalar base per trip plus a
+    // per-lane offset that never changes: forward rows put lane l at +16*l, reverse-complemented
+    // rows mirror the index (lane l at +16*(63-l) from the trip's lowest address).
+    {
+        const int jo_base = rc ? (L - GROUP - lo_clip - GROUP * (WAVE - 1)) : lo_clip;
+        const int jo_step = rc ? -TRIP : TRIP;
+        const u32 lane_rev = rc ? (u32)(WAVE - 1 - lane) : (u32)lane;
 #pragma unroll
-    for (int u = 0; u < CHUNK_TRIPS; ++u) {
-        if ((umask >> u) & 1u) {
-            const int p0 = lo_clip + u * TRIP;
-            int av4[GROUP], ap4[GROUP];
-            if (ANNOT) {
-                const u32 lo = (u32)rdl((int)d_lo0, u), hi = (u32)rdl((int)d_hi0, u);
-                const u32 kind = hi >> 30;
-                const int se = rdl(d_idx, u);
-                const int p = p0 + GROUP * lane;
+        for (int u = 0; u < CHUNK_TRIPS; ++u) {
+            if ((umask >> u) & 1u) {
+                const int p0 = lo_clip + u * TRIP;
+                const int pc0 = rdl(d_pc0, u), pcn = rdl(d_pcn, u);
+                u32 wv = wq[u];
+                int av4[GROUP], ap4[GROUP];
+                if (ANNOT) {
+                    const u32 lo = (u32)rdl((int)d_lo0, u), hi = (u32)rdl((int)d_hi0, u);
+                    const u32 kind = hi >> 30;
+                    const int se = rdl(d_idx, u);
 #pragma unroll
-                for (int i = 0; i < GROUP; ++i) {
-                    if (kind == K_REF) { av4[i] = -1; ap4[i] = (int)(seg_delta(lo, hi) + p + i - c_s); }
-                    else if (kind == K_ALLELE) { av4[i] = pl.s_a[se]; ap4[i] = pl.s_b[se]; }
-                    else { av4[i] = -1; ap4[i] = kind == K_PAD_LEAD ? -1 : 2147483647; }
+                    for (int i = 0; i < GROUP; ++i) {
+                        if (kind == K_REF) { av4[i] = -1; ap4[i] = (int)(seg_delta(lo, hi) + p0 + lane4 + i - c_s); }
+                        else { av4[i] = pl.s_a[se]; ap4[i] = pl.s_b[se]; }
+                    }
+                }
+                for (int q = pc0; q < pcn; ++q) {
+                    const u32 dd = (u32)(pl.p_out[q] - p0 - lane4);
+                    if (dd < (u32)GROUP) {
+                        const u32 sh = dd * 8;
+                        wv = (wv & ~(0xFFu << sh)) | ((u32)pl.p_val[q] << sh);
+                    }
+                    if (ANNOT) {
+                        const int pid = pl.p_id[q];
+#pragma unroll
+                        for (int i = 0; i < GROUP; ++i) if (dd == (u32)i) av4[i] = pid;
+                    }
+                }
+                if (lane4 < limit - p0 && !(A.dbg & 2)) {
+                    const i64 jo0 = (i64)(jo_base + u * jo_step);       // scalar
+                    const u32 ww = __builtin_amdgcn_perm(0u, wv, rc_sel);
+                    const u32 b0_ = ww & 0xFF, b1_ = (ww >> 8) & 0xFF, b2_ = (ww >> 16) & 0xFF, b3_ = ww >> 24;
+                    if (OH == OH_LC) {
+                        u32x4_a4 o = {oh_t[b0_], oh_t[b1_], oh_t[b2_], oh_t[b3_]};
+                        *reinterpret_cast<u32x4_a4 *>(oh_row + 4 * jo0 + 16u * lane_rev) = o;
+                    } else if (OH == OH_CL) {
+                        const u32 d0 = oh_t[b0_], d1 = oh_t[b1_], d2 = oh_t[b2_], d3 = oh_t[b3_];
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            const u32 sh = 8 * a;
+                            const u32 v = ((d0 >> sh) & 0xFF) | (((d1 >> sh) & 0xFF) << 8) |
+                                          (((d2 >> sh) & 0xFF) << 16) | (((d3 >> sh) & 0xFF) << 24);
+                            __builtin_memcpy(oh_row + (i64)a * L + jo0 + 4u * lane_rev, &v, 4);
+                        }
+                    }
+                    if (HAPS) {
+                        u32 hv = ww;
+                        if (rc) hv = luts.comp[b0_] | (luts.comp[b1_] << 8) | (luts.comp[b2_] << 16) | (luts.comp[b3_] << 24);
+                        __builtin_memcpy(hap_row + jo0 + 4u * lane_rev, &hv, 4);
+                    }
+                    if (ANNOT) {
+                        if (av_row) {
+                            i32x4_a4 o = rc ? i32x4_a4{av4[3], av4[2], av4[1], av4[0]} : i32x4_a4{av4[0], av4[1], av4[2], av4[3]};
+                            *reinterpret_cast<i32x4_a4 *>(av_row + jo0 + 4u * lane_rev) = o;
+                        }
+                        if (ap_row) {
+                            i32x4_a4 o = rc ? i32x4_a4{ap4[3], ap4[2], ap4[1], ap4[0]} : i32x4_a4{ap4[0], ap4[1], ap4[2], ap4[3]};
+                            *reinterpret_cast<i32x4_a4 *>(ap_row + jo0 + 4u * lane_rev) = o;
+                        }
+                    }
                 }
             }
-            finish(p0, rdl(d_pc0, u), rdl(d_pcn, u), wq[u], av4, ap4);
         }
     }
     __builtin_amdgcn_s_waitcnt(0);
