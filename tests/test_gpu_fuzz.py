@@ -1,0 +1,37 @@
+"""Short randomised sweeps (tools/fuzz.py, tools/fuzz_tracks.py): random contigs, variant
+densities, indel sizes, ploidy 1-3, lengths 1-5000, ragged / fixed, shifts far beyond
+max_shift, keep masks, regions stride 3 / 4, annotations, both one-hot layouts, all five
+insertion-fill strategies, overlapping intervals -- HIP vs oracle, bit-exact.  Once on the
+planned (scan) path and once with every row forced through the scalar path."""
+
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = Path(__file__).resolve().parent.parent
+
+
+def _run(script, n, seed, dbg=None):
+    env = dict(os.environ)
+    if dbg is not None:
+        env["GVL_DBG"] = str(dbg)
+    r = subprocess.run([sys.executable, str(REPO / "tools" / script), str(n), str(seed)], capture_output=True,
+                       text=True, env=env, cwd=REPO, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 mismatches" in r.stdout
+
+
+def test_fuzz_haplotypes_planned_path():
+    _run("fuzz.py", 600, 101)
+
+
+def test_fuzz_haplotypes_scalar_path():
+    _run("fuzz.py", 300, 102, dbg=8)
+
+
+def test_fuzz_tracks():
+    _run("fuzz_tracks.py", 300, 103)
