@@ -105,12 +105,19 @@ def main() -> None:
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    torch.cuda.set_device(local_rank)
+    # GVL_BENCH_DEVICE / GVL_BENCH_BACKEND exist only so that the N > 1 code path can be smoke
+    # tested on a 1-GPU box (several ranks sharing GPU 0 over gloo); the driver never sets them.
+    dev_index = int(os.environ.get("GVL_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("GVL_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     from genvarloader_amd import HapsDevice, synth
 
@@ -120,7 +127,7 @@ def main() -> None:
     K, L = bt.n_windows, bt.output_length
     dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
                      alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=bt.geno_offsets,
-                     geno_v_idxs=bt.geno_v_idxs, pad_char=st.pad_char, device=f"cuda:{local_rank}")
+                     geno_v_idxs=bt.geno_v_idxs, pad_char=st.pad_char, device=f"cuda:{dev_index}")
     dbt = dev.prepare_batch(bt.regions, bt.shifts, bt.geno_offset_idx, L, to_rc=bt.to_rc)
     slots = [dev.alloc_output(dbt, K * L, haps=args.haps, onehot=True) for _ in range(max(1, args.slots))]
     stream = torch.cuda.current_stream()
@@ -173,7 +180,7 @@ def main() -> None:
     torch.cuda.synchronize()
     kern_ms = ev0.elapsed_time(ev1) / args.steps
     if dist is not None:
-        tt = torch.tensor([wall, kern_ms], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([wall, kern_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, kern_ms = float(tt[0]), float(tt[1])
 
