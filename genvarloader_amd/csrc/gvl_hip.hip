@@ -1585,10 +1585,12 @@ __global__ __launch_bounds__(256) void onehot_kernel(const u8 *in, i64 n, u8 *ou
 
 // ---------------------------------------------------------------------------------
 // Tracks (BASELINE config 4): interval painting and realignment of
-// reference-coordinate f32 tracks to a haplotype.  First correct version: one wave per
-// (row, chunk) replays the reference's walk on the scalar unit into a lane-resident
-// segment table (same flush/compaction scheme as recon_wave_scalar) and streams 4 values
-// per lane per trip; values inside a plain track run are one 16-B load + one 16-B store.
+// reference-coordinate f32 tracks to a haplotype.  One wave per (row, chunk): the walk is
+// planned with wave scans (lane j = variant j) into a 64-entry LDS table of the chunk's
+// entries, then the wave streams 4 values per lane per trip; values inside a plain track run
+// are one 16-B load + one 16-B store.  Rows the planner cannot express (coordinates beyond
+// 2^30, > 64 entries per chunk) replay the reference's walk on the scalar unit with the same
+// flush/compaction scheme as recon_wave_scalar.
 // ---------------------------------------------------------------------------------
 struct TrackArgs {
     const i64 *go_starts; const i64 *go_stops; const int *geno_v_idxs; const int *v_starts;
@@ -1599,6 +1601,7 @@ struct TrackArgs {
     const float *tracks; const i64 *track_offsets;
     double param; i64 strategy; u64 base_seed;
     float *out;
+    int dbg;
 };
 enum : int { T_TRACK = 0, T_REPEAT = 1, T_FILL = 2, T_ZERO = 3 };
 struct TrackMirror { int out[SEG_CAP]; int kind[SEG_CAP]; int plo[SEG_CAP]; int phi[SEG_CAP]; int vlen[SEG_CAP]; };
@@ -1709,6 +1712,144 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A) 
         push(T_TRACK, 0, L, 0, 0);
         out_idx = L;
         walk_done = true;
+    }
+
+    // Planned walk: the same restatement as reconstruct_kernel's P3 (lane j = variant j, wave
+    // scans for "first ALT wins" and the output offsets), with the track rules: SNPs only take
+    // part in the shift (:312-314), every applied indel ends a track run, no lead pad.  It
+    // writes the chunk's entries straight into the LDS table; anything it cannot express in
+    // i32 / 64 entries leaves the table empty for the scalar walk below.
+    if (!walk_done && !(A.dbg & 8)) {
+        bool ok = q_start > -(1ll << 30) && q_start < (1ll << 30) && shift >= 0 && shift < (1ll << 30);
+        int rem = (int)(ok ? shift : 0);
+        int tidx0 = 0, pm_carry = 0, x_carry = 0;
+        bool ended = false, past_chunk = false;
+        int tidx_end = 0, out_end = 0;
+        int n_ent = 0;
+        const int qs = (int)(ok ? q_start : 0);
+        auto put = [&](int q, int kind, int o_start, i64 pval, int vlen) {
+            if (q < SEG_CAP) {
+                M.out[q] = o_start; M.kind[q] = kind; M.plo[q] = (int)(u32)(u64)pval;
+                M.phi[q] = (int)(u32)((u64)pval >> 32); M.vlen[q] = vlen;
+            }
+        };
+        for (int tb = 0; tb < n_var && ok && !ended && !past_chunk; tb += WAVE) {
+            int pos = 0, d = 0;
+            bool valid = tb + lane < n_var;
+            if (valid) {
+                int v = A.geno_v_idxs[o_s + tb + lane];
+                v = v < 0 ? 0 : ((i64)v >= A.n_variants ? (int)(A.n_variants - 1) : v);
+                pos = A.v_starts[v]; d = A.ilens[v];
+                if (has_keep) valid = A.keep[keep_off + tb + lane] != 0;
+            }
+            const bool weird = valid && (pos <= -(1 << 30) || pos >= (1 << 30) || d <= -(1 << 30) || d >= (1 << 30));
+            ok = ok && __builtin_amdgcn_ballot_w64(weird) == 0;
+            const int vrp = pos - qs;                                   // :264
+            const int E = vrp - (d < 0 ? d : 0) + 1;                    // :267
+            int v_len = (d > 0 ? d : 0) + 1;                            // :282
+            const u64 m_span = __builtin_amdgcn_ballot_w64(valid && d < 0 && vrp < 0 && E >= 0);   // :271-274
+            if (m_span) { tidx0 = rdl(E, 63 - __builtin_clzll(m_span)); pm_carry = tidx0; tidx_end = tidx0; }
+            bool cand = valid && vrp >= 0;
+            if (rem > 0) {                                              // :285-308
+                const int base = tidx0;
+                const u64 m_t = __builtin_amdgcn_ballot_w64(cand && vrp >= base && (vrp - base) + v_len >= rem);
+                if (m_t == 0) {
+                    cand = false;
+                } else {
+                    const int f = __builtin_ctzll(m_t);
+                    const int dist = rdl(vrp, f) - base;
+                    if (dist >= rem) {
+                        tidx0 = base + rem;
+                        cand = cand && lane >= f;
+                    } else {
+                        const int skip = rem - dist;
+                        if (skip == rdl(v_len, f)) {
+                            tidx0 = rdl(E, f);
+                            cand = cand && lane > f;
+                        } else {
+                            tidx0 = rdl(vrp, f);
+                            cand = cand && lane >= f;
+                            if (lane == f) v_len -= skip;
+                        }
+                    }
+                    rem = 0;
+                    pm_carry = tidx0; tidx_end = tidx0;
+                }
+            }
+            cand = cand && d != 0;                                      // :312-314
+            bool inB = cand;
+            int PM = 0, pm_incl = 0;
+            {
+                u64 mB = __builtin_amdgcn_ballot_w64(inB);
+                bool stable = false;
+#pragma unroll 1
+                for (int it = 0; it < 4 && !stable; ++it) {
+                    PM = wave_scan_exclusive<OpMaxU>(inB ? E : 0, pm_incl);
+                    PM = PM > pm_carry ? PM : pm_carry;
+                    inB = cand && vrp >= PM;                            // :277-279
+                    const u64 m2 = __builtin_amdgcn_ballot_w64(inB);
+                    stable = m2 == mB;
+                    mB = m2;
+                }
+                ok = ok && stable;
+            }
+            const int n_i = inB ? vrp - PM : 0;                         // :317
+            const int S_i = inB ? OpSat::f(n_i, v_len) : 0;
+            int x_incl;
+            const int X = OpSat::f(x_carry, wave_scan_exclusive<OpSat>(S_i, x_incl));   // out_idx before this variant
+            const int fill_out = OpSat::f(X, n_i);
+            const bool applied = inB && fill_out < L;                   // :319-321 break
+            const int w_i = applied ? ((v_len < L - fill_out) ? v_len : L - fill_out) : 0;   // :329
+            const u64 m_inB = __builtin_amdgcn_ballot_w64(inB);
+            const u64 m_app = __builtin_amdgcn_ballot_w64(applied);
+            if (m_inB != m_app) ended = true;
+            if (m_app) {
+                const int last = 63 - __builtin_clzll(m_app);
+                tidx_end = rdl(E, last);
+                out_end = rdl(fill_out, last) + rdl(w_i, last);
+                if (rdl(fill_out, last) >= hi_clip) past_chunk = true;
+            }
+            const bool e_trk = applied && n_i > 0 && fill_out > lo_clip && X < hi_clip;
+            const bool e_fil = applied && w_i > 0 && fill_out + w_i > lo_clip && fill_out < hi_clip;
+            const int slot0 = n_ent + wave_scan_exclusive<OpAdd>((e_trk ? 1 : 0) + (e_fil ? 1 : 0));
+            const int add_ent = __builtin_popcountll(__builtin_amdgcn_ballot_w64(e_trk)) +
+                                __builtin_popcountll(__builtin_amdgcn_ballot_w64(e_fil));
+            if (n_ent + add_ent + 2 > SEG_CAP) ok = false;
+            if (ok) {
+                int q = slot0;
+                if (e_trk) { put(q, T_TRACK, X, (i64)PM - X, 0); ++q; }
+                if (e_fil) put(q, (d > 0 && A.strategy != GVL_FILL_REPEAT_5P) ? T_FILL : T_REPEAT, fill_out, (i64)vrp, v_len);
+            }
+            if (tb + WAVE < n_var) {
+                const int mx = rdl(pm_incl, 63);
+                pm_carry = mx > pm_carry ? mx : pm_carry;
+                x_carry = OpSat::f(x_carry, rdl(x_incl, 63));
+            }
+            n_ent += add_ent;
+        }
+        if (ok) {
+            if (!(past_chunk && !ended)) {                              // :365-392 tail
+                i64 t_idx = tidx_end;
+                if (rem > 0) t_idx = imin((i64)tidx0 + rem, tlen);
+                const int u = L - out_end;
+                if (u > 0 && lane == 0) {
+                    const i64 avail = tlen - t_idx;
+                    const int w = (int)imin((i64)u, avail);
+                    int end = out_end;
+                    int q = n_ent;
+                    if (w > 0) {
+                        end += w;
+                        if (end > lo_clip && out_end < hi_clip) { put(q, T_TRACK, out_end, t_idx - out_end, 0); ++q; }
+                    }
+                    if (end < L && L > lo_clip && end < hi_clip) { put(q, T_ZERO, end, 0, 0); ++q; }
+                    n_ent = q;
+                }
+                n_ent = rfl(n_ent);
+            }
+            nseg = n_ent;
+            out_idx = L;
+            walk_done = true;
+        }
     }
 
     for (;;) {
@@ -2208,6 +2349,7 @@ int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *t
     A.tracks = tracks; A.track_offsets = (const i64 *)track_offsets;
     A.param = params[0]; A.strategy = strategy_id; A.base_seed = base_seed;
     A.out = out;
+    A.dbg = debug_flags();
     if (A.n_rows > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: batch too large");
     const i64 grid = (A.n_rows + 3) / 4;
     realign_tracks_kernel<<<dim3((unsigned)grid, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream>>>(A);

@@ -33,5 +33,9 @@ def test_fuzz_haplotypes_scalar_path():
     _run("fuzz.py", 300, 102, dbg=8)
 
 
-def test_fuzz_tracks():
-    _run("fuzz_tracks.py", 300, 103)
+def test_fuzz_tracks_planned_walk():
+    _run("fuzz_tracks.py", 400, 103)
+
+
+def test_fuzz_tracks_scalar_walk():
+    _run("fuzz_tracks.py", 200, 104, dbg=8)
