@@ -31,6 +31,11 @@ SYMBOLS = (
     "gvl_intervals_to_tracks",
     "gvl_realign_tracks",
     "gvl_prepare_request",
+    "gvl_loader_slot_bytes",
+    "gvl_loader_create",
+    "gvl_loader_start_epoch",
+    "gvl_loader_next",
+    "gvl_loader_destroy",
 )
 
 GVL_ONEHOT_LC = 0
@@ -62,6 +67,23 @@ class GvlOut(C.Structure):
     _fields_ = [
         ("haps", _vp), ("onehot", _vp), ("onehot_layout", C.c_int32),
         ("annot_v_idxs", _vp), ("annot_ref_pos", _vp), ("out_offsets", _vp),
+    ]
+
+
+class GvlLoaderConfig(C.Structure):
+    _fields_ = [
+        ("full_regions", _vp), ("n_regions", _i64), ("n_samples", _i64), ("ploidy", _i64),
+        ("batch_size", _i64), ("output_length", _i64), ("jitter", _i64),
+        ("rc_neg", C.c_int32), ("deterministic", C.c_int32), ("seed", C.c_uint64),
+        ("want_haps", C.c_int32), ("want_onehot", C.c_int32), ("onehot_layout", C.c_int32),
+        ("in_flight", C.c_int32), ("n_slots", C.c_int32), ("slot_arenas", C.POINTER(_vp)),
+    ]
+
+
+class GvlLoaderBatch(C.Structure):
+    _fields_ = [
+        ("slot", C.c_int32), ("batch", _i64), ("idx", _vp), ("onehot", _vp), ("haps", _vp),
+        ("regions", _vp), ("geno_offset_idx", _vp), ("shifts", _vp), ("to_rc", _vp), ("out_offsets", _vp),
     ]
 
 
@@ -104,8 +126,9 @@ def load() -> C.CDLL:
         fn = getattr(lib, name, None)
         if fn is None:
             raise GvlError(f"{p} does not export {name}")
-        if name not in ("gvl_last_error",):
+        if name not in ("gvl_last_error", "gvl_loader_slot_bytes"):
             fn.restype = C.c_int
+    lib.gvl_loader_slot_bytes.restype = C.c_int64
     _LIB = lib
     return lib
 

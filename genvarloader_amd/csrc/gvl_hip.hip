@@ -34,6 +34,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <new>
 
 #include "gvl_hip.h"
 
@@ -2116,6 +2118,17 @@ int log2_exact(i64 v) {
     return -1;
 }
 
+// GVL_TRACE=1: report any HIP call of the loop that holds the host for more than 1 ms.
+bool trace_on() { static const bool on = [] { const char *e = getenv("GVL_TRACE"); return e && atoi(e) != 0; }(); return on; }
+double now_ms() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+template <typename F> hipError_t traced(const char *tag, F f) {
+    if (!trace_on()) return f();
+    const double t0 = now_ms();
+    const hipError_t e = f();
+    const double dt = now_ms() - t0;
+    if (dt > 1.0) fprintf(stderr, "[gvl trace] %s held the host for %.1f ms\n", tag, dt);
+    return e;
+}
 }  // namespace
 
 extern "C" {
@@ -2385,6 +2398,166 @@ int gvl_prepare_request(const gvl_static *st, const int64_t *idx, int64_t batch,
     if (grid > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_prepare_request: batch too large");
     prepare_request_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(P);
     return check_launch("gvl_prepare_request");
+}
+
+// ---- native batch loop ---------------------------------------------------------------
+struct gvl_loader {
+    gvl_static st;
+    gvl_loader_config cfg;
+    void *arenas[64];
+    int64_t part[7];
+    hipStream_t streams[16];
+    hipEvent_t done[64], released[64], epoch_ready;
+    bool slot_used[64];
+    bool stream_synced[16];
+    const int64_t *order; i64 n_order; i64 n_batches;
+    i64 submitted, consumed; int prev_slot;
+    u64 counter;
+};
+
+static i64 align256(i64 x) { return (x + 255) & ~255ll; }
+
+int64_t gvl_loader_slot_bytes(const gvl_loader_config *cfg, int64_t *part_offsets) {
+    if (!cfg || cfg->batch_size <= 0 || cfg->ploidy <= 0 || cfg->output_length <= 0) return -1;
+    const i64 b = cfg->batch_size, K = b * cfg->ploidy, L = cfg->output_length;
+    const i64 sizes[7] = {cfg->want_onehot ? 4 * K * L : 0, cfg->want_haps ? K * L : 0, 16 * b, 8 * K, 4 * K, K, 8 * (K + 1)};
+    i64 off = 0;
+    for (int i = 0; i < 7; ++i) {
+        if (part_offsets) part_offsets[i] = off;
+        off += align256(sizes[i]);
+    }
+    return off;
+}
+
+int gvl_loader_create(const gvl_static *st, const gvl_loader_config *cfg, gvl_loader **out) {
+    if (!st || !cfg || !out) return fail(GVL_ERR_INVALID, "%s", "gvl_loader_create: NULL argument");
+    if (cfg->in_flight < 1 || cfg->in_flight > 16 || cfg->n_slots < cfg->in_flight + 1 || cfg->n_slots > 64)
+        return fail(GVL_ERR_INVALID, "%s", "gvl_loader_create: need 1 <= in_flight <= 16 and in_flight < n_slots <= 64");
+    if (!cfg->full_regions || !cfg->slot_arenas || cfg->n_regions <= 0 || cfg->n_samples <= 0 || cfg->batch_size <= 0 ||
+        cfg->ploidy <= 0 || cfg->output_length <= 0 || (!cfg->want_haps && !cfg->want_onehot))
+        return fail(GVL_ERR_INVALID, "%s", "gvl_loader_create: bad config");
+    gvl_loader *ld = new (std::nothrow) gvl_loader;
+    if (!ld) return fail(GVL_ERR_HIP, "%s", "gvl_loader_create: out of host memory");
+    memset(ld, 0, sizeof(*ld));
+    ld->st = *st; ld->cfg = *cfg;
+    gvl_loader_slot_bytes(cfg, ld->part);
+    for (int i = 0; i < cfg->n_slots; ++i) {
+        ld->arenas[i] = cfg->slot_arenas[i];
+        if (!ld->arenas[i] || ((uintptr_t)ld->arenas[i] & 255)) {
+            delete ld;
+            return fail(GVL_ERR_INVALID, "%s", "gvl_loader_create: slot arenas must be non-NULL and 256-byte aligned");
+        }
+    }
+    ld->cfg.slot_arenas = nullptr;
+    bool ok = true;
+    for (int i = 0; i < cfg->in_flight && ok; ++i) ok = hipStreamCreateWithFlags(&ld->streams[i], hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < cfg->n_slots && ok; ++i)
+        ok = hipEventCreateWithFlags(&ld->done[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&ld->released[i], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ld->epoch_ready, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { gvl_loader_destroy(ld); return fail(GVL_ERR_HIP, "%s", "gvl_loader_create: stream / event creation failed"); }
+    ld->prev_slot = -1;
+    *out = ld;
+    return GVL_OK;
+}
+
+int gvl_loader_destroy(gvl_loader *ld) {
+    if (!ld) return GVL_OK;
+    for (int i = 0; i < 16; ++i) if (ld->streams[i]) { hipStreamSynchronize(ld->streams[i]); hipStreamDestroy(ld->streams[i]); }
+    for (int i = 0; i < 64; ++i) {
+        if (ld->done[i]) hipEventDestroy(ld->done[i]);
+        if (ld->released[i]) hipEventDestroy(ld->released[i]);
+    }
+    if (ld->epoch_ready) hipEventDestroy(ld->epoch_ready);
+    delete ld;
+    return GVL_OK;
+}
+
+int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int32_t drop_last, void *stream) {
+    if (!ld || n < 0 || (n > 0 && !order)) return fail(GVL_ERR_INVALID, "%s", "gvl_loader_start_epoch: bad arguments");
+    if (ld->submitted != ld->consumed)   // an abandoned epoch: let its batches drain before slots are reused
+        for (int i = 0; i < ld->cfg.in_flight; ++i) hipStreamSynchronize(ld->streams[i]);
+    const i64 bs = ld->cfg.batch_size;
+    ld->order = order; ld->n_order = n;
+    ld->n_batches = drop_last ? n / bs : (n + bs - 1) / bs;
+    ld->submitted = ld->consumed = 0;
+    if (hipEventRecord(ld->epoch_ready, (hipStream_t)stream) != hipSuccess)
+        return fail(GVL_ERR_HIP, "%s", "gvl_loader_start_epoch: hipEventRecord failed");
+    for (int i = 0; i < 16; ++i) ld->stream_synced[i] = false;
+    return GVL_OK;
+}
+
+static int loader_parts(gvl_loader *ld, int slot, i64 j, gvl_loader_batch *o) {
+    const i64 bs = ld->cfg.batch_size;
+    u8 *base = (u8 *)ld->arenas[slot];
+    o->slot = slot;
+    o->batch = (j + 1) * bs <= ld->n_order ? bs : ld->n_order - j * bs;
+    o->idx = ld->order + j * bs;
+    o->onehot = ld->cfg.want_onehot ? base + ld->part[0] : nullptr;
+    o->haps = ld->cfg.want_haps ? base + ld->part[1] : nullptr;
+    o->regions = (int *)(base + ld->part[2]);
+    o->geno_offset_idx = (int64_t *)(base + ld->part[3]);
+    o->shifts = (int *)(base + ld->part[4]);
+    o->to_rc = base + ld->part[5];
+    o->out_offsets = (int64_t *)(base + ld->part[6]);
+    return 0;
+}
+
+static int loader_submit(gvl_loader *ld, i64 j) {
+    const int slot = (int)(j % ld->cfg.n_slots);
+    const int si = (int)(j % ld->cfg.in_flight);
+    hipStream_t s = ld->streams[si];
+    if (!ld->stream_synced[si]) {
+        if (traced("wait epoch_ready", [&] { return hipStreamWaitEvent(s, ld->epoch_ready, 0); }) != hipSuccess) return fail(GVL_ERR_HIP, "%s", "gvl_loader: hipStreamWaitEvent failed");
+        ld->stream_synced[si] = true;
+    }
+    if (ld->slot_used[slot] && traced("wait released", [&] { return hipStreamWaitEvent(s, ld->released[slot], 0); }) != hipSuccess)
+        return fail(GVL_ERR_HIP, "%s", "gvl_loader: hipStreamWaitEvent failed");
+    gvl_loader_batch o;
+    loader_parts(ld, slot, j, &o);
+    const gvl_loader_config &c = ld->cfg;
+    int rc = GVL_OK;
+    traced("launch prepare_request", [&] {
+        rc = gvl_prepare_request(&ld->st, o.idx, o.batch, c.full_regions, c.n_regions, c.n_samples, c.ploidy, c.jitter,
+                                 c.rc_neg, c.deterministic, c.output_length, c.seed, ++ld->counter, o.regions,
+                                 o.geno_offset_idx, o.to_rc, o.shifts, s);
+        return hipSuccess; });
+    if (rc) return rc;
+    gvl_batch bt;
+    memset(&bt, 0, sizeof(bt));
+    bt.regions = o.regions; bt.regions_stride = 4; bt.shifts = o.shifts; bt.geno_offset_idx = o.geno_offset_idx;
+    bt.batch = o.batch; bt.ploidy = c.ploidy; bt.to_rc = c.rc_neg ? o.to_rc : nullptr;
+    bt.output_length = c.output_length; bt.max_row_len = c.output_length;
+    gvl_out oc;
+    memset(&oc, 0, sizeof(oc));
+    oc.haps = o.haps; oc.onehot = o.onehot; oc.onehot_layout = c.onehot_layout; oc.out_offsets = o.out_offsets;
+    traced("launch reconstruct", [&] { rc = gvl_reconstruct(&ld->st, &bt, &oc, s); return hipSuccess; });
+    if (rc) return rc;
+    if (traced("record done", [&] { return hipEventRecord(ld->done[slot], s); }) != hipSuccess) return fail(GVL_ERR_HIP, "%s", "gvl_loader: hipEventRecord failed");
+    ld->slot_used[slot] = true;
+    return GVL_OK;
+}
+
+int gvl_loader_next(gvl_loader *ld, void *consumer_stream, gvl_loader_batch *out) {
+    if (!ld || !out) return fail(GVL_ERR_INVALID, "%s", "gvl_loader_next: NULL argument");
+    hipStream_t cs = (hipStream_t)consumer_stream;
+    if (ld->prev_slot >= 0) {   // the consumer is done with the previous batch once its queued work has run
+        if (traced("record released", [&] { return hipEventRecord(ld->released[ld->prev_slot], cs); }) != hipSuccess) return fail(GVL_ERR_HIP, "%s", "gvl_loader_next: hipEventRecord failed");
+        ld->prev_slot = -1;
+    }
+    while (ld->submitted < ld->n_batches && ld->submitted - ld->consumed < ld->cfg.in_flight) {
+        const int rc = loader_submit(ld, ld->submitted);
+        if (rc) return rc;
+        ++ld->submitted;
+    }
+    memset(out, 0, sizeof(*out));
+    if (ld->consumed >= ld->n_batches) { out->slot = -1; return GVL_OK; }
+    const int slot = (int)(ld->consumed % ld->cfg.n_slots);
+    if (traced("wait done", [&] { return hipStreamWaitEvent(cs, ld->done[slot], 0); }) != hipSuccess) return fail(GVL_ERR_HIP, "%s", "gvl_loader_next: hipStreamWaitEvent failed");
+    loader_parts(ld, slot, ld->consumed, out);
+    ld->prev_slot = slot;
+    ++ld->consumed;
+    return GVL_OK;
 }
 
 }  // extern "C"

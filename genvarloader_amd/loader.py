@@ -187,35 +187,143 @@ class DeviceHapsDataset:
 
 class DeviceLoader:
     """Iterates batches of a :class:`DeviceHapsDataset`, ``in_flight`` batches ahead, each on
-    its own HIP stream; the consumer's current stream waits on the batch's event."""
+    its own HIP stream; the consumer's current stream waits on the batch's event.
+
+    Without a custom ``sampler`` the batch loop is native (``gvl_loader_*`` in
+    ``libgvl_hip.so``): the epoch order goes to the device once, each ``next()`` is one C call
+    that releases the previous batch, tops the pipeline up (request prep + reconstruct per
+    batch on the loader's streams) and makes the current stream wait for the next batch.  The
+    yielded tensors are views of a ring slot: **valid until the next iteration** (the
+    contract of the reference's ``double_buffered`` mode, ``_double_buffered_loader.py``).
+    With a ``sampler`` (arbitrary index lists) every batch is submitted from Python and owns
+    its memory."""
 
     def __init__(self, ds: DeviceHapsDataset, batch_size=1, shuffle=False, sampler=None, drop_last=False,
                  generator=None, in_flight=3):
         self.ds, self.batch_size, self.shuffle, self.drop_last = ds, int(batch_size), shuffle, drop_last
         self.sampler, self.generator = sampler, generator
-        self.in_flight = max(1, int(in_flight))
-        self.streams = [torch.cuda.Stream(device=ds.dev.device) for _ in range(self.in_flight)]
+        self.in_flight = max(1, min(16, int(in_flight)))
+        self._native = None
+        self.streams = None
 
+    # ---- native loop -------------------------------------------------------------------
+    def _native_setup(self):
+        import ctypes as C
+
+        from . import _lib
+        from ._lib import GvlLoaderBatch, GvlLoaderConfig
+
+        ds, d = self.ds, self.ds.dev.device
+        lib = ds.dev.lib
+        n_slots = self.in_flight + 2
+        cfg = GvlLoaderConfig(
+            full_regions=ds.full_regions.data_ptr(), n_regions=ds.n_regions, n_samples=ds.n_samples, ploidy=ds.ploidy,
+            batch_size=self.batch_size, output_length=ds.output_length, jitter=ds.jitter, rc_neg=int(ds.rc_neg),
+            deterministic=int(ds.deterministic), seed=ds.seed, want_haps=int(ds.haps), want_onehot=int(ds.onehot),
+            onehot_layout=_lib.GVL_ONEHOT_LC if ds.layout == "lc" else _lib.GVL_ONEHOT_CL, in_flight=self.in_flight,
+            n_slots=n_slots, slot_arenas=None)
+        parts = (C.c_int64 * 7)()
+        nbytes = int(lib.gvl_loader_slot_bytes(C.byref(cfg), parts))
+        if nbytes <= 0:
+            raise ValueError("bad loader configuration")
+        arenas = [torch.empty(nbytes, dtype=torch.uint8, device=d) for _ in range(n_slots)]
+        ptrs = (C.c_void_p * n_slots)(*[a.data_ptr() for a in arenas])
+        cfg.slot_arenas = C.cast(ptrs, C.POINTER(C.c_void_p))
+        handle = C.c_void_p()
+        with torch.cuda.device(d):
+            _lib.check(lib.gvl_loader_create(C.byref(ds.dev.c), C.byref(cfg), C.byref(handle)))
+        self._native = dict(handle=handle, arenas=arenas, parts=[int(x) for x in parts], cfg=cfg, ptrs=ptrs,
+                            out=GvlLoaderBatch(), views={})
+
+    def _slot_views(self, slot: int, b: int) -> Batch:
+        nat, ds = self._native, self.ds
+        key = (slot, b)
+        v = nat["views"].get(key)
+        if v is not None:
+            return v
+        arena, parts = nat["arenas"][slot], nat["parts"]
+        P, L = ds.ploidy, ds.output_length
+        K = b * P
+
+        def view(i, dtype, shape):
+            n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+            return arena[parts[i]:parts[i] + n].view(dtype).view(shape)
+
+        oh = view(0, torch.uint8, (b, P, L, 4) if ds.layout == "lc" else (b, P, 4, L)) if ds.onehot else None
+        hp = view(1, torch.uint8, (b, P, L)) if ds.haps else None
+        v = Batch(oh, hp, None, view(2, torch.int32, (b, 4)), view(4, torch.int32, (b, P)),
+                  view(3, torch.int64, (b, P)), view(5, torch.uint8, (K,)) if ds.rc_neg else None)
+        nat["views"][key] = v
+        return v
+
+    def _iter_native(self):
+        import ctypes as C
+
+        from . import _lib
+
+        if self._native is None:
+            self._native_setup()
+        nat, ds, d = self._native, self.ds, self.ds.dev.device
+        lib, handle, out = ds.dev.lib, nat["handle"], nat["out"]
+        n = len(ds)
+        with torch.cuda.device(d):
+            cur = torch.cuda.current_stream(d)
+            g = self.generator
+            if not self.shuffle:
+                order = torch.arange(n, device=d)
+            elif g is None or g.device.type == "cuda":      # shuffle on the device: no H2D of the order
+                order = torch.randperm(n, generator=g, device=d)
+            else:
+                # host generator: shuffle into a persistent pinned buffer and copy asynchronously (a
+                # pageable H2D copy leaves deferred un-pinning work that can hold a later HIP call
+                # for tens of ms on some hosts)
+                pin = nat.get("pinned")
+                if pin is None or pin.numel() != n:
+                    pin = nat["pinned"] = torch.empty(n, dtype=torch.int64).pin_memory()
+                torch.randperm(n, generator=g, out=pin)
+                order = torch.empty(n, dtype=torch.int64, device=d)
+                order.copy_(pin, non_blocking=True)
+            _lib.check(lib.gvl_loader_start_epoch(handle, C.c_void_p(order.data_ptr()), C.c_int64(n),
+                                                  C.c_int32(int(self.drop_last)), C.c_void_p(cur.cuda_stream)))
+            nat["order"] = order                       # keep the epoch order alive
+            nxt, ref_out, bs = lib.gvl_loader_next, C.byref(out), self.batch_size
+            pos = 0
+            while True:
+                rc = nxt(handle, C.c_void_p(torch.cuda.current_stream(d).cuda_stream), ref_out)
+                if rc:
+                    _lib.check(rc)
+                if out.slot < 0:
+                    return
+                b = out.batch
+                batch = self._slot_views(out.slot, b)
+                batch.idx = order[pos:pos + b]
+                pos += bs
+                yield batch
+
+    def __del__(self):
+        nat = getattr(self, "_native", None)
+        if nat is not None:
+            try:
+                self.ds.dev.lib.gvl_loader_destroy(nat["handle"])
+            except Exception:
+                pass
+            self._native = None
+
+    # ---- Python loop (custom samplers) ---------------------------------------------------
     def _index_batches(self):
-        if self.sampler is not None:
-            for b in self.sampler:                      # a BatchSampler-like iterable of index lists
-                yield np.asarray(b, dtype=np.int64).reshape(-1)
-            return
-        # the epoch's order goes to the device ONCE; batches are views of it (no per-batch H2D)
-        n = len(self.ds)
-        order = torch.randperm(n, generator=self.generator) if self.shuffle else torch.arange(n)
-        order = order.to(self.ds.dev.device)
-        for s in range(0, n, self.batch_size):
-            b = order[s:s + self.batch_size]
-            if b.numel() < self.batch_size and self.drop_last:
-                return
-            yield b
+        for b in self.sampler:                      # a BatchSampler-like iterable of index lists
+            yield np.asarray(b, dtype=np.int64).reshape(-1)
 
     def __len__(self):
         n = len(self.ds)
         return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
 
     def __iter__(self):
+        if self.sampler is None:
+            yield from self._iter_native()
+            return
+        if self.streams is None:
+            self.streams = [torch.cuda.Stream(device=self.ds.dev.device) for _ in range(self.in_flight)]
         pending: deque = deque()
         it = iter(self._index_batches())
         k = 0

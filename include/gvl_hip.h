@@ -233,6 +233,61 @@ int gvl_prepare_request(const gvl_static *st, const int64_t *idx, int64_t batch,
                         int32_t *regions_out, int64_t *geno_offset_idx_out, uint8_t *to_rc_out,
                         int32_t *shifts_out, void *stream);
 
+/* ---- native batch loop ----------------------------------------------- */
+
+/* The producer side of Dataset.to_dataloader (_dataset/_impl.py:1963-2072) for device
+ * consumers: what the reference does with a producer process + shared-memory double buffer
+ * (_torch.py:94-211, _double_buffered_loader.py) is here a ring of output slots in HBM
+ * filled `in_flight` batches ahead on the loader's own HIP streams.  Per batch the loader
+ * launches gvl_prepare_request + gvl_reconstruct; nothing returns to the host.
+ *
+ * Slot memory is the caller's (n_slots device buffers of gvl_loader_slot_bytes() each,
+ * 256-byte aligned), so a torch caller hands over torch-allocated arenas and builds views.
+ * Contract: the batch returned by gvl_loader_next stays valid until the NEXT call of
+ * gvl_loader_next (which records its release on `consumer_stream`); n_slots >= in_flight + 1. */
+typedef struct gvl_loader gvl_loader;
+
+typedef struct gvl_loader_config {
+    const int32_t *full_regions; /* device i32 (n_regions, 4) [contig, start, end, strand] */
+    int64_t n_regions, n_samples, ploidy;
+    int64_t batch_size;          /* queries per batch (rows = batch_size * ploidy) */
+    int64_t output_length;       /* fixed L >= 1 */
+    int64_t jitter;              /* see gvl_prepare_request */
+    int32_t rc_neg, deterministic;
+    uint64_t seed;
+    int32_t want_haps, want_onehot, onehot_layout;
+    int32_t in_flight;           /* batches submitted ahead, one HIP stream each: 1..16 */
+    int32_t n_slots;             /* ring slots: in_flight + 1 .. 64 */
+    void *const *slot_arenas;    /* HOST array of n_slots device pointers */
+} gvl_loader_config;
+
+typedef struct gvl_loader_batch {
+    int32_t slot;                /* ring slot, -1 = epoch finished */
+    int64_t batch;               /* queries in this batch (the last one may be short) */
+    const int64_t *idx;          /* device: this batch's dataset indices (into the epoch order) */
+    uint8_t *onehot;             /* device pointers into the slot (NULL when not requested) */
+    uint8_t *haps;
+    int32_t *regions;            /* (batch, 4) */
+    int64_t *geno_offset_idx;    /* (batch, ploidy) */
+    int32_t *shifts;             /* (batch, ploidy) */
+    uint8_t *to_rc;              /* (batch * ploidy) */
+    int64_t *out_offsets;        /* (batch * ploidy + 1) */
+} gvl_loader_batch;
+
+/* Bytes of one slot and the offsets of its parts (7 values: onehot, haps, regions,
+ * geno_offset_idx, shifts, to_rc, out_offsets), for a full batch. */
+int64_t gvl_loader_slot_bytes(const gvl_loader_config *cfg, int64_t *part_offsets);
+/* `st` is copied; the device arrays it points to must outlive the loader. */
+int gvl_loader_create(const gvl_static *st, const gvl_loader_config *cfg, gvl_loader **out);
+/* Begin an epoch over `order` (device i64[n] dataset indices, already shuffled by the caller;
+ * must stay alive until the epoch ends).  `stream` is the stream `order` was produced on. */
+int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int32_t drop_last,
+                           void *stream);
+/* Release the previously returned batch, top the pipeline up, and make `consumer_stream` wait
+ * for the next batch.  Never blocks the host.  out->slot == -1 when the epoch is over. */
+int gvl_loader_next(gvl_loader *ld, void *consumer_stream, gvl_loader_batch *out);
+int gvl_loader_destroy(gvl_loader *ld);
+
 #ifdef __cplusplus
 }
 #endif

@@ -119,3 +119,70 @@ def test_loader_random_shifts_and_jitter(oracle):
         np.testing.assert_array_equal(batch.onehot.cpu().numpy().reshape(-1, 4), exp_oh)
     s = np.concatenate(all_shifts)
     assert s.max() > 0 and len(s) == R * S * P
+
+
+@pytest.mark.gpu
+def test_native_loop_ring_reuse_drop_last_and_epochs(oracle):
+    """Many more batches than ring slots, a consumer that lags behind on its own stream, a short
+    last batch / drop_last, two epochs over the same loader: every batch must be the oracle's
+    and must not be overwritten before the consumer's queued work has read it."""
+    from genvarloader_amd import HapsDevice
+    from genvarloader_amd.loader import DeviceHapsDataset
+
+    R, S, P, L = 7, 11, 2, 300
+    st, full_regions, go, gv = _grid_dataset(9, R, S, P, L, indel_frac=0.3)
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+    ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, onehot=False, haps=True)
+    idx_all = np.arange(R * S)
+    r_idx, s_idx = np.unravel_index(idx_all, (R, S))
+    goi = np.ravel_multi_index((r_idx[:, None], s_idx[:, None], np.arange(P)), (R, S, P))
+    exp, _ = oracle.reconstruct_haplotypes_fused(
+        full_regions[r_idx], np.zeros_like(goi, dtype=np.int32), goi, go, gv, st.v_starts, st.ilens, st.alt_alleles,
+        st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, L, None, None, np.repeat(full_regions[r_idx, 3] == -1, P),
+        False)
+    exp = exp.reshape(R * S, P, L)
+    for drop_last in (False, True):
+        dl = ds.to_dataloader(batch_size=3, shuffle=True, generator=torch.Generator().manual_seed(5), drop_last=drop_last,
+                              in_flight=2)
+        assert len(dl) == (R * S) // 3 + (0 if drop_last or (R * S) % 3 == 0 else 1)
+        for epoch in range(2):
+            copies, idxs = [], []
+            lag = torch.zeros(1 << 22, device="cuda")
+            for batch in dl:
+                lag.add_(1.0)                        # the consumer is busy before it reads the batch
+                copies.append(batch.haps.clone())    # read on the consumer stream, queued behind `lag`
+                idxs.append(batch.idx.clone())
+            torch.cuda.synchronize()
+            got_idx = torch.cat(idxs).cpu().numpy()
+            n_exp = (R * S) // 3 * 3 if drop_last else R * S
+            assert len(got_idx) == n_exp and len(set(got_idx.tolist())) == n_exp
+            got = torch.cat(copies).cpu().numpy()
+            np.testing.assert_array_equal(got, exp[got_idx])
+
+
+@pytest.mark.gpu
+def test_loader_sampler_path(oracle):
+    from genvarloader_amd import HapsDevice
+    from genvarloader_amd.loader import DeviceHapsDataset
+
+    R, S, P, L = 4, 5, 2, 260
+    st, full_regions, go, gv = _grid_dataset(10, R, S, P, L)
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+    ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, onehot=True, haps=True)
+    sampler = [[0, 19, 3], [7], [5, 5, 12, 1]]
+    held = list(ds.to_dataloader(sampler=sampler, in_flight=2))      # sampler batches own their memory
+    assert [len(b.idx) for b in held] == [3, 1, 4]
+    for b, want in zip(held, sampler):
+        idx = np.asarray(want)
+        r_idx, s_idx = np.unravel_index(idx, (R, S))
+        goi = np.ravel_multi_index((r_idx[:, None], s_idx[:, None], np.arange(P)), (R, S, P))
+        exp, _, exp_oh = oracle.reconstruct_haplotypes_fused(
+            full_regions[r_idx], np.zeros_like(goi, dtype=np.int32), goi, go, gv, st.v_starts, st.ilens,
+            st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, L, None, None,
+            np.repeat(full_regions[r_idx, 3] == -1, P), False, onehot=True)
+        np.testing.assert_array_equal(b.haps.cpu().numpy().ravel(), exp)
+        np.testing.assert_array_equal(b.onehot.cpu().numpy().reshape(-1, 4), exp_oh)
