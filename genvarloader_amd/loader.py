@@ -26,6 +26,8 @@ from dataclasses import dataclass
 import numpy as np
 import torch
 
+from .sharding import epoch_order
+
 
 def build_request(idx: torch.Tensor, full_regions: torch.Tensor, n_samples: int, ploidy: int,
                   jitter: int = 0, rc_neg: bool = True, generator: torch.Generator | None = None):
@@ -180,9 +182,14 @@ class DeviceHapsDataset:
         return batch
 
     def to_dataloader(self, batch_size: int = 1, shuffle: bool = False, sampler=None, drop_last: bool = False,
-                      generator: torch.Generator | None = None, in_flight: int = 3) -> "DeviceLoader":
-        """``Dataset.to_dataloader`` (``_impl.py:1963-2072``) for device consumers."""
-        return DeviceLoader(self, batch_size, shuffle, sampler, drop_last, generator, in_flight)
+                      generator: torch.Generator | None = None, in_flight: int = 3, rank: int = 0,
+                      world_size: int = 1, seed: int = 0) -> "DeviceLoader":
+        """``Dataset.to_dataloader`` (``_impl.py:1963-2072``) for device consumers.  With
+        ``world_size > 1`` the epoch is sharded across ranks like ``DistributedSampler``
+        (:func:`genvarloader_amd.sharding.epoch_order`): same permutation on every rank, disjoint
+        strided shares, no collective."""
+        return DeviceLoader(self, batch_size, shuffle, sampler, drop_last, generator, in_flight, rank, world_size,
+                            seed)
 
 
 class DeviceLoader:
@@ -199,9 +206,14 @@ class DeviceLoader:
     its memory."""
 
     def __init__(self, ds: DeviceHapsDataset, batch_size=1, shuffle=False, sampler=None, drop_last=False,
-                 generator=None, in_flight=3):
+                 generator=None, in_flight=3, rank=0, world_size=1, seed=0):
         self.ds, self.batch_size, self.shuffle, self.drop_last = ds, int(batch_size), shuffle, drop_last
         self.sampler, self.generator = sampler, generator
+        self.rank, self.world_size, self.seed, self.epoch = int(rank), int(world_size), int(seed), 0
+        if not (0 <= self.rank < self.world_size):
+            raise ValueError("rank out of range")
+        if sampler is not None and self.world_size > 1:
+            raise ValueError("a custom sampler does its own sharding: pass world_size=1")
         self.in_flight = max(1, min(16, int(in_flight)))
         self._native = None
         self.streams = None
@@ -265,24 +277,23 @@ class DeviceLoader:
             self._native_setup()
         nat, ds, d = self._native, self.ds, self.ds.dev.device
         lib, handle, out = ds.dev.lib, nat["handle"], nat["out"]
-        n = len(ds)
         with torch.cuda.device(d):
             cur = torch.cuda.current_stream(d)
             g = self.generator
-            if not self.shuffle:
-                order = torch.arange(n, device=d)
-            elif g is None or g.device.type == "cuda":      # shuffle on the device: no H2D of the order
-                order = torch.randperm(n, generator=g, device=d)
-            else:
-                # host generator: shuffle into a persistent pinned buffer and copy asynchronously (a
-                # pageable H2D copy leaves deferred un-pinning work that can hold a later HIP call
-                # for tens of ms on some hosts)
+            if self.world_size == 1 and self.shuffle and g is not None and g.device.type != "cuda":
+                # host generator: shuffle into a persistent pinned buffer and copy asynchronously
                 pin = nat.get("pinned")
-                if pin is None or pin.numel() != n:
-                    pin = nat["pinned"] = torch.empty(n, dtype=torch.int64).pin_memory()
-                torch.randperm(n, generator=g, out=pin)
-                order = torch.empty(n, dtype=torch.int64, device=d)
+                if pin is None or pin.numel() != len(ds):
+                    pin = nat["pinned"] = torch.empty(len(ds), dtype=torch.int64).pin_memory()
+                torch.randperm(len(ds), generator=g, out=pin)
+                order = torch.empty(len(ds), dtype=torch.int64, device=d)
                 order.copy_(pin, non_blocking=True)
+            else:                                  # shuffle on the device: no H2D of the order
+                order = epoch_order(len(ds), shuffle=self.shuffle, seed=self.seed, epoch=self.epoch, rank=self.rank,
+                                    world=self.world_size, drop_last=self.drop_last and self.world_size > 1,
+                                    device=d, generator=g)
+            self.epoch += 1
+            n = int(order.numel())
             _lib.check(lib.gvl_loader_start_epoch(handle, C.c_void_p(order.data_ptr()), C.c_int64(n),
                                                   C.c_int32(int(self.drop_last)), C.c_void_p(cur.cuda_stream)))
             nat["order"] = order                       # keep the epoch order alive
@@ -316,7 +327,13 @@ class DeviceLoader:
 
     def __len__(self):
         n = len(self.ds)
+        if self.world_size > 1:                     # DistributedSampler: equal shares
+            n = n // self.world_size if self.drop_last else -(-n // self.world_size)
         return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+    def set_epoch(self, epoch: int) -> None:
+        """Like ``DistributedSampler.set_epoch``: the permutation is seeded by ``seed + epoch``."""
+        self.epoch = int(epoch)
 
     def __iter__(self):
         if self.sampler is None:

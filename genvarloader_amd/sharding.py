@@ -75,3 +75,38 @@ def all_gather_rows(local, row_lengths=None, group=None):
         return data
     lens = all_gather_rows(row_lengths.to(dev), None, group)
     return data, lens
+
+
+def epoch_order(n: int, *, shuffle: bool, seed: int = 0, epoch: int = 0, rank: int = 0, world: int = 1,
+                drop_last: bool = False, device="cpu", generator=None):
+    """This rank's dataset indices for one epoch, as an int64 tensor on ``device``.
+
+    The epoch is sharded across ranks the way ``torch.utils.data.DistributedSampler`` does it
+    (the sampler the reference's ``to_dataloader`` docs pair with DDP, ``_impl.py:1963-2072``):
+    every rank draws the SAME permutation (seeded by ``seed + epoch``), the list is padded by
+    wrapping (or truncated with ``drop_last``) to a multiple of ``world``, and rank ``r`` takes
+    elements ``r, r + world, ...`` -- disjoint, equal-sized, no collective.  With ``world == 1``
+    and a caller ``generator`` the permutation comes from that generator instead."""
+    import torch
+
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    if not shuffle:
+        order = torch.arange(n, device=device)
+    elif generator is not None and world == 1:
+        order = torch.randperm(n, generator=generator, device=generator.device).to(device)
+    else:
+        g = torch.Generator(device=device)
+        g.manual_seed(int(seed) + int(epoch))
+        order = torch.randperm(n, generator=g, device=device)
+    if world == 1:
+        return order
+    if drop_last:
+        total = (n // world) * world
+        order = order[:total]
+    else:
+        total = -(-n // world) * world
+        if total > n and n > 0:
+            reps = -(-(total - n) // n)
+            order = torch.cat([order] + [order] * reps)[:total]
+    return order[rank:total:world].contiguous()

@@ -186,3 +186,27 @@ def test_loader_sampler_path(oracle):
             np.repeat(full_regions[r_idx, 3] == -1, P), False, onehot=True)
         np.testing.assert_array_equal(b.haps.cpu().numpy().ravel(), exp)
         np.testing.assert_array_equal(b.onehot.cpu().numpy().reshape(-1, 4), exp_oh)
+
+
+@pytest.mark.gpu
+def test_loader_rank_shares_are_disjoint_and_cover():
+    """Two ranks' loaders (run one after the other on this GPU) see disjoint, equal shares of the
+    same per-epoch permutation -- the N-GPU epoch needs no collective."""
+    from genvarloader_amd import HapsDevice
+    from genvarloader_amd.loader import DeviceHapsDataset
+
+    R, S, P, L = 5, 7, 2, 256
+    st, full_regions, go, gv = _grid_dataset(12, R, S, P, L)
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+    ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L)
+    seen = []
+    for rank in range(2):
+        dl = ds.to_dataloader(batch_size=4, shuffle=True, rank=rank, world_size=2, seed=3)
+        dl.set_epoch(7)
+        ids = torch.cat([b.idx.clone() for b in dl]).cpu().numpy()
+        assert len(ids) == -(-R * S // 2) and len(dl) == -(-len(ids) // 4)
+        seen.append(ids)
+    both = np.concatenate(seen)
+    assert set(both.tolist()) == set(range(R * S)) and len(both) == R * S + (R * S) % 2

@@ -113,3 +113,39 @@ def test_synth_configs_shapes():
     assert ((st.ilens != 0).mean() > 0.05) and bt.output_length == 2048
     st2, bt2 = synth.make_config("cfg3", contig=1 << 20, windows=256)
     np.testing.assert_array_equal(bt.geno_v_idxs, bt2.geno_v_idxs)  # seeded
+
+
+def test_epoch_order_matches_distributed_sampler_semantics():
+    """Every rank draws the same permutation and takes a strided share; shares are equal-sized,
+    cover the dataset (padding by wrap-around) or truncate with drop_last."""
+    import torch
+
+    from genvarloader_amd.sharding import epoch_order
+
+    n = 103
+    for world in (1, 2, 3, 8):
+        for shuffle in (False, True):
+            for drop_last in (False, True):
+                shares = [epoch_order(n, shuffle=shuffle, seed=11, epoch=4, rank=r, world=world, drop_last=drop_last)
+                          for r in range(world)]
+                sizes = {int(s.numel()) for s in shares}
+                assert len(sizes) == 1
+                per = n // world if (drop_last and world > 1) else -(-n // world)
+                assert sizes == {per}
+                allv = torch.stack(shares, 1).reshape(-1)          # interleave back: rank r holds r::world
+                g = torch.Generator().manual_seed(11 + 4)
+                full = torch.randperm(n, generator=g) if shuffle else torch.arange(n)
+                if world == 1:
+                    assert torch.equal(allv, full)
+                elif drop_last:
+                    assert torch.equal(allv, full[: per * world])
+                else:
+                    assert torch.equal(allv[:n], full) and torch.equal(allv[n:], full[: per * world - n])
+    # another epoch -> another permutation; a caller generator is honoured at world 1
+    a = epoch_order(n, shuffle=True, seed=1, epoch=0)
+    b = epoch_order(n, shuffle=True, seed=1, epoch=1)
+    assert not torch.equal(a, b) and torch.equal(torch.sort(a).values, torch.arange(n))
+    g1, g2 = torch.Generator().manual_seed(3), torch.Generator().manual_seed(3)
+    assert torch.equal(epoch_order(n, shuffle=True, generator=g1), torch.randperm(n, generator=g2))
+    with pytest.raises(ValueError):
+        epoch_order(n, shuffle=False, rank=2, world=2)
