@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from genvarloader_amd import HapsDevice, synth, _lib
 wl = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
-st, bt = synth.make_config(wl)
+nwin = int(sys.argv[2]) if len(sys.argv) > 2 else None
+st, bt = synth.make_config(wl, windows=nwin)
 dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens, alt_alleles=st.alt_alleles,
                  alt_offsets=st.alt_offsets, geno_offsets=bt.geno_offsets, geno_v_idxs=bt.geno_v_idxs, pad_char=st.pad_char)
 dbt = dev.prepare_batch(bt.regions, bt.shifts, bt.geno_offset_idx, bt.output_length, to_rc=bt.to_rc)
