@@ -19,8 +19,10 @@ LIB_NAME = "libgvl_hip.so"
 # every symbol include/gvl_hip.h declares (tests check the library exports them all)
 SYMBOLS = (
     "gvl_abi_version",
+    "gvl_set_debug_flags",
     "gvl_last_error",
     "gvl_pack_variants",
+    "gvl_pack_genotypes",
     "gvl_reconstruct",
     "gvl_get_diffs_sparse",
     "gvl_hap_offsets",
@@ -38,6 +40,7 @@ SYMBOLS = (
     "gvl_loader_destroy",
 )
 
+ABI_VERSION = 2          # include/gvl_hip.h: GVL_ABI_VERSION
 GVL_ONEHOT_LC = 0
 GVL_ONEHOT_CL = 1
 
@@ -51,7 +54,7 @@ class GvlStatic(C.Structure):
         ("v_starts", _vp), ("ilens", _vp), ("alt_offsets", _vp), ("alt_alleles", _vp),
         ("n_variants", _i64), ("alt_len", _i64), ("vrec", _vp),
         ("geno_o_starts", _vp), ("geno_o_stops", _vp), ("n_geno_offsets", _i64),
-        ("geno_v_idxs", _vp), ("n_geno", _i64), ("pad_char", C.c_uint8),
+        ("geno_v_idxs", _vp), ("n_geno", _i64), ("pad_char", C.c_uint8), ("geno_rec", _vp),
     ]
 
 
@@ -122,6 +125,8 @@ def load() -> C.CDLL:
         raise GvlError(f"failed to load {p}: {e}") from e
     lib.gvl_last_error.restype = C.c_char_p
     lib.gvl_abi_version.restype = C.c_int
+    if lib.gvl_abi_version() != ABI_VERSION:
+        raise GvlError(f"{p}: ABI version {lib.gvl_abi_version()}, this binding needs {ABI_VERSION} (rebuild the library)")
     for name in SYMBOLS:
         fn = getattr(lib, name, None)
         if fn is None:

@@ -144,7 +144,7 @@ struct ReconArgs {
     const u8 *ref; i64 ref_len; const i64 *ref_offsets;
     const gvl_vrec *vrec; const i64 *alt_offsets; const u8 *alt_alleles; i64 alt_len;
     i64 n_variants;
-    const i64 *go_starts; const i64 *go_stops; const int *geno_v_idxs;
+    const i64 *go_starts; const i64 *go_stops; const int *geno_v_idxs; const gvl_grec *grec;
     // batch
     const int *regions; i64 regions_stride; const int *shifts; const i64 *geno_offset_idx;
     const u8 *keep; const i64 *keep_offsets; const u8 *to_rc; const i64 *out_offsets;
@@ -793,21 +793,34 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             int pos = 0, d = 0, alen = 0, inl = 0, vi = 0; i64 a0 = 0;
             bool valid = tb + lane < n_var;
             if (valid) {
-                int v = A.geno_v_idxs[o_s + tb + lane];
-                v = v < 0 ? 0 : ((i64)v >= A.n_variants ? (int)(A.n_variants - 1) : v);
-                const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.vrec + v);
-                a0 = A.alt_offsets[v];
-                pos = rec.x; d = rec.y; alen = rec.z; inl = rec.w; vi = v;
+                if (A.grec) {
+                    // the variant's fields sit next to the CSR entry: one contiguous read, and
+                    // only lanes that will need allele bytes from memory go on to alt_offsets
+                    const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.grec + (o_s + tb + lane));
+                    pos = rec.x; d = rec.y; alen = (int)((u32)rec.z >> 8); inl = rec.z & 0xFF; vi = rec.w;
+                    if (!(d == 0 && alen == 1)) a0 = A.alt_offsets[vi];
+                } else {
+                    int v = A.geno_v_idxs[o_s + tb + lane];
+                    v = v < 0 ? 0 : ((i64)v >= A.n_variants ? (int)(A.n_variants - 1) : v);
+                    const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.vrec + v);
+                    a0 = A.alt_offsets[v];
+                    pos = rec.x; d = rec.y; alen = rec.z; inl = rec.w; vi = v;
+                }
                 if (has_keep) valid = A.keep[keep_off + tb + lane] != 0;
             }
             // coordinates beyond 2^30 (or nonsense) go to the scalar path: everything below is i32
+            // (grec clips alen to 2^24 - 1: such an allele is "weird" here and exact there)
             const bool weird = valid && (pos < 0 || pos >= (1 << 30) || d <= -(1 << 30) || d >= (1 << 30) ||
-                                         alen < 0 || alen >= (1 << 30));
+                                         alen < 0 || alen >= (A.grec ? 0xFFFFFF : (1 << 30)));
             ok = ok && __builtin_amdgcn_ballot_w64(weird) == 0;
             const int E = pos - (d < 0 ? d : 0) + 1;                        // v_ref_end, :96
             const bool is_snp = d == 0 && alen == 1;
             // DEL spanning the window start (:99-102): the last one in order sets ref_idx.  Such
             // variants precede every candidate (sorted by position), so nothing is applied yet.
+            // a row with an indel has the longest plan and the slowest trips; it decides when the
+            // launch ends, so its wave wins the issue arbitration against waves already streaming
+            // (cfg3: -0.4..-0.7 us per launch, nothing lost with several batches in flight)
+            if (__builtin_amdgcn_ballot_w64(valid && !is_snp)) __builtin_amdgcn_s_setprio(3);
             const u64 m_span = __builtin_amdgcn_ballot_w64(valid && pos < ref_start && d < 0 && E >= ref_start);
             if (m_span) { ref_idx0 = rdl(E, 63 - __builtin_clzll(m_span)); pm_carry = ref_idx0; ref_idx_end = ref_idx0; }
             bool cand = valid && pos >= ref_start;
@@ -1045,6 +1058,14 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         }
     }
     GVL_STAMP(5);
+#ifdef GVL_DIAG
+    if (A.stamps && lane == 0) {   // every wave: latest / earliest "plan ready"
+        unsigned long long *b = (unsigned long long *)&A.stamps[((u64)blockIdx.x * gridDim.y + blockIdx.y) * 16];
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        atomicMax(b + 13, t);
+        atomicMin(b + 14, t);
+    }
+#endif
 
     // ---- P4: stream ----------------------------------------------------------------------
     const bool rc = rfl(ri.rc) != 0;
@@ -1334,6 +1355,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         finish_partial(p0, wv, av4, ap4);
     }
     GVL_STAMP(7);
+    __builtin_amdgcn_s_setprio(0);
     // pass B: finish the class-0 trips.  Store addresses are a scalar base per trip plus a
     // per-lane offset that never changes: forward rows put lane l at +16*l, reverse-complemented
     // rows mirror the index (lane l at +16*(63-l) from the trip's lowest address).
@@ -1408,6 +1430,14 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     }
     __builtin_amdgcn_s_waitcnt(0);
     GVL_STAMP(8);
+#ifdef GVL_DIAG
+    if (A.stamps && lane == 0) {   // every wave: latest / earliest end of the workgroup
+        unsigned long long *b = (unsigned long long *)&A.stamps[((u64)blockIdx.x * gridDim.y + blockIdx.y) * 16];
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        atomicMax(b + 11, t);
+        atomicMin(b + 12, t);
+    }
+#endif
 }
 
 #undef GVL_STAMP
@@ -1556,6 +1586,19 @@ __global__ __launch_bounds__(256) void pack_variants_kernel(const int *v_starts,
     r.alen = (int)(len < 0 ? 0 : (len > 2147483647ll ? 2147483647ll : len));
     r.inl = inl;
     out[v] = r;
+}
+
+__global__ __launch_bounds__(256) void pack_genotypes_kernel(const int *geno_v_idxs, i64 n_geno, const gvl_vrec *vrec,
+                                                              i64 n_variants, gvl_grec *out) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_geno) return;
+    int v = geno_v_idxs[i];
+    v = v < 0 ? 0 : ((i64)v >= n_variants ? (int)(n_variants - 1) : v);
+    const i32x4 r = *reinterpret_cast<const i32x4 *>(vrec + v);
+    const u32 alen = r.z < 0 ? 0xFFFFFFu : ((u32)r.z > 0xFFFFFFu ? 0xFFFFFFu : (u32)r.z);   // 0xFFFFFF = "ask vrec"
+    gvl_grec g;
+    g.pos = r.x; g.ilen = r.y; g.alen_inl = (alen << 8) | ((u32)r.w & 0xFFu); g.v_idx = v;
+    out[i] = g;
 }
 
 // ---------------------------------------------------------------------------
@@ -2130,10 +2173,11 @@ int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
 
 // GVL_DBG (read once): test/diagnostic switches.  8 = force the scalar per-wave path for every
 // row (the GPU suite runs once this way); 1/2/4 = ablations (no variants / no stores / no loads)
-// that only make sense for timing.
+// that only make sense for timing; 16 = ignore gvl_static.geno_rec (A/B of the record layout).
+int g_debug_override = -1;
 int debug_flags() {
     static const int flags = [] { const char *e = getenv("GVL_DBG"); return e ? atoi(e) : 0; }();
-    return flags;
+    return g_debug_override >= 0 ? g_debug_override : flags;
 }
 
 int log2_exact(i64 v) {
@@ -2157,6 +2201,7 @@ template <typename F> hipError_t traced(const char *tag, F f) {
 extern "C" {
 
 int gvl_abi_version(void) { return GVL_ABI_VERSION; }
+int gvl_set_debug_flags(int flags) { g_debug_override = flags; return GVL_OK; }
 #ifdef GVL_DIAG
 void gvl_diag_set_stamps(void *buf) { g_stamps = (u64 *)buf; }
 #endif
@@ -2173,6 +2218,18 @@ int gvl_pack_variants(const int32_t *v_starts, const int32_t *ilens, const int64
     hipLaunchKernelGGL(pack_variants_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        v_starts, ilens, (const i64 *)alt_offsets, alt_alleles, (i64)n_variants, vrec_out);
     return check_launch("gvl_pack_variants");
+}
+
+int gvl_pack_genotypes(const gvl_static *st, gvl_grec *grec_out, void *stream) {
+    if (!st || st->n_geno < 0 || st->n_variants < 0) return fail(GVL_ERR_INVALID, "%s", "gvl_pack_genotypes: bad arguments");
+    if (st->n_geno == 0) return GVL_OK;
+    if (!st->geno_v_idxs || !st->vrec || !grec_out || st->n_variants == 0)
+        return fail(GVL_ERR_INVALID, "%s", "gvl_pack_genotypes: NULL array (vrec from gvl_pack_variants is required)");
+    const i64 grid = (st->n_geno + 255) / 256;
+    if (grid > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_pack_genotypes: too many entries");
+    pack_genotypes_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(st->geno_v_idxs, st->n_geno, st->vrec,
+                                                                                       st->n_variants, grec_out);
+    return check_launch("gvl_pack_genotypes");
 }
 
 int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *out, void *stream) {
@@ -2202,6 +2259,7 @@ int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *ou
     A.alt_len = st->alt_len; A.n_variants = st->n_variants;
     A.go_starts = (const i64 *)st->geno_o_starts; A.go_stops = (const i64 *)st->geno_o_stops;
     A.geno_v_idxs = st->geno_v_idxs;
+    A.grec = (debug_flags() & 16) ? nullptr : st->geno_rec;
     A.regions = bt->regions; A.regions_stride = bt->regions_stride; A.shifts = bt->shifts;
     A.geno_offset_idx = (const i64 *)bt->geno_offset_idx;
     A.keep = bt->keep; A.keep_offsets = (const i64 *)bt->keep_offsets; A.to_rc = bt->to_rc;

@@ -97,7 +97,7 @@ class ReconOutput:
 
 class HapsDevice:
     def __init__(self, *, ref, ref_offsets, v_starts, ilens, alt_alleles, alt_offsets,
-                 geno_offsets, geno_v_idxs, pad_char=ord("N"), device="cuda"):
+                 geno_offsets, geno_v_idxs, pad_char=ord("N"), device="cuda", inline_genotypes=None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.GvlError("genvarloader_amd needs a HIP device (no CPU fallback)")
@@ -131,8 +131,20 @@ class HapsDevice:
             n_variants=n_var, alt_len=self.alt_alleles.numel(), vrec=self.vrec.data_ptr(),
             geno_o_starts=self.geno_offsets[0].data_ptr(), geno_o_stops=self.geno_offsets[1].data_ptr(),
             n_geno_offsets=n_go, geno_v_idxs=self.geno_v_idxs.data_ptr(),
-            n_geno=self.geno_v_idxs.numel(), pad_char=self.pad_char,
+            n_geno=self.geno_v_idxs.numel(), pad_char=self.pad_char, geno_rec=None,
         )
+        # Derived layout: the variant's fields next to each genotype CSR entry (gvl_grec, 16 B per
+        # entry) removes one of the dependent gathers in the kernel head.  Default: build it
+        # when it costs less than a quarter of the free HBM.
+        self.geno_rec = None
+        n_geno = int(self.geno_v_idxs.numel())
+        if inline_genotypes is None:
+            inline_genotypes = n_geno > 0 and n_var > 0 and 16 * n_geno <= torch.cuda.mem_get_info(d)[0] // 4
+        if inline_genotypes and n_geno > 0 and n_var > 0:
+            with torch.cuda.device(d):
+                self.geno_rec = torch.empty((n_geno, 4), dtype=torch.int32, device=d)
+                _lib.check(self.lib.gvl_pack_genotypes(C.byref(self.c), _ptr(self.geno_rec), _stream_ptr()))
+            self.c.geno_rec = self.geno_rec.data_ptr()
 
     # ------------------------------------------------------------------ batches
     def prepare_batch(self, regions, shifts, geno_offset_idx, output_length, keep=None,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GVL_ABI_VERSION 1
+#define GVL_ABI_VERSION 2
 
 enum {
     GVL_OK = 0,
@@ -56,6 +56,17 @@ typedef struct gvl_vrec {
     uint32_t inl;    /* first 4 ALT bytes, little endian (zero padded)     */
 } gvl_vrec;
 
+/* 16-byte record per genotype CSR entry, built once per dataset by
+ * gvl_pack_genotypes(): the variant's fields next to the CSR entry itself, so that a row's
+ * variants are ONE contiguous 16-B-per-lane read (geno_v_idxs[i] -> vrec[v] is two dependent
+ * gathers, ~1 us of a 13 us launch).  Optional: 16 B x n_geno of HBM. */
+typedef struct gvl_grec {
+    int32_t pos;       /* v_starts[v]                                              */
+    int32_t ilen;      /* ilens[v]                                                 */
+    uint32_t alen_inl; /* (min(alen, 2^24 - 1) << 8) | first ALT byte              */
+    int32_t v_idx;     /* geno_v_idxs[i], clamped to [0, n_variants)               */
+} gvl_grec;
+
 /* Per-dataset, device-resident arrays.  Mirrors `_HapsFfiStatic`
  * (_haps.py:233-247) + `Reference` (_reference.py:31-50) + the sparse genotype
  * CSR (`genotypes/offsets.npy`, `variant_idxs.npy`). */
@@ -77,6 +88,7 @@ typedef struct gvl_static {
     const int32_t *geno_v_idxs;  /* n_geno                                  */
     int64_t n_geno;
     uint8_t pad_char;
+    const gvl_grec *geno_rec;    /* nullable: n_geno, from gvl_pack_genotypes() */
 } gvl_static;
 
 /* Per-batch arrays.  Mirrors `ReconstructionRequest` (_haps.py:58-93) as
@@ -115,6 +127,9 @@ typedef struct gvl_out {
 } gvl_out;
 
 int gvl_abi_version(void);
+/* Test / diagnostic switches (the bits of the GVL_DBG environment variable, see
+ * debug_flags() in gvl_hip.hip); flags < 0 returns to the environment's value. */
+int gvl_set_debug_flags(int flags);
 const char *gvl_last_error(void);
 
 /* Build the packed variant records (once per dataset).
@@ -123,6 +138,10 @@ const char *gvl_last_error(void);
 int gvl_pack_variants(const int32_t *v_starts, const int32_t *ilens,
                       const int64_t *alt_offsets, const uint8_t *alt_alleles,
                       int64_t n_variants, gvl_vrec *vrec_out, void *stream);
+
+/* Build the per-genotype-entry records (once per dataset; optional, see gvl_grec).
+ * Needs st->vrec, st->geno_v_idxs, st->n_geno, st->n_variants. */
+int gvl_pack_genotypes(const gvl_static *st, gvl_grec *grec_out, void *stream);
 
 /* Haplotype reconstruction (+RC, +one-hot, +annotations) for a batch.
  * Replaces: reconstruct_haplotypes_fused (src/ffi/mod.rs:722-860) steps 3-4b,

@@ -33,6 +33,11 @@ def test_fuzz_haplotypes_scalar_path():
     _run("fuzz.py", 300, 102, dbg=8)
 
 
+def test_fuzz_haplotypes_without_genotype_records():
+    """GVL_DBG=16: ignore gvl_static.geno_rec, i.e. the geno_v_idxs -> vrec gather."""
+    _run("fuzz.py", 300, 105, dbg=16)
+
+
 def test_fuzz_tracks_planned_walk():
     _run("fuzz_tracks.py", 400, 103)
 

@@ -13,6 +13,9 @@ dbt = dev.prepare_batch(bt.regions, bt.shifts, bt.geno_offset_idx, bt.output_len
 out, oc = dev.alloc_output(dbt, bt.n_windows * bt.output_length, haps=False, onehot=True)
 nwg = (bt.n_windows + 7) // 8
 stamps = torch.zeros(nwg * 16, dtype=torch.int64, device="cuda")
+def reset():
+    stamps.zero_(); stamps.view(nwg, 16)[:, 12] = 1 << 62; stamps.view(nwg, 16)[:, 14] = 1 << 62
+reset()
 lib = _lib.load()
 for i in range(20): dev.launch(dbt, oc)
 torch.cuda.synchronize()
@@ -35,3 +38,7 @@ end = s[:, 8] - s[:, 0]
 for g in sorted(set(ng.tolist())):
     m = ng == g
     print(f"wave0 general trips={g}: {m.sum():4d} WGs  passG median {np.median(d[m, 6]):7.0f} ns  total median {np.median(end[m]):7.0f} max {end[m].max():7.0f}")
+
+for name, col in (("plan ready, earliest wave", 14), ("plan ready, latest wave", 13), ("end, earliest wave", 12), ("end, latest wave", 11)):
+    c = s[:, col] - t0
+    print(f"{name:28s} min {c.min():8.0f}  p10 {np.percentile(c,10):8.0f}  median {np.median(c):8.0f}  p90 {np.percentile(c,90):8.0f}  max {c.max():8.0f} ns")
