@@ -30,6 +30,7 @@ SYMBOLS = (
     "gvl_rc_rows",
     "gvl_reverse_rows_4",
     "gvl_onehot",
+    "gvl_intervals_prefix_max",
     "gvl_intervals_to_tracks",
     "gvl_realign_tracks",
     "gvl_prepare_request",

@@ -2060,9 +2060,12 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A) 
 
 // src/intervals.rs:19-126.  One thread per output value: the value is that of the LAST
 // interval (in order) that covers the position -- what sequential painting leaves behind.
+// `pmax[c]` = max(ends[list start .. c]): a position no earlier interval reaches is 0.0 without
+// walking back over the whole list (gaps between intervals are the common case).
 __global__ __launch_bounds__(256) void intervals_to_tracks_kernel(
     const i64 *offset_idxs, const int *starts, i64 starts_stride, i64 n_queries, const int *itv_starts,
-    const int *itv_ends, const float *itv_values, const i64 *itv_offsets, float *out, const i64 *out_offsets) {
+    const int *itv_ends, const float *itv_values, const i64 *itv_offsets, const int *pmax, float *out,
+    const i64 *out_offsets, int chunk_len, const u8 *chunk_todo) {
     const i64 q = blockIdx.y;
     if (q >= n_queries) return;
     const i64 o0 = out_offsets[q];
@@ -2070,7 +2073,16 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_kernel(
     const i64 idx = offset_idxs[q];
     const i64 s0 = itv_offsets[idx], e0 = itv_offsets[idx + 1];
     const i64 qs = starts[q * starts_stride];
-    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < length; j += (i64)gridDim.x * blockDim.x) {
+    // chunk mode (after the tiled kernel): block = one chunk, only the chunks it left behind;
+    // otherwise a grid-stride loop over the whole row
+    i64 j_begin = (i64)blockIdx.x * blockDim.x + threadIdx.x, j_end = length, j_step = (i64)gridDim.x * blockDim.x;
+    if (chunk_todo) {
+        if (!chunk_todo[q * gridDim.x + blockIdx.x]) return;
+        j_begin = (i64)blockIdx.x * chunk_len + threadIdx.x;
+        j_end = ((i64)blockIdx.x + 1) * chunk_len < length ? ((i64)blockIdx.x + 1) * chunk_len : length;
+        j_step = blockDim.x;
+    }
+    for (i64 j = j_begin; j < j_end; j += j_step) {
         // c = last interval with start - qs <= j  (intervals are sorted by start)
         i64 lo = s0, hi = e0;   // first interval with start - qs > j
         while (lo < hi) {
@@ -2078,10 +2090,166 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_kernel(
             if ((i64)itv_starts[mid] - qs <= j) lo = mid + 1; else hi = mid;
         }
         float v = 0.0f;
-        for (i64 c = lo - 1; c >= s0; --c) {
-            if ((i64)itv_ends[c] - qs > j) { v = itv_values[c]; break; }
+        if (lo > s0 && (i64)pmax[lo - 1] - qs > j) {
+            for (i64 c = lo - 1; c >= s0; --c) {
+                if ((i64)itv_ends[c] - qs > j) { v = itv_values[c]; break; }
+            }
         }
         __builtin_nontemporal_store(v, out + o0 + j);
+    }
+}
+
+// Tiled painter: one wave per (query, 2048-value chunk).  The intervals that can touch the chunk
+// are [lo_c, hi_c): hi_c = first start at or after the chunk's end, lo_c = first interval whose
+// running max of ends passes the chunk's start (two interleaved 64-ary searches, 2 rounds for
+// lists of thousands).  "Later intervals overwrite earlier ones" = every position takes the
+// candidate with the HIGHEST index that covers it, so the wave paints candidate indices into an
+// LDS image of the chunk with ds_max (order-free; lane = interval for short ones, the whole wave
+// for a long one) and then streams the image out through the candidates' values.  Chunks with
+// more than PAINT_TILE candidates are left to the per-value kernel above.
+constexpr int PAINT_TILE = 256;
+constexpr int PAINT_CHUNK = 2048;
+struct PaintTile { u32 idx[PAINT_CHUNK]; float cv[PAINT_TILE]; };
+
+__global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
+    const i64 *offset_idxs, const int *starts, i64 starts_stride, i64 n_queries, const int *itv_starts,
+    const int *itv_ends, const float *itv_values, const i64 *itv_offsets, const int *pmax, float *out,
+    const i64 *out_offsets, int chunk_len, int n_chunks, u8 *chunk_todo) {
+    __shared__ PaintTile tiles[4];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = rfl((int)(threadIdx.x >> 6));
+    PaintTile &T = tiles[wave];
+    const i64 q = blockIdx.y;
+    const i64 chunk = (i64)blockIdx.x * 4 + wave;
+    if (chunk >= n_chunks) return;
+    const i64 o0 = rfl64(out_offsets[q]);
+    const i64 length = rfl64(out_offsets[q + 1]) - o0;
+    const i64 j0 = chunk * chunk_len;
+    if (j0 >= length) { if (lane == 0) chunk_todo[q * n_chunks + chunk] = 0; return; }
+    const i64 j1 = (length - j0 > chunk_len) ? j0 + chunk_len : length;
+    const i64 idx = rfl64(offset_idxs[q]);
+    const i64 s0 = rfl64(itv_offsets[idx]), e0 = rfl64(itv_offsets[idx + 1]);
+    const i64 qs = rfl(starts[q * starts_stride]);
+    // first start - qs >= j1 and first pmax - qs > j0: both searches advance together so that
+    // their probe loads overlap (2 dependent rounds for lists of thousands instead of 4)
+    i64 hi_c, lo_c;
+    {
+        i64 a1 = s0, b1 = e0, a2 = s0, b2 = e0;
+        bool d1 = false, d2 = false;
+        while (!(d1 && d2)) {
+            i64 p1 = 0, p2 = 0, st1 = 1, st2 = 1;
+            int k1 = 0, k2 = 0;
+            if (!d1) {
+                if (a1 >= b1) d1 = true;
+                else { st1 = (b1 - a1 + WAVE - 1) / WAVE; p1 = a1 + (i64)(lane + 1) * st1 - 1; if (p1 > b1 - 1) p1 = b1 - 1; k1 = itv_starts[p1]; }
+            }
+            if (!d2) {
+                if (a2 >= b2) d2 = true;
+                else { st2 = (b2 - a2 + WAVE - 1) / WAVE; p2 = a2 + (i64)(lane + 1) * st2 - 1; if (p2 > b2 - 1) p2 = b2 - 1; k2 = pmax[p2]; }
+            }
+            if (!d1) {
+                const u64 m = __builtin_amdgcn_ballot_w64((i64)k1 - qs > j1 - 1);
+                if (m == 0) { a1 = b1; d1 = true; }
+                else {
+                    const int f = __builtin_ctzll(m);
+                    i64 pf = a1 + (i64)(f + 1) * st1 - 1; if (pf > b1 - 1) pf = b1 - 1;
+                    if (st1 == 1) { b1 = pf; a1 = pf; d1 = true; }
+                    else { if (f > 0) a1 += (i64)f * st1; b1 = pf; if (a1 >= b1) d1 = true; }
+                }
+            }
+            if (!d2) {
+                const u64 m = __builtin_amdgcn_ballot_w64((i64)k2 - qs > j0);
+                if (m == 0) { a2 = b2; d2 = true; }
+                else {
+                    const int f = __builtin_ctzll(m);
+                    i64 pf = a2 + (i64)(f + 1) * st2 - 1; if (pf > b2 - 1) pf = b2 - 1;
+                    if (st2 == 1) { b2 = pf; a2 = pf; d2 = true; }
+                    else { if (f > 0) a2 += (i64)f * st2; b2 = pf; if (a2 >= b2) d2 = true; }
+                }
+            }
+        }
+        hi_c = b1; lo_c = b2 < hi_c ? b2 : hi_c;
+    }
+    const i64 n_c64 = hi_c - lo_c;
+    u8 *todo = chunk_todo + q * n_chunks + chunk;
+    if (n_c64 > PAINT_TILE) { if (lane == 0) *todo = 1; return; }              // the per-value kernel takes it
+    if (lane == 0) *todo = 0;
+    const int n_c = (int)n_c64;
+    const int clen = (int)(j1 - j0);
+    {   // clear the image
+        const u32x4_a4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int t = 0; t < PAINT_CHUNK / (4 * WAVE); ++t) *reinterpret_cast<u32x4_a4 *>(&T.idx[4 * (t * WAVE + lane)]) = z;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int b = 0; b < n_c; b += WAVE) {
+        const int i = b + lane;
+        int s_rel = 0, w = 0;
+        if (i < n_c) {
+            i64 s64 = (i64)itv_starts[lo_c + i] - qs - j0, e64 = (i64)itv_ends[lo_c + i] - qs - j0;
+            s64 = s64 < 0 ? 0 : s64;
+            e64 = e64 > clen ? clen : e64;
+            if (e64 > s64) { s_rel = (int)s64; w = (int)(e64 - s64); }
+            T.cv[i] = itv_values[lo_c + i];
+        }
+        const u32 tag = (u32)(i + 1);
+        const bool is_long = w > 32;
+        // short intervals: lane = interval
+        for (int t = 0; __builtin_amdgcn_ballot_w64(!is_long && t < w) != 0; ++t)
+            if (!is_long && t < w) atomicMax(&T.idx[s_rel + t], tag);
+        // long intervals: the whole wave paints one at a time
+        u64 m_long = __builtin_amdgcn_ballot_w64(is_long);
+        while (m_long) {
+            const int l = __builtin_ctzll(m_long);
+            m_long &= m_long - 1;
+            const int ls = rdl(s_rel, l), lw = rdl(w, l);
+            const u32 lt = (u32)(b + l + 1);
+            for (int t = lane; t < lw; t += WAVE) atomicMax(&T.idx[ls + t], lt);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float *row = out + o0 + j0;
+#pragma unroll
+    for (int t = 0; t < PAINT_CHUNK / TRIP; ++t) {
+        const int p = t * TRIP + GROUP * lane;
+        if (p < clen) {
+            const u32x4_a4 ix = *reinterpret_cast<const u32x4_a4 *>(&T.idx[p]);
+            const float v0 = ix.x ? T.cv[ix.x - 1] : 0.0f, v1 = ix.y ? T.cv[ix.y - 1] : 0.0f;
+            const float v2 = ix.z ? T.cv[ix.z - 1] : 0.0f, v3 = ix.w ? T.cv[ix.w - 1] : 0.0f;
+            if (p + GROUP <= clen) {
+                store_f32x4(row + p, v0, v1, v2, v3);
+            } else {
+                if (p < clen) row[p] = v0;
+                if (p + 1 < clen) row[p + 1] = v1;
+                if (p + 2 < clen) row[p + 2] = v2;
+            }
+        }
+    }
+}
+
+// pmax[c] = max(ends[s .. c]) within each queried list: one wave per list, 64 entries per trip
+__global__ __launch_bounds__(256) void intervals_prefix_max_kernel(const i64 *list_idxs, i64 n_lists,
+                                                                    const int *itv_ends, const i64 *itv_offsets,
+                                                                    int *pmax) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    for (i64 w = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n_lists; w += ((i64)gridDim.x * blockDim.x) >> 6) {
+        const i64 idx = list_idxs ? list_idxs[w] : w;
+        const i64 s0 = itv_offsets[idx], e0 = itv_offsets[idx + 1];
+        int carry = (int)0x80000000;
+        for (i64 b = s0; b < e0; b += WAVE) {
+            const i64 c = b + lane;
+            int v = c < e0 ? itv_ends[c] : (int)0x80000000;
+            // inclusive max scan (signed): bias to unsigned order for OpMaxU
+            int u = wave_scan_inclusive<OpMaxU>((int)((u32)v ^ 0x80000000u));
+            int m = (int)((u32)u ^ 0x80000000u);
+            m = m > carry ? m : carry;
+            if (c < e0) pmax[c] = m;
+            carry = rdl(m, WAVE - 1);
+        }
     }
 }
 
@@ -2400,21 +2568,72 @@ int gvl_onehot(const uint8_t *in, int64_t n, uint8_t *out, void *stream) {
 }
 
 
+int gvl_intervals_prefix_max(const int32_t *itv_ends, const int64_t *itv_offsets, int64_t n_lists,
+                             int32_t *pmax_out, void *stream) {
+    if (n_lists < 0) return fail(GVL_ERR_INVALID, "%s", "gvl_intervals_prefix_max: negative size");
+    if (n_lists == 0) return GVL_OK;
+    if (!itv_ends || !itv_offsets || !pmax_out) return fail(GVL_ERR_INVALID, "%s", "gvl_intervals_prefix_max: NULL array");
+    i64 grid = (n_lists + 3) / 4;
+    if (grid > 65535) grid = 65535;
+    intervals_prefix_max_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(
+        nullptr, (i64)n_lists, itv_ends, (const i64 *)itv_offsets, pmax_out);
+    return check_launch("gvl_intervals_prefix_max");
+}
+
 int gvl_intervals_to_tracks(const int64_t *offset_idxs, const int32_t *starts, int64_t starts_stride,
                             int64_t n_queries, const int32_t *itv_starts, const int32_t *itv_ends,
-                            const float *itv_values, const int64_t *itv_offsets, float *out,
-                            const int64_t *out_offsets, int64_t max_row_len, void *stream) {
-    if (n_queries < 0 || max_row_len < 0) return fail(GVL_ERR_INVALID, "%s", "gvl_intervals_to_tracks: negative size");
+                            const float *itv_values, const int64_t *itv_offsets, int64_t n_intervals,
+                            const int32_t *itv_pmax_ends, float *out, const int64_t *out_offsets,
+                            int64_t max_row_len, void *stream) {
+    if (n_queries < 0 || max_row_len < 0 || n_intervals < 0) return fail(GVL_ERR_INVALID, "%s", "gvl_intervals_to_tracks: negative size");
     if (n_queries == 0 || max_row_len == 0) return GVL_OK;
     if (!offset_idxs || !starts || !itv_offsets || !out || !out_offsets || starts_stride < 1)
         return fail(GVL_ERR_INVALID, "%s", "gvl_intervals_to_tracks: NULL/invalid array");
+    if (n_intervals > 0 && (!itv_starts || !itv_ends || !itv_values))
+        return fail(GVL_ERR_INVALID, "%s", "gvl_intervals_to_tracks: NULL interval array");
     if (n_queries > 65535) return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_intervals_to_tracks: more than 65535 queries per call");
-    i64 gx = (max_row_len + 255) / 256;
-    if (gx > 1024) gx = 1024;
-    intervals_to_tracks_kernel<<<dim3((unsigned)gx, (unsigned)n_queries), dim3(256), 0, (hipStream_t)stream>>>(
-        (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
-        (const i64 *)itv_offsets, out, (const i64 *)out_offsets);
-    return check_launch("gvl_intervals_to_tracks");
+    hipStream_t s = (hipStream_t)stream;
+    int *scratch = nullptr;
+    if (!itv_pmax_ends && n_intervals > 0) {
+        // no precomputed prefix maxima: build them for the queried lists in stream-ordered scratch
+        if (hipMallocAsync((void **)&scratch, (size_t)n_intervals * sizeof(int), s) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(GVL_ERR_HIP, "%s", "gvl_intervals_to_tracks: scratch allocation failed (pass itv_pmax_ends)");
+        }
+        i64 grid = (n_queries + 3) / 4;
+        intervals_prefix_max_kernel<<<dim3((unsigned)grid), dim3(256), 0, s>>>((const i64 *)offset_idxs, (i64)n_queries, itv_ends,
+                                                                             (const i64 *)itv_offsets, scratch);
+        itv_pmax_ends = scratch;
+    }
+    // tiled pass (rows shorter than 2^31, every list has its prefix maxima), then the per-value
+    // kernel for the chunks it left (more than PAINT_TILE candidate intervals) -- or for everything
+    // when the flag scratch cannot be had
+    const int chunk_len = 2048;
+    const i64 n_chunks = (max_row_len + chunk_len - 1) / chunk_len;
+    u8 *todo = nullptr;
+    if (itv_pmax_ends && max_row_len < 0x7FFFFF00ll && n_chunks <= 0x7FFFFFFFll / 4 &&
+        hipMallocAsync((void **)&todo, (size_t)(n_queries * n_chunks), s) != hipSuccess) {
+        (void)hipGetLastError();
+        todo = nullptr;
+    }
+    if (todo) {
+        intervals_to_tracks_tiled_kernel<<<dim3((unsigned)((n_chunks + 3) / 4), (unsigned)n_queries), dim3(256), 0, s>>>(
+            (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
+            (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, (int)n_chunks, todo);
+        intervals_to_tracks_kernel<<<dim3((unsigned)n_chunks, (unsigned)n_queries), dim3(256), 0, s>>>(
+            (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
+            (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, todo);
+    } else {
+        i64 gx = (max_row_len + 255) / 256;
+        if (gx > 1024) gx = 1024;
+        intervals_to_tracks_kernel<<<dim3((unsigned)gx, (unsigned)n_queries), dim3(256), 0, s>>>(
+            (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
+            (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, nullptr);
+    }
+    const int rc = check_launch("gvl_intervals_to_tracks");
+    if (todo) (void)hipFreeAsync(todo, s);
+    if (scratch) (void)hipFreeAsync(scratch, s);
+    return rc;
 }
 
 int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *tracks,

@@ -331,8 +331,19 @@ def onehot(x: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------- tracks (a12)
+def intervals_prefix_max(itv_ends, itv_offsets, device="cuda") -> torch.Tensor:
+    """Running max of the interval ends inside each list (once per interval set)."""
+    lib = _lib.load()
+    d = torch.device(device)
+    b, io = _dev(itv_ends, torch.int32, d), _dev(itv_offsets, torch.int64, d)
+    pm = torch.empty_like(b)
+    with torch.cuda.device(d):
+        _lib.check(lib.gvl_intervals_prefix_max(_ptr(b), _ptr(io), C.c_int64(int(io.numel()) - 1), _ptr(pm), _stream_ptr()))
+    return pm
+
+
 def intervals_to_tracks(offset_idxs, starts, itv_starts, itv_ends, itv_values, itv_offsets, out_offsets,
-                        device="cuda", starts_stride=1, max_row_len=None) -> torch.Tensor:
+                        device="cuda", starts_stride=1, max_row_len=None, itv_pmax_ends=None) -> torch.Tensor:
     """intervals_to_tracks (src/intervals.rs:19-126) -> f32[out_offsets[-1]] device tensor."""
     lib = _lib.load()
     d = torch.device(device)
@@ -348,9 +359,10 @@ def intervals_to_tracks(offset_idxs, starts, itv_starts, itv_ends, itv_values, i
     if max_row_len is None:
         max_row_len = int((oo[1:] - oo[:-1]).max().item())
     with torch.cuda.device(d):
+        pm = _dev(itv_pmax_ends, torch.int32, d)
         _lib.check(lib.gvl_intervals_to_tracks(_ptr(oi), _ptr(st), C.c_int64(starts_stride), C.c_int64(n), _ptr(a),
-                                               _ptr(b), _ptr(v), _ptr(io), _ptr(out), _ptr(oo),
-                                               C.c_int64(max_row_len), _stream_ptr()))
+                                               _ptr(b), _ptr(v), _ptr(io), C.c_int64(int(a.numel())), _ptr(pm),
+                                               _ptr(out), _ptr(oo), C.c_int64(max_row_len), _stream_ptr()))
     return out
 
 

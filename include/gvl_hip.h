@@ -209,15 +209,24 @@ enum {
     GVL_FILL_INTERPOLATE = 4
 };
 
+/* Running maximum of the interval ends inside each list: pmax[c] = max(itv_ends[list start..c]).
+ * Built once per interval set (n_lists = number of lists in itv_offsets); lets the painter
+ * answer "no interval reaches this position" without walking back over the list. */
+int gvl_intervals_prefix_max(const int32_t *itv_ends, const int64_t *itv_offsets, int64_t n_lists,
+                             int32_t *pmax_out, void *stream);
+
 /* Paint sorted (start, end, value) intervals into zeroed per-query f32 rows.
  * Replaces intervals_to_tracks (src/ffi/mod.rs:188-240 -> src/intervals.rs:19-126).
  * offset_idxs i64 (n_queries): index into itv_offsets; starts i32 read at `starts_stride`
  * elements per query (regions + 1 with stride 4 works); out f32 (out_offsets[-1]);
- * out_offsets i64 (n_queries + 1).  max_row_len: host bound of any row's length. */
+ * out_offsets i64 (n_queries + 1).  max_row_len: host bound of any row's length.
+ * n_intervals: length of the itv_* arrays.  itv_pmax_ends: from gvl_intervals_prefix_max, or
+ * NULL (then it is built for the queried lists in stream-ordered scratch memory). */
 int gvl_intervals_to_tracks(const int64_t *offset_idxs, const int32_t *starts, int64_t starts_stride,
                             int64_t n_queries, const int32_t *itv_starts, const int32_t *itv_ends,
-                            const float *itv_values, const int64_t *itv_offsets, float *out,
-                            const int64_t *out_offsets, int64_t max_row_len, void *stream);
+                            const float *itv_values, const int64_t *itv_offsets, int64_t n_intervals,
+                            const int32_t *itv_pmax_ends, float *out, const int64_t *out_offsets,
+                            int64_t max_row_len, void *stream);
 
 /* Shift and realign per-query reference-coordinate tracks to each haplotype.
  * Replaces shift_and_realign_tracks_sparse (src/tracks/mod.rs:495-667; core :224-406,

@@ -154,3 +154,57 @@ def test_cfg4_full_haps_and_track(ffi, oracle):
     t_t = time.perf_counter() - t0
     np.testing.assert_array_equal(bits(got.cpu().numpy()), bits(exp_t))
     print(f"\ncfg4: V/row={bt.mean_variants:.0f}  haps+onehot {t_h*1e3:.2f} ms  track {t_t*1e3:.2f} ms (host-timed, incl. upload)")
+
+
+def test_painting_dense_nested_and_gappy_intervals(ffi, oracle):
+    """Painting beyond the tiled kernel's comfort zone: thousands of 1-3 bp intervals per 2048-value
+    chunk (more candidates than one LDS tile -> the per-value kernel takes those chunks), long
+    intervals with many short ones nested inside (the walk-back), wide gaps (the prefix-max
+    shortcut), negative relative starts, rows of different lengths, an empty list, with and
+    without precomputed prefix maxima."""
+    import torch
+
+    from genvarloader_amd import device
+
+    rng = np.random.default_rng(77)
+    lens = [5000, 2048, 1, 7001, 300]
+    qstart = rng.integers(1000, 2000, len(lens)).astype(np.int32)
+    lists = []
+    for qi, (L, q0) in enumerate(zip(lens, qstart)):
+        if qi == 4:
+            lists.append((np.zeros(0, np.int32),) * 2 + (np.zeros(0, np.float32),))
+            continue
+        parts = []
+        # dense: every position of [q0 - 50, q0 + 2500) starts a 1-3 bp interval (3 per position in a burst)
+        dense = np.repeat(np.arange(q0 - 50, q0 + min(L, 2500)), 1 + (qi == 0) * 2)
+        parts.append((dense, dense + rng.integers(1, 4, dense.size)))
+        # long intervals holding nested short ones, then gaps
+        base = q0 + 2600
+        while base < q0 + L + 100:
+            w = int(rng.integers(200, 900))
+            parts.append((np.array([base]), np.array([base + w])))
+            inner = np.sort(rng.integers(base, base + w // 2, 40))
+            parts.append((inner, inner + rng.integers(1, 6, inner.size)))
+            base += w + int(rng.integers(50, 700))
+        s = np.concatenate([p[0] for p in parts]); e = np.concatenate([p[1] for p in parts])
+        order = np.argsort(s, kind="stable")
+        lists.append((s[order].astype(np.int32), e[order].astype(np.int32), rng.random(s.size).astype(np.float32) + 0.5))
+    its = np.concatenate([l[0] for l in lists]); ite = np.concatenate([l[1] for l in lists])
+    itv = np.concatenate([l[2] for l in lists])
+    ito = np.concatenate([[0], np.cumsum([len(l[0]) for l in lists])]).astype(np.int64)
+    out_offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    # query order differs from list order and one list is used twice
+    oi = np.array([3, 0, 2, 1, 4, 0], np.int64)
+    qs = np.array([qstart[3], qstart[0], qstart[2], qstart[1], qstart[4], qstart[0] + 17], np.int32)
+    qlens = [lens[3], lens[0], lens[2], lens[1], lens[4], 4000]
+    oo = np.concatenate([[0], np.cumsum(qlens)]).astype(np.int64)
+    exp = np.full(int(oo[-1]), 7.0, np.float32)
+    oracle.intervals_to_tracks(oi, qs, its, ite, itv, ito, exp, oo)
+    got = device.intervals_to_tracks(oi, qs, its, ite, itv, ito, oo).cpu().numpy()
+    np.testing.assert_array_equal(bits(got), bits(exp))
+    pm = device.intervals_prefix_max(ite, ito)
+    ref_pm = np.concatenate([np.maximum.accumulate(l[1]) if len(l[1]) else l[1] for l in lists])
+    np.testing.assert_array_equal(pm.cpu().numpy(), ref_pm)
+    got2 = device.intervals_to_tracks(oi, qs, its, ite, itv, ito, oo, itv_pmax_ends=pm).cpu().numpy()
+    np.testing.assert_array_equal(bits(got2), bits(exp))
+    torch.cuda.synchronize()
