@@ -649,7 +649,7 @@ __device__ __forceinline__ int wave_scan_exclusive(int v, int &inclusive) {
 // ---------------------------------------------------------------------------------
 struct RowIn {
     i64 c_s, R, ref_start, shift, o_s, keep_off, row_base;
-    int n_var, L, rc, flags;     // flags: 1 = no work (row out of range / chunk past the row), 2 = scalar path, 4 = zero fill
+    int n_var, L, rc, flags;     // flags: 1 = no work (row out of range / chunk past the row), 2 = scalar path, 4 = zero fill, 8 = packed plan
 };
 template <bool ANNOT>
 struct RowPlan {
@@ -658,6 +658,292 @@ struct RowPlan {
     int p_out[WAVE], p_val[WAVE], p_id[ANNOT ? WAVE : 1];
 };
 constexpr u32 GENERAL_HI = 0x80000000u;
+
+// Trip descriptors of one row (what P3b produces), 8 trips per chunk; and the row's table sizes.
+struct TripDesc {
+    int cls[CHUNK_TRIPS], b1[CHUNK_TRIPS], b2[CHUNK_TRIPS], pc0[CHUNK_TRIPS], pcn[CHUNK_TRIPS], idx[CHUNK_TRIPS];
+    u32 ldlo[CHUNK_TRIPS], ldhi[CHUNK_TRIPS];
+    u32 lo0[CHUNK_TRIPS], hi0[CHUNK_TRIPS], lo1[CHUNK_TRIPS], hi1[CHUNK_TRIPS], lo2[CHUNK_TRIPS], hi2[CHUNK_TRIPS];
+};
+struct RowMeta { int nseg, npatch, bad, pad_; };
+
+// scans inside groups of 8 lanes (DPP row_shr 1/2/4, masked at the group boundary)
+template <typename Op>
+__device__ __forceinline__ int seg8_scan_inclusive(int v, int j) {
+    constexpr int id = Op::identity;
+    int t;
+    t = dpp_mov<0x111, 0xf>(id, v); v = j >= 1 ? Op::f(v, t) : v;
+    t = dpp_mov<0x112, 0xf>(id, v); v = j >= 2 ? Op::f(v, t) : v;
+    t = dpp_mov<0x114, 0xf>(id, v); v = j >= 4 ? Op::f(v, t) : v;
+    return v;
+}
+template <typename Op>
+__device__ __forceinline__ int seg8_scan_exclusive(int v, int j) {
+    const int inc = seg8_scan_inclusive<Op>(v, j);
+    const int t = dpp_mov<0x111, 0xf>(Op::identity, inc);
+    return j >= 1 ? t : Op::identity;
+}
+
+// ---------------------------------------------------------------------------------
+// Packed plan: ONE wave plans all 8 rows of the workgroup at once, lane = (row r = lane / 8,
+// variant j = lane % 8), for rows with at most 8 variants (99.7 % of cfg2 / cfg3 rows).  The
+// same restatement of the walk as the per-wave P3 below, with the scans confined to groups of 8
+// lanes; then P3b with lane = (row, trip).  It exists because the plan is a dependent
+// instruction chain: eight waves each running it for one row take eight times the issue slots
+// (and a row with an indel, whose plan is the longest, ends the launch), one wave running it
+// for eight rows takes the same chain once.
+// ---------------------------------------------------------------------------------
+template <bool ANNOT>
+__device__ __forceinline__ void packed_plan(const ReconArgs &A, const RowIn *rin, RowPlan<ANNOT> *plan, TripDesc *desc,
+                                            RowMeta *meta, const int lane, const int lo_clip, const bool has_keep) {
+    const int r = lane >> 3, j = lane & 7, seg_base = lane & ~7;
+    const RowIn &ri = rin[r];
+    RowPlan<ANNOT> &pl = plan[r];
+    const int rflags = ri.flags;
+    const bool elig = (rflags & 8) != 0 && !(rflags & 1);
+    const int L = ri.L;
+    const i64 c_s = ri.c_s, R = ri.R;
+    const int hi_clip = (L - lo_clip > A.chunk_len) ? lo_clip + A.chunk_len : L;
+    const int n_var = ri.n_var;
+    const i64 o_s = ri.o_s;
+    const i64 rs64 = ri.ref_start;
+    bool ok = rs64 > -(1 << 30) && rs64 < (1 << 30);
+    const int ref_start = ok ? (int)rs64 : 0;
+    const int shift_i = (int)ri.shift;                 // [0, 2^30): checked in P1
+    auto seg_byte = [&](u64 m) -> u32 { return (u32)(m >> seg_base) & 0xFFu; };
+
+    // ---- P2: records ----------------------------------------------------------------
+    int pos = 0, d = 0, alen = 0, inl = 0, vi = 0; i64 a0 = 0;
+    bool valid = elig && j < n_var;
+    if (valid) {
+        if (A.grec) {
+            const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.grec + (o_s + j));
+            pos = rec.x; d = rec.y; alen = (int)((u32)rec.z >> 8); inl = rec.z & 0xFF; vi = rec.w;
+            if (!(d == 0 && alen == 1)) a0 = A.alt_offsets[vi];
+        } else {
+            int v = A.geno_v_idxs[o_s + j];
+            v = v < 0 ? 0 : ((i64)v >= A.n_variants ? (int)(A.n_variants - 1) : v);
+            const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.vrec + v);
+            a0 = A.alt_offsets[v];
+            pos = rec.x; d = rec.y; alen = rec.z; inl = rec.w; vi = v;
+        }
+        if (has_keep) valid = A.keep[ri.keep_off + j] != 0;
+    }
+    const bool weird = valid && (pos < 0 || pos >= (1 << 30) || d <= -(1 << 30) || d >= (1 << 30) || alen < 0 ||
+                                 alen >= (A.grec ? 0xFFFFFF : (1 << 30)));
+    ok = ok && seg_byte(__builtin_amdgcn_ballot_w64(weird)) == 0;
+    if (!ok) valid = false;
+
+    // ---- P3 ---------------------------------------------------------------------------
+    const int raw = ref_start < 0 ? -ref_start : 0;
+    const int shifted0 = shift_i < raw ? shift_i : raw;
+    const int n_lead = (raw - shifted0 < L) ? raw - shifted0 : L;
+    int rem = shift_i - shifted0;
+    int ref_idx0 = ref_start < 0 ? 0 : ref_start;
+    const int lead_kept = (n_lead > 0 && n_lead > lo_clip && 0 < hi_clip) ? 1 : 0;
+    const int E = pos - (d < 0 ? d : 0) + 1;
+    const bool is_snp = d == 0 && alen == 1;
+    {   // DEL spanning the window start: the last one in order sets ref_idx
+        const u32 b = seg_byte(__builtin_amdgcn_ballot_w64(valid && pos < ref_start && d < 0 && E >= ref_start));
+        const int src = seg_base + (b ? 31 - __builtin_clz(b) : 0);
+        const int e_src = bperm(src, E);
+        if (b) ref_idx0 = e_src;
+    }
+    bool cand = valid && pos >= ref_start;
+    int a_skip = 0;     // a0 (a second dependent load for indel lanes) is first touched at the very end
+    {   // shift consumption
+        const int base = ref_idx0;
+        const u32 b = seg_byte(__builtin_amdgcn_ballot_w64(rem > 0 && cand && pos >= base && (pos - base) + alen >= rem));
+        const int f = b ? __builtin_ctz(b) : 0;
+        const int fl = seg_base + f;
+        const int pos_f = bperm(fl, pos), alen_f = bperm(fl, alen), E_f = bperm(fl, E);
+        if (rem > 0) {
+            if (b == 0) {
+                cand = false;
+            } else {
+                const int dist = pos_f - base;
+                if (dist >= rem) {
+                    ref_idx0 = base + rem;
+                    cand = cand && j >= f;
+                } else {
+                    const int skip = rem - dist;
+                    if (skip == alen_f) {
+                        ref_idx0 = E_f;
+                        cand = cand && j > f;
+                    } else {
+                        ref_idx0 = pos_f;
+                        cand = cand && j >= f;
+                        if (j == f) { alen -= skip; a_skip = skip; }
+                    }
+                }
+                rem = 0;
+            }
+        }
+    }
+    const int pm_carry = ref_idx0;
+    // first ALT wins: fixed point, all rows at once
+    bool inB = cand;
+    int PM = 0;
+    {
+        u64 mB = __builtin_amdgcn_ballot_w64(inB);
+        bool stable = false;
+#pragma unroll 1
+        for (int it = 0; it < 4 && !stable; ++it) {
+            PM = seg8_scan_exclusive<OpMaxU>(inB ? E : 0, j);
+            PM = PM > pm_carry ? PM : pm_carry;
+            inB = cand && pos >= PM;
+            const u64 m2 = __builtin_amdgcn_ballot_w64(inB);
+            stable = m2 == mB;
+            if (it == 3) ok = ok && seg_byte(m2) == seg_byte(mB);
+            mB = m2;
+        }
+    }
+    const int n_i = inB ? pos - PM : 0;
+    const int S_i = inB ? OpSat::f(n_i, alen) : 0;
+    const int X = seg8_scan_exclusive<OpSat>(S_i, j);
+    const int allele_out = OpSat::f(OpSat::f(n_lead, X), n_i);
+    const bool applied = inB && allele_out < L;
+    const int w_i = applied ? ((alen < L - allele_out) ? alen : L - allele_out) : 0;
+    const bool nonsnp = applied && !is_snp;
+    const bool snp = applied && is_snp;
+    const u32 b_app = seg_byte(__builtin_amdgcn_ballot_w64(applied));
+    const bool any_applied = b_app != 0;
+    int ref_idx_end = ref_idx0, out_idx_end = n_lead;
+    {
+        const int last = seg_base + (b_app ? 31 - __builtin_clz(b_app) : 0);
+        const int e_l = bperm(last, E), o_l = bperm(last, allele_out + w_i);
+        if (b_app) { ref_idx_end = e_l; out_idx_end = o_l; }
+    }
+    const int prevNS = seg8_scan_exclusive<OpMaxI>(nonsnp ? j : -1, j);
+    const int pidx = seg_base + (prevNS < 0 ? 0 : prevNS);
+    const int p_end = bperm(pidx, allele_out + alen);
+    const int p_E = bperm(pidx, E);
+    const int run_start = prevNS < 0 ? n_lead : p_end;
+    const i64 run_src = c_s + (prevNS < 0 ? ref_idx0 : p_E);
+    const bool e_ref = nonsnp && allele_out > run_start && allele_out > lo_clip && run_start < hi_clip;
+    const bool e_all = nonsnp && w_i > 0 && allele_out + w_i > lo_clip && allele_out < hi_clip;
+    const int slot0 = lead_kept + seg8_scan_exclusive<OpAdd>((e_ref ? 1 : 0) + (e_all ? 1 : 0), j);
+    const u32 b_ns = seg_byte(__builtin_amdgcn_ballot_w64(nonsnp));
+    const u32 b_snp = seg_byte(__builtin_amdgcn_ballot_w64(snp && allele_out >= lo_clip && allele_out < hi_clip));
+    const int n_ent = lead_kept + __builtin_popcount(seg_byte(__builtin_amdgcn_ballot_w64(e_ref))) +
+                      __builtin_popcount(seg_byte(__builtin_amdgcn_ballot_w64(e_all)));
+    const int npatch = __builtin_popcount(b_snp);
+    auto put = [&](int q, u32 kind, int o_start, i64 delta, int id, int vpos) {
+        const u64 e = (u64)(delta + DELTA_BIAS) | ((u64)kind << 62);
+        pl.s_out[q] = o_start; pl.s_lo[q] = (u32)e; pl.s_hi[q] = (u32)(e >> 32);
+        if (ANNOT) { pl.s_a[q] = id; pl.s_b[q] = vpos; }
+    };
+    if (ok && elig) {
+        int q = slot0;
+        if (e_ref) { put(q, K_REF, run_start, run_src - run_start, -1, -1); ++q; }
+        if (e_all) put(q, K_ALLELE, allele_out, a0 + a_skip - allele_out, vi, pos);
+        if ((b_snp >> j) & 1u) {
+            const int ps = __builtin_popcount(b_snp & ((1u << j) - 1u));
+            pl.p_out[ps] = allele_out; pl.p_val[ps] = inl & 0xFF;
+            if (ANNOT) pl.p_id[ps] = vi;
+        }
+    }
+    // last applied indel of the row -> start of the tail run
+    int ns_end = 0, ns_E = 0;
+    {
+        const int ln = seg_base + (b_ns ? 31 - __builtin_clz(b_ns) : 0);
+        ns_end = bperm(ln, allele_out + alen);
+        ns_E = bperm(ln, E);
+    }
+    const bool have_ns = b_ns != 0;
+    if (rem > 0) ref_idx_end = (int)imin((i64)ref_idx0 + rem, R);
+    const int t_start = have_ns ? ns_end : n_lead;
+    const i64 t_src = c_s + (have_ns ? ns_E : ((rem > 0 && !any_applied) ? ref_idx_end : ref_idx0));
+    int t_end = out_idx_end;
+    {
+        const int u = L - out_idx_end;
+        if (u > 0) {
+            const int w = (int)imin((i64)u, R - ref_idx_end);
+            if (w > 0) t_end = out_idx_end + w;
+        }
+    }
+    const bool tail_pad = t_end < L && L > lo_clip && t_end < hi_clip;
+    const bool tail_ref = t_end > t_start && t_end > lo_clip && t_start < hi_clip;
+    const int nseg = n_ent + (tail_ref ? 1 : 0) + (tail_pad ? 1 : 0);
+    if (ok && elig) {
+        if (j == 0) {
+            if (lead_kept) put(0, K_PAD_LEAD, 0, 0, -1, -1);
+            int q = n_ent;
+            if (tail_ref) { put(q, K_REF, t_start, t_src - t_start, -1, -1); ++q; }
+            if (tail_pad) put(q, K_PAD_TRAIL, t_end, 0, -1, -1);
+            meta[r].nseg = nseg; meta[r].npatch = npatch;
+        }
+        if (j >= nseg) pl.s_out[j] = 0x7FFFFFFF;       // sentinels for the 8-wide reads of P3b
+        if (j >= npatch) pl.p_out[j] = 0x7FFFFFFF;
+    }
+    if (j == 0 && elig) meta[r].bad = ok ? 0 : 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- P3b: lane = (row r, trip u = j) -------------------------------------------------
+    if (ok && elig) {
+        const int u = j;
+        const int limit = hi_clip;
+        const int p0 = lo_clip + u * TRIP;
+        TripDesc &D = desc[r];
+        int cls = 3, b1 = limit, b2 = limit, b3 = limit, idx = 0, pc0 = 0, pcn = 0;
+        u32 lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0, lo2 = 0, hi2 = 0, ldlo = 0, ldhi = 0;
+        if (p0 < limit) {
+            const int t_end2 = (limit - p0 > TRIP) ? p0 + TRIP : limit;
+            {
+                int so[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) so[t] = pl.s_out[t];
+#pragma unroll
+                for (int t = 1; t < 8; ++t) idx += (so[t] <= p0) ? 1 : 0;
+                for (int s2 = 8; s2 < nseg; ++s2) idx += (pl.s_out[s2] <= p0) ? 1 : 0;
+            }
+            auto at = [&](int i) { return i < SEG_CAP ? i : SEG_CAP - 1; };
+            b1 = idx + 1 < nseg ? pl.s_out[at(idx + 1)] : limit;
+            b2 = idx + 2 < nseg ? pl.s_out[at(idx + 2)] : limit;
+            b3 = idx + 3 < nseg ? pl.s_out[at(idx + 3)] : limit;
+            lo0 = pl.s_lo[at(idx)]; hi0 = pl.s_hi[at(idx)];
+            lo1 = pl.s_lo[at(idx + 1)]; hi1 = pl.s_hi[at(idx + 1)];
+            lo2 = pl.s_lo[at(idx + 2)]; hi2 = pl.s_hi[at(idx + 2)];
+            cls = b1 >= t_end2 ? 0 : (b2 >= t_end2 ? 1 : (b3 >= t_end2 ? 2 : 3));
+            auto in_bounds = [&](u32 lo, u32 hi, int s, int e) {
+                const u32 kind = hi >> 30;
+                if (kind != K_REF && kind != K_ALLELE) return true;
+                const i64 dl = seg_delta(lo, hi);
+                const i64 len = kind == K_REF ? A.ref_len : A.alt_len;
+                const int s3 = (s - 3 > p0 ? s - 3 : p0), e3 = (e + 3 < t_end2 ? e + 3 : t_end2);
+                return dl + s3 >= 0 && dl + e3 <= len;
+            };
+            bool okb = in_bounds(lo0, hi0, p0, b1 < t_end2 ? b1 : t_end2);
+            if (cls >= 1 && cls < 3) okb = okb && in_bounds(lo1, hi1, b1, b2 < t_end2 ? b2 : t_end2);
+            if (cls == 2) okb = okb && in_bounds(lo2, hi2, b2, t_end2);
+            if (!okb || ((t_end2 - p0) & 3) != 0 || (rflags & 4)) cls = 3;
+            if (cls == 0) {
+                const u32 kind = hi0 >> 30;
+                if (kind == K_REF || kind == K_ALLELE) {
+                    const u64 ad = (u64)(kind == K_REF ? A.ref : A.alt_alleles) + (u64)(seg_delta(lo0, hi0) + p0);
+                    ldlo = (u32)ad; ldhi = (u32)(ad >> 32);
+                } else {
+                    cls = 3;
+                }
+            }
+            {
+                int po[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) po[t] = pl.p_out[t];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    pc0 += (po[t] < p0) ? 1 : 0;
+                    pcn += (po[t] < t_end2) ? 1 : 0;
+                }
+            }
+        }
+        D.cls[u] = cls; D.b1[u] = b1; D.b2[u] = b2; D.pc0[u] = pc0; D.pcn[u] = pcn; D.idx[u] = idx;
+        D.ldlo[u] = ldlo; D.ldhi[u] = ldhi;
+        D.lo0[u] = lo0; D.hi0[u] = hi0; D.lo1[u] = lo1; D.hi1[u] = hi1; D.lo2[u] = lo2; D.hi2[u] = hi2;
+    }
+}
 
 #ifdef GVL_DIAG
 #define GVL_STAMP(i) do { if (A.stamps && tid == 0) A.stamps[((u64)blockIdx.x * gridDim.y + blockIdx.y) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -672,6 +958,8 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     __shared__ Stage<ANNOT> stage[WG_WAVES];
     __shared__ RowIn rin[WG_WAVES];
     __shared__ RowPlan<ANNOT> plan[WG_WAVES];
+    __shared__ TripDesc desc[WG_WAVES];
+    __shared__ RowMeta meta[WG_WAVES];
 
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
@@ -733,6 +1021,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
                     if (has_keep) ri.keep_off = A.keep_offsets[k];
                 }
                 if (ri.shift < 0 || ri.shift >= (1 << 30) || !planned_ok) fl |= 2;
+                else if (ri.n_var <= 8 && !(A.dbg & 512)) fl |= 8;      // planned by wave 0 with the other rows
             }
             ri.flags = fl;
         }
@@ -744,7 +1033,14 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     GVL_STAMP(2);
     const RowIn &ri = rin[wave];
     int flags = rfl(ri.flags);
-    if (flags & 1) return;
+    if (wave == 0) {
+        const u64 m_packed = __builtin_amdgcn_ballot_w64(lane < WG_WAVES && (rin[lane < WG_WAVES ? lane : 0].flags & 9) == 8);
+        if (m_packed) {
+            __builtin_amdgcn_s_setprio(3);      // seven waves wait for this one
+            packed_plan<ANNOT>(A, rin, plan, desc, meta, lane, lo_clip, has_keep);
+        }
+    }
+    const bool packed = (flags & 9) == 8;
     const i64 k = (i64)blockIdx.x * WG_WAVES + wave;
     RowPlan<ANNOT> &pl = plan[wave];
     Stage<ANNOT> &G = stage[wave];
@@ -753,7 +1049,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     const int hi_clip = (L - lo_clip > A.chunk_len) ? lo_clip + A.chunk_len : L;
     int nseg = 0, npatch = 0;
 
-    if (!(flags & 2)) {
+    if (!(flags & 3) && !packed) {
         // ---- P2 + P3, 64 variants per trip with carries between trips ------------------------
         const int n_var = rfl(ri.n_var);
         const i64 o_s = rfl64(ri.o_s);
@@ -974,6 +1270,12 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    __syncthreads();            // the packed plan of wave 0 is visible
+    if (flags & 1) return;
+    if (packed) {
+        if (rfl(meta[wave].bad)) flags |= 2;
+        nseg = rfl(meta[wave].nseg); npatch = rfl(meta[wave].npatch);
+    }
     GVL_STAMP(4);
 #ifdef GVL_DIAG
     if (A.stamps && lane == 0 && (flags & 2)) atomicAdd((unsigned long long *)&A.stamps[((u64)blockIdx.x * gridDim.y + blockIdx.y) * 16 + 9], 1ull);
@@ -993,7 +1295,15 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     int d_cls = 3, d_b1 = 0, d_b2 = 0, d_pc0 = 0, d_pcn = 0, d_idx = 0;
     u32 d_ldlo = 0, d_ldhi = 0;     // class 0: address of the trip's first source byte
     u32 d_lo0 = 0, d_hi0 = 0, d_lo1 = 0, d_hi1 = 0, d_lo2 = 0, d_hi2 = 0;
-    if (lane < CHUNK_TRIPS) {
+    if (packed) {
+        if (lane < CHUNK_TRIPS) {
+            const TripDesc &D = desc[wave];
+            d_cls = D.cls[lane]; d_b1 = D.b1[lane]; d_b2 = D.b2[lane]; d_pc0 = D.pc0[lane]; d_pcn = D.pcn[lane];
+            d_idx = D.idx[lane]; d_ldlo = D.ldlo[lane]; d_ldhi = D.ldhi[lane];
+            d_lo0 = D.lo0[lane]; d_hi0 = D.hi0[lane]; d_lo1 = D.lo1[lane]; d_hi1 = D.hi1[lane];
+            d_lo2 = D.lo2[lane]; d_hi2 = D.hi2[lane];
+        }
+    } else if (lane < CHUNK_TRIPS) {
         const int p0 = lo_clip + lane * TRIP;
         if (p0 < limit) {
             const int t_end = (limit - p0 > TRIP) ? p0 + TRIP : limit;
