@@ -665,7 +665,7 @@ struct TripDesc {
     u32 ldlo[CHUNK_TRIPS], ldhi[CHUNK_TRIPS];
     u32 lo0[CHUNK_TRIPS], hi0[CHUNK_TRIPS], lo1[CHUNK_TRIPS], hi1[CHUNK_TRIPS], lo2[CHUNK_TRIPS], hi2[CHUNK_TRIPS];
 };
-struct RowMeta { int nseg, npatch, bad, pad_; };
+struct RowMeta { int nseg, npatch, bad, slow, ready, pad0_, pad1_, pad2_; };
 
 // scans inside groups of 8 lanes (DPP row_shr 1/2/4, masked at the group boundary)
 template <typename Op>
@@ -700,7 +700,7 @@ __device__ __forceinline__ void packed_plan(const ReconArgs &A, const RowIn *rin
     const RowIn &ri = rin[r];
     RowPlan<ANNOT> &pl = plan[r];
     const int rflags = ri.flags;
-    const bool elig = (rflags & 8) != 0 && !(rflags & 1);
+    const bool elig = (rflags & 9) == 8 && meta[r].slow != 0;
     const int L = ri.L;
     const i64 c_s = ri.c_s, R = ri.R;
     const int hi_clip = (L - lo_clip > A.chunk_len) ? lo_clip + A.chunk_len : L;
@@ -943,6 +943,9 @@ __device__ __forceinline__ void packed_plan(const ReconArgs &A, const RowIn *rin
         D.ldlo[u] = ldlo; D.ldhi[u] = ldhi;
         D.lo0[u] = lo0; D.hi0[u] = hi0; D.lo1[u] = lo1; D.hi1[u] = hi1; D.lo2[u] = lo2; D.hi2[u] = hi2;
     }
+    // release the rows' own waves (they poll meta[r].ready)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (elig && j == 0) __hip_atomic_store(&meta[r].ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 #ifdef GVL_DIAG
@@ -1026,6 +1029,8 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             ri.flags = fl;
         }
         rin[tid] = ri;
+        RowMeta m0; m0.nseg = m0.npatch = m0.bad = m0.slow = m0.ready = m0.pad0_ = m0.pad1_ = m0.pad2_ = 0;
+        meta[tid] = m0;
     }
     GVL_STAMP(1);
     __syncthreads();
@@ -1033,14 +1038,6 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     GVL_STAMP(2);
     const RowIn &ri = rin[wave];
     int flags = rfl(ri.flags);
-    if (wave == 0) {
-        const u64 m_packed = __builtin_amdgcn_ballot_w64(lane < WG_WAVES && (rin[lane < WG_WAVES ? lane : 0].flags & 9) == 8);
-        if (m_packed) {
-            __builtin_amdgcn_s_setprio(3);      // seven waves wait for this one
-            packed_plan<ANNOT>(A, rin, plan, desc, meta, lane, lo_clip, has_keep);
-        }
-    }
-    const bool packed = (flags & 9) == 8;
     const i64 k = (i64)blockIdx.x * WG_WAVES + wave;
     RowPlan<ANNOT> &pl = plan[wave];
     Stage<ANNOT> &G = stage[wave];
@@ -1049,7 +1046,115 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     const int hi_clip = (L - lo_clip > A.chunk_len) ? lo_clip + A.chunk_len : L;
     int nseg = 0, npatch = 0;
 
-    if (!(flags & 3) && !packed) {
+    // ---- who plans this row ---------------------------------------------------------------
+    //  * rows with at most 8 variants ("packable", flags & 8) read their records here, lane j =
+    //    variant j.  If every kept variant is a SNP inside the contig and no two share a position
+    //    the row is FAST: no scan is needed, its own wave plans it below and starts streaming
+    //    while the others are still planning.
+    //  * the other packable rows are SLOW: the first slow wave plans all of them at once
+    //    (packed_plan), the other slow waves wait for their flag.
+    //  * rows with more than 8 variants run the per-wave scans (P2 + P3 further down).
+    const bool packable = (flags & 11) == 8;
+    int f_pos = 0, f_inl = 0, f_vi = 0;
+    bool f_valid = false, is_fast = false;
+    if (packable) {
+        const int n_var = rfl(ri.n_var);
+        const i64 o_s = rfl64(ri.o_s);
+        int d = 0, alen = 0;
+        f_valid = lane < n_var;
+        if (f_valid) {
+            if (A.grec) {
+                const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.grec + (o_s + lane));
+                f_pos = rec.x; d = rec.y; alen = (int)((u32)rec.z >> 8); f_inl = rec.z & 0xFF; f_vi = rec.w;
+            } else {
+                int v = A.geno_v_idxs[o_s + lane];
+                v = v < 0 ? 0 : ((i64)v >= A.n_variants ? (int)(A.n_variants - 1) : v);
+                const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.vrec + v);
+                f_pos = rec.x; d = rec.y; alen = rec.z; f_inl = rec.w & 0xFF; f_vi = v;
+            }
+            if (has_keep) f_valid = A.keep[rfl64(ri.keep_off) + lane] != 0;
+        }
+        const i64 rs = rfl64(ri.ref_start);
+        const int pos_prev = dpp_mov<0x138, 0xf>(-1, f_pos);               // wave_shr:1
+        const u64 m_slow = __builtin_amdgcn_ballot_w64(
+            (f_valid && (d != 0 || alen != 1 || f_pos < 0 || (i64)f_pos + 1 > rfl64(ri.R))) ||
+            (lane > 0 && lane < n_var && f_pos == pos_prev));
+        is_fast = m_slow == 0 && rs > -(1 << 30) && rs < (1 << 30) && !(A.dbg & 32);
+        if (!is_fast && lane == 0) meta[wave].slow = 1;
+    }
+    __syncthreads();            // every row knows who plans it
+    const bool slow_row = packable && !is_fast;
+    if (slow_row) {
+        const u64 m_slow_rows = __builtin_amdgcn_ballot_w64(lane < WG_WAVES && meta[lane < WG_WAVES ? lane : 0].slow != 0);
+        if (wave == __builtin_ctzll(m_slow_rows)) {
+            __builtin_amdgcn_s_setprio(3);      // the other slow rows wait for this wave
+            packed_plan<ANNOT>(A, rin, plan, desc, meta, lane, lo_clip, has_keep);
+        } else {
+            while (__hip_atomic_load(&meta[wave].ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
+                __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    const bool packed = slow_row;
+    const bool fast_row = packable && is_fast;
+    int fp_n_lead = 0, fp_t_end = 0, fp_lead_kept = 0; bool fp_ref = false, fp_pad = false; i64 fp_delta = 0;
+
+    if (fast_row) {
+        // ---- fast plan: ONE reference run from the shifted origin r0 + SNP patches.  With SNPs only,
+        // whichever way the shift completes (:115-146) or runs out (:200-205), ref_idx lands on
+        // ref_idx0 + shift; SNP i sits at n_lead + (pos_i - r0) iff pos_i >= r0 and that is
+        // inside the row (:154-158).
+        const int ref_start = (int)rfl64(ri.ref_start);
+        const i64 R = rfl64(ri.R);
+        const int shift_i = (int)rfl64(ri.shift);
+        const int raw = ref_start < 0 ? -ref_start : 0;
+        const int shifted0 = shift_i < raw ? shift_i : raw;
+        const int n_lead = (raw - shifted0 < L) ? raw - shifted0 : L;
+        const int r0 = (int)imin((i64)(ref_start < 0 ? 0 : ref_start) + (shift_i - shifted0), R);
+        const int ao = n_lead + (f_pos - r0);
+        const bool app = f_valid && f_pos >= r0 && (f_pos - r0) < (L - n_lead);
+        const u64 m_p = __builtin_amdgcn_ballot_w64(app && ao >= lo_clip && ao < hi_clip);
+        if ((m_p >> lane) & 1ull) {
+            const int ps = __builtin_popcountll(m_p & ((1ull << lane) - 1ull));
+            pl.p_out[ps] = ao; pl.p_val[ps] = f_inl;
+            if (ANNOT) pl.p_id[ps] = f_vi;
+        }
+        npatch = __builtin_popcountll(m_p);
+        const int lead_kept = (n_lead > 0 && n_lead > lo_clip && 0 < hi_clip) ? 1 : 0;
+        int t_end = n_lead;
+        {
+            const int u = L - n_lead;
+            if (u > 0) {
+                const int w = (int)imin((i64)u, R - r0);
+                if (w > 0) t_end = n_lead + w;
+            }
+        }
+        const bool tail_pad = t_end < L && L > lo_clip && t_end < hi_clip;
+        const bool tail_ref = t_end > n_lead && t_end > lo_clip && n_lead < hi_clip;
+        nseg = lead_kept + (tail_ref ? 1 : 0) + (tail_pad ? 1 : 0);
+        fp_n_lead = n_lead; fp_t_end = t_end; fp_lead_kept = lead_kept; fp_ref = tail_ref; fp_pad = tail_pad;
+        fp_delta = c_s + r0 - n_lead;
+        if (lane == 0) {
+            auto put1 = [&](int q, u32 kind, int o_start, i64 delta) {
+                const u64 e = (u64)(delta + DELTA_BIAS) | ((u64)kind << 62);
+                pl.s_out[q] = o_start; pl.s_lo[q] = (u32)e; pl.s_hi[q] = (u32)(e >> 32);
+                if (ANNOT) { pl.s_a[q] = -1; pl.s_b[q] = -1; }
+            };
+            int q = 0;
+            if (lead_kept) { put1(q, K_PAD_LEAD, 0, 0); ++q; }
+            if (tail_ref) { put1(q, K_REF, n_lead, c_s + r0 - n_lead); ++q; }
+            if (tail_pad) put1(q, K_PAD_TRAIL, t_end, 0);
+        }
+        if (lane < 8) {
+            if (lane >= nseg) pl.s_out[lane] = 0x7FFFFFFF;
+            if (lane >= npatch) pl.p_out[lane] = 0x7FFFFFFF;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    if (!(flags & 3) && !packable) {
         // ---- P2 + P3, 64 variants per trip with carries between trips ------------------------
         const int n_var = rfl(ri.n_var);
         const i64 o_s = rfl64(ri.o_s);
@@ -1270,7 +1375,6 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __syncthreads();            // the packed plan of wave 0 is visible
     if (flags & 1) return;
     if (packed) {
         if (rfl(meta[wave].bad)) flags |= 2;
@@ -1302,6 +1406,39 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             d_idx = D.idx[lane]; d_ldlo = D.ldlo[lane]; d_ldhi = D.ldhi[lane];
             d_lo0 = D.lo0[lane]; d_hi0 = D.hi0[lane]; d_lo1 = D.lo1[lane]; d_hi1 = D.hi1[lane];
             d_lo2 = D.lo2[lane]; d_hi2 = D.hi2[lane];
+        }
+    } else if (fast_row) {
+        // one reference run (+ pads at a contig edge): a trip inside the run is class 0 with a known
+        // address, any other trip is general
+        if (lane < CHUNK_TRIPS) {
+            const int p0 = lo_clip + lane * TRIP;
+            if (p0 < limit) {
+                const int t_end = (limit - p0 > TRIP) ? p0 + TRIP : limit;
+                d_idx = fp_lead_kept + ((fp_ref && fp_n_lead <= p0) ? 1 : 0) + ((fp_pad && fp_t_end <= p0) ? 1 : 0) - 1;
+                if (d_idx < 0) d_idx = 0;
+                d_b1 = limit; d_b2 = limit;
+                const bool inside = fp_ref && p0 >= fp_n_lead && t_end <= fp_t_end && fp_delta + p0 >= 0 &&
+                                    fp_delta + t_end <= A.ref_len && ((t_end - p0) & 3) == 0 && !ref_zero_fill;
+                if (inside) {
+                    d_cls = 0;
+                    const u64 ad = (u64)A.ref + (u64)(fp_delta + p0);
+                    d_ldlo = (u32)ad; d_ldhi = (u32)(ad >> 32);
+                    if (ANNOT) {
+                        const u64 e = (u64)(fp_delta + DELTA_BIAS) | ((u64)K_REF << 62);
+                        d_lo0 = (u32)e; d_hi0 = (u32)(e >> 32);
+                    }
+                }
+                if (npatch > 0) {
+                    int po[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) po[j] = pl.p_out[j];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        d_pc0 += (po[j] < p0) ? 1 : 0;
+                        d_pcn += (po[j] < t_end) ? 1 : 0;
+                    }
+                }
+            }
         }
     } else if (lane < CHUNK_TRIPS) {
         const int p0 = lo_clip + lane * TRIP;

@@ -387,3 +387,76 @@ def test_shift_stress_scan_path(gpu, oracle, seed):
     idx = bt.geno_offset_idx.ravel()
     assert (bt.geno_offsets[1, idx] - bt.geno_offsets[0, idx]).max() <= 64
     check_batch(gpu, oracle, st, bt, annotate=True)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_snp_only_rows_fast_plan(gpu, oracle, seed):
+    """Rows whose kept variants are all SNPs take the scan-free plan: duplicate positions (first
+    ALT wins -> those rows must fall back), shifts that end before / on / after a SNP or run past
+    the contig end, windows hanging over both contig edges, keep masks that remove the only indel
+    of a row, 0..8 and more than 8 variants per row, ragged and fixed length, annotations."""
+    rng = np.random.default_rng(1000 + seed)
+    contig = 6000
+    ref = rng.choice(np.frombuffer(b"ACGTN", np.uint8), contig, p=[0.24, 0.24, 0.24, 0.24, 0.04]).astype(np.uint8)
+    ref_offsets = np.array([0, contig], np.int64)
+    # variant table: SNPs every ~9 bp with runs of duplicates, a few indels
+    pos = np.sort(rng.integers(0, contig, 700)).astype(np.int32)
+    dup = rng.random(pos.size) < 0.12
+    pos[1:][dup[1:]] = pos[:-1][dup[1:]]                      # duplicates of the previous position
+    pos = np.sort(pos)
+    ilens = np.zeros(pos.size, np.int32)
+    is_indel = rng.random(pos.size) < 0.06
+    ilens[is_indel] = rng.integers(-4, 5, int(is_indel.sum()))
+    alts, offs = [], [0]
+    for p_, il in zip(pos, ilens):
+        n = max(1, 1 + int(il))
+        alts.append(rng.choice(np.frombuffer(b"ACGT", np.uint8), n))
+        offs.append(offs[-1] + n)
+    alt_alleles = np.concatenate(alts).astype(np.uint8)
+    alt_offsets = np.asarray(offs, np.int64)
+    B, P, L = 40, 2, 333
+    starts = rng.integers(-150, contig - 100, B).astype(np.int32)
+    regions = np.stack([np.zeros(B, np.int32), starts, starts + L + 40, np.where(rng.random(B) < 0.5, 1, -1).astype(np.int32)], 1)
+    lists, keeps = [], []
+    for b in range(B):
+        lo, hi = np.searchsorted(pos, starts[b] - 20), np.searchsorted(pos, starts[b] + L + 60)
+        cand = np.arange(lo, hi)
+        for p_ in range(P):
+            m = rng.random(cand.size) < rng.choice([0.05, 0.15, 0.4])
+            sel = cand[m].astype(np.int32)
+            lists.append(sel)
+            kp = np.ones(sel.size, bool)
+            indel = ilens[sel] != 0
+            if indel.any() and rng.random() < 0.5:
+                kp[indel] = False                              # the mask leaves a SNP-only row
+            kp[rng.random(sel.size) < 0.1] = False
+            keeps.append(kp)
+    lens = np.array([len(x) for x in lists])
+    go = np.stack([np.concatenate([[0], np.cumsum(lens)[:-1]]), np.cumsum(lens)]).astype(np.int64)
+    gv = np.concatenate(lists).astype(np.int32) if lens.sum() else np.zeros(0, np.int32)
+    keep = np.concatenate(keeps) if lens.sum() else np.zeros(0, bool)
+    keep_offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    goi = np.arange(B * P, dtype=np.int64).reshape(B, P)
+    shifts = rng.integers(0, 25, (B, P)).astype(np.int32)
+    shifts[rng.random((B, P)) < 0.3] = 0
+    shifts[0, 0] = 5000                                        # runs past the contig end
+    to_rc = np.repeat(regions[:, 3] == -1, P)
+    assert (lens > 8).any() and (lens == 0).any()
+    for use_keep in (False, True):
+        for out_len in (L, -1):
+            kw = dict(keep=keep if use_keep else None, keep_offsets=keep_offsets if use_keep else None)
+            exp, exp_off, exp_oh = oracle.reconstruct_haplotypes_fused(
+                regions, shifts, goi, go, gv, pos, ilens, alt_alleles, alt_offsets, ref, ref_offsets, ord("N"),
+                out_len, kw["keep"], kw["keep_offsets"], to_rc, False, onehot=True)
+            dev = gpu.device.HapsDevice(ref=ref, ref_offsets=ref_offsets, v_starts=pos, ilens=ilens, alt_alleles=alt_alleles,
+                                 alt_offsets=alt_offsets, geno_offsets=go, geno_v_idxs=gv, pad_char=ord("N"))
+            out = dev.reconstruct(regions, shifts, goi, out_len, kw["keep"], kw["keep_offsets"], to_rc, haps=True,
+                                  onehot=True, annotate=True)
+            np.testing.assert_array_equal(out.out_offsets.cpu().numpy(), exp_off)
+            np.testing.assert_array_equal(out.haps.cpu().numpy(), exp)
+            np.testing.assert_array_equal(out.onehot.cpu().numpy(), exp_oh)
+            _, av, ap, _ = oracle.reconstruct_annotated_haplotypes_fused(
+                regions, shifts, goi, go, gv, pos, ilens, alt_alleles, alt_offsets, ref, ref_offsets, ord("N"),
+                out_len, kw["keep"], kw["keep_offsets"], to_rc, False)
+            np.testing.assert_array_equal(out.annot_v_idxs.cpu().numpy(), av)
+            np.testing.assert_array_equal(out.annot_ref_pos.cpu().numpy(), ap)
