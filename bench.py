@@ -93,7 +93,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--slots", type=int, default=2, help="output ring slots")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=4,
                     help="batches kept in flight (one HIP stream each) in the timed region")
     args = ap.parse_args()
 

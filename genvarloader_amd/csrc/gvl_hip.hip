@@ -1082,7 +1082,10 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         is_fast = m_slow == 0 && rs > -(1 << 30) && rs < (1 << 30) && !(A.dbg & 32);
         if (!is_fast && lane == 0) meta[wave].slow = 1;
     }
-    __syncthreads();            // every row knows who plans it
+    // (uniform over the workgroup: without a packable row nobody waits for anybody)
+    const bool any_packable =
+        __builtin_amdgcn_ballot_w64(lane < WG_WAVES && (rin[lane < WG_WAVES ? lane : 0].flags & 11) == 8) != 0;
+    if (any_packable) __syncthreads();            // every row knows who plans it
     const bool slow_row = packable && !is_fast;
     if (slow_row) {
         const u64 m_slow_rows = __builtin_amdgcn_ballot_w64(lane < WG_WAVES && meta[lane < WG_WAVES ? lane : 0].slow != 0);
