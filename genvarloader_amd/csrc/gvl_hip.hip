@@ -2569,33 +2569,45 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = rfl((int)(threadIdx.x >> 6));
     PaintTile &T = tiles[wave];
+    __shared__ int probe_s[WAVE], probe_p[WAVE];
     const i64 q = blockIdx.y;
     const i64 chunk = (i64)blockIdx.x * 4 + wave;
-    if (chunk >= n_chunks) return;
     const i64 o0 = rfl64(out_offsets[q]);
     const i64 length = rfl64(out_offsets[q + 1]) - o0;
-    const i64 j0 = chunk * chunk_len;
-    if (j0 >= length) { if (lane == 0) chunk_todo[q * n_chunks + chunk] = 0; return; }
-    const i64 j1 = (length - j0 > chunk_len) ? j0 + chunk_len : length;
     const i64 idx = rfl64(offset_idxs[q]);
     const i64 s0 = rfl64(itv_offsets[idx]), e0 = rfl64(itv_offsets[idx + 1]);
     const i64 qs = rfl(starts[q * starts_stride]);
+    // the first round of both searches probes the same 64 strided entries of the query's list for
+    // every chunk: wave 0 fetches them once for the block's 4 chunks
+    if (wave == 0 && e0 > s0) {
+        const i64 st = (e0 - s0 + WAVE - 1) / WAVE;
+        i64 pp = s0 + (i64)(lane + 1) * st - 1;
+        if (pp > e0 - 1) pp = e0 - 1;
+        probe_s[lane] = itv_starts[pp];
+        probe_p[lane] = pmax[pp];
+    }
+    __syncthreads();
+    if (chunk >= n_chunks) return;
+    const i64 j0 = chunk * chunk_len;
+    if (j0 >= length) { if (lane == 0) chunk_todo[q * n_chunks + chunk] = 0; return; }
+    const i64 j1 = (length - j0 > chunk_len) ? j0 + chunk_len : length;
     // first start - qs >= j1 and first pmax - qs > j0: both searches advance together so that
     // their probe loads overlap (2 dependent rounds for lists of thousands instead of 4)
     i64 hi_c, lo_c;
     {
         i64 a1 = s0, b1 = e0, a2 = s0, b2 = e0;
         bool d1 = false, d2 = false;
+        bool first = true;
         while (!(d1 && d2)) {
             i64 p1 = 0, p2 = 0, st1 = 1, st2 = 1;
             int k1 = 0, k2 = 0;
             if (!d1) {
                 if (a1 >= b1) d1 = true;
-                else { st1 = (b1 - a1 + WAVE - 1) / WAVE; p1 = a1 + (i64)(lane + 1) * st1 - 1; if (p1 > b1 - 1) p1 = b1 - 1; k1 = itv_starts[p1]; }
+                else { st1 = (b1 - a1 + WAVE - 1) / WAVE; p1 = a1 + (i64)(lane + 1) * st1 - 1; if (p1 > b1 - 1) p1 = b1 - 1; k1 = first ? probe_s[lane] : itv_starts[p1]; }
             }
             if (!d2) {
                 if (a2 >= b2) d2 = true;
-                else { st2 = (b2 - a2 + WAVE - 1) / WAVE; p2 = a2 + (i64)(lane + 1) * st2 - 1; if (p2 > b2 - 1) p2 = b2 - 1; k2 = pmax[p2]; }
+                else { st2 = (b2 - a2 + WAVE - 1) / WAVE; p2 = a2 + (i64)(lane + 1) * st2 - 1; if (p2 > b2 - 1) p2 = b2 - 1; k2 = first ? probe_p[lane] : pmax[p2]; }
             }
             if (!d1) {
                 const u64 m = __builtin_amdgcn_ballot_w64((i64)k1 - qs > j1 - 1);
@@ -2617,6 +2629,7 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
                     else { if (f > 0) a2 += (i64)f * st2; b2 = pf; if (a2 >= b2) d2 = true; }
                 }
             }
+            first = false;
         }
         hi_c = b1; lo_c = b2 < hi_c ? b2 : hi_c;
     }
