@@ -1082,6 +1082,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         is_fast = m_slow == 0 && rs > -(1 << 30) && rs < (1 << 30) && !(A.dbg & 32);
         if (!is_fast && lane == 0) meta[wave].slow = 1;
     }
+    GVL_STAMP(3);
     // (uniform over the workgroup: without a packable row nobody waits for anybody)
     const bool any_packable =
         __builtin_amdgcn_ballot_w64(lane < WG_WAVES && (rin[lane < WG_WAVES ? lane : 0].flags & 11) == 8) != 0;
@@ -1338,7 +1339,6 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             n_ent += add_ent;
             npatch += add_pat;
         }
-        GVL_STAMP(3);
         if (ok) {
             // the run after the last applied indel (through any SNPs), then -- if the walk ran to
             // its end -- the rest of the contig and the right pad (:200-255)
