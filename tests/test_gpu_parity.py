@@ -460,3 +460,60 @@ def test_snp_only_rows_fast_plan(gpu, oracle, seed):
                 out_len, kw["keep"], kw["keep_offsets"], to_rc, False)
             np.testing.assert_array_equal(out.annot_v_idxs.cpu().numpy(), av)
             np.testing.assert_array_equal(out.annot_ref_pos.cpu().numpy(), ap)
+
+
+def test_coordinates_beyond_2_30_fall_back_to_the_scalar_walk(gpu, oracle):
+    """The scan planners work in i32 with 2^30 head-room; a contig longer than 2^30 bp (and a shift
+    of 2^30) must be detected per row and replayed by the i64 scalar walk -- in the same
+    workgroups as ordinary rows (small coordinates on a second contig)."""
+    rng = np.random.default_rng(5)
+    big = (1 << 30) + 6000
+    block = rng.choice(np.frombuffer(b"ACGT", np.uint8), 1 << 20).astype(np.uint8)
+    ref = np.concatenate([np.tile(block, big // block.size + 1)[:big], block[:50_000]])
+    ref_offsets = np.array([0, big, big + 50_000], np.int64)
+    # variants at the far end of contig 0 and at the start of contig 1 (positions are per contig)
+    far = np.sort(rng.integers((1 << 30) - 2000, (1 << 30) + 5500, 260)).astype(np.int32)
+    near = np.sort(rng.integers(100, 40_000, 260)).astype(np.int32)
+    pos = np.concatenate([near, far])             # the table is per dataset; rows pick by index
+    order = np.argsort(pos, kind="stable")
+    pos = pos[order]
+    ilens = rng.choice([0, 0, 0, 1, -2, 3, -5], pos.size).astype(np.int32)
+    alts, offs = [], [0]
+    for il in ilens:
+        n = max(1, 1 + int(il))
+        alts.append(rng.choice(np.frombuffer(b"ACGT", np.uint8), n)); offs.append(offs[-1] + n)
+    alt_alleles = np.concatenate(alts).astype(np.uint8); alt_offsets = np.asarray(offs, np.int64)
+    B, P, L = 24, 2, 700
+    contig = (np.arange(B) % 2).astype(np.int32)                      # alternate big / small contig
+    starts = np.where(contig == 0, rng.integers((1 << 30) - 1500, (1 << 30) + 5200, B), rng.integers(0, 39_000, B)).astype(np.int32)
+    regions = np.stack([contig, starts, starts + L + 30, np.where(rng.random(B) < 0.5, 1, -1).astype(np.int32)], 1)
+    lists = []
+    for b in range(B):
+        lo, hi = np.searchsorted(pos, starts[b] - 10), np.searchsorted(pos, starts[b] + L + 40)
+        cand = np.arange(lo, hi)
+        for _ in range(P):
+            lists.append(cand[rng.random(cand.size) < 0.3].astype(np.int32))
+    lens = np.array([len(x) for x in lists])
+    go = np.stack([np.concatenate([[0], np.cumsum(lens)[:-1]]), np.cumsum(lens)]).astype(np.int64)
+    gv = np.concatenate(lists).astype(np.int32)
+    goi = np.arange(B * P, dtype=np.int64).reshape(B, P)
+    shifts = rng.integers(0, 12, (B, P)).astype(np.int32)
+    shifts[3, 1] = 1 << 30
+    to_rc = np.repeat(regions[:, 3] == -1, P)
+    dev = gpu.device.HapsDevice(ref=ref, ref_offsets=ref_offsets, v_starts=pos, ilens=ilens, alt_alleles=alt_alleles,
+                                alt_offsets=alt_offsets, geno_offsets=go, geno_v_idxs=gv, pad_char=ord("N"))
+    for out_len in (L, -1):
+        exp, exp_off, exp_oh = oracle.reconstruct_haplotypes_fused(
+            regions, shifts, goi, go, gv, pos, ilens, alt_alleles, alt_offsets, ref, ref_offsets, ord("N"), out_len,
+            None, None, to_rc, False, onehot=True)
+        out = dev.reconstruct(regions, shifts, goi, out_len, None, None, to_rc, haps=True, onehot=True, annotate=True)
+        np.testing.assert_array_equal(out.out_offsets.cpu().numpy(), exp_off)
+        np.testing.assert_array_equal(out.haps.cpu().numpy(), exp)
+        np.testing.assert_array_equal(out.onehot.cpu().numpy(), exp_oh)
+        _, av, ap, _ = oracle.reconstruct_annotated_haplotypes_fused(
+            regions, shifts, goi, go, gv, pos, ilens, alt_alleles, alt_offsets, ref, ref_offsets, ord("N"), out_len,
+            None, None, to_rc, False)
+        np.testing.assert_array_equal(out.annot_v_idxs.cpu().numpy(), av)
+        np.testing.assert_array_equal(out.annot_ref_pos.cpu().numpy(), ap)
+    del dev
+    gpu.torch.cuda.empty_cache()

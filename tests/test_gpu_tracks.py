@@ -208,3 +208,31 @@ def test_painting_dense_nested_and_gappy_intervals(ffi, oracle):
     got2 = device.intervals_to_tracks(oi, qs, its, ite, itv, ito, oo, itv_pmax_ends=pm).cpu().numpy()
     np.testing.assert_array_equal(bits(got2), bits(exp))
     torch.cuda.synchronize()
+
+
+def test_tracks_coordinates_beyond_2_30(ffi, oracle):
+    """Same batch twice: as generated, and with every genomic coordinate moved up by 2^30 + 12345
+    (regions, variant positions, interval starts / ends).  Tracks are relative to the query
+    start, so both must give the same output -- and the shifted one must give it through the
+    i64 scalar walk (the scan planner only takes |coordinates| < 2^30)."""
+    st, bt, itv = _track_batch(91, 12, 1500, 120_000, shifts=True)
+    B, P = bt.geno_offset_idx.shape
+    L = bt.output_length
+    tlen = (bt.regions[:, 2] - bt.regions[:, 1]) + 40
+    track_offsets = np.concatenate([[0], np.cumsum(tlen)]).astype(np.int64)
+    out_offsets = np.arange(B * P + 1, dtype=np.int64) * L
+    outs = []
+    for off in (0, (1 << 30) + 12345):
+        regions = bt.regions.copy(); regions[:, 1:3] += off
+        args = (out_offsets, regions, bt.shifts, bt.geno_offset_idx, bt.geno_v_idxs, bt.geno_offsets,
+                (st.v_starts.astype(np.int64) + off).astype(np.int32), st.ilens, itv["offset_idxs"],
+                (itv["itv_starts"].astype(np.int64) + off).astype(np.int32),
+                (itv["itv_ends"].astype(np.int64) + off).astype(np.int32), itv["itv_values"], itv["itv_offsets"],
+                track_offsets, np.array([2.0]), 4, 7, None, None, bt.to_rc)
+        exp = np.zeros(B * P * L, np.float32)
+        oracle.intervals_and_realign_track_fused(exp, *args)
+        got = np.full(B * P * L, 9.0, np.float32)
+        ffi.intervals_and_realign_track_fused(got, *args)
+        np.testing.assert_array_equal(bits(got), bits(exp))
+        outs.append(got)
+    np.testing.assert_array_equal(bits(outs[0]), bits(outs[1]))

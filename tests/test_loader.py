@@ -210,3 +210,64 @@ def test_loader_rank_shares_are_disjoint_and_cover():
         seen.append(ids)
     both = np.concatenate(seen)
     assert set(both.tolist()) == set(range(R * S)) and len(both) == R * S + (R * S) % 2
+
+
+@pytest.mark.gpu
+def test_cfg5_epoch_full_size_properties_and_sampled_parity(oracle):
+    """BASELINE configs[4]: a 1.0 M-window epoch (200 regions x 2504 samples x 2 haplotypes,
+    2048 bp, one-hot) through the native loader in batches of 4096 windows.  Size-independent
+    properties over the whole epoch (every dataset index exactly once; every one-hot row has at
+    most one channel set and the count of all-zero rows equals the count of N / pad bases; a
+    checksum of per-batch checksums equal to the same sum taken in index order) and bit-exact
+    parity with the oracle on sampled batches."""
+    from genvarloader_amd import HapsDevice
+    from genvarloader_amd.loader import DeviceHapsDataset
+
+    R, S, P, L, bs = 200, 2504, 2, 2048, 2048
+    rng = np.random.default_rng(20260802 + 5)
+    st = synth.make_static(rng, (64 << 20,), indel_frac=0.15)
+    full_regions, go, gv = synth.make_grid(rng, st, R, S, P, L)
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+    ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, onehot=True, haps=True)
+    w = torch.arange(1, 5, dtype=torch.int64, device="cuda")              # channel weights of the checksum
+
+    def epoch(shuffle, sample_at):
+        seen = torch.zeros(R * S, dtype=torch.int32, device="cuda")
+        total = torch.zeros((), dtype=torch.int64, device="cuda")
+        zero_rows = torch.zeros((), dtype=torch.int64, device="cuda")
+        non_acgt = torch.zeros((), dtype=torch.int64, device="cuda")
+        samples = []
+        for bi, batch in enumerate(ds.to_dataloader(batch_size=bs, shuffle=shuffle, seed=3, in_flight=3)):
+            seen.index_add_(0, batch.idx, torch.ones_like(batch.idx, dtype=torch.int32))
+            oh = batch.onehot
+            rs = oh.sum(-1, dtype=torch.int32)
+            assert int(rs.max()) <= 1
+            zero_rows += (rs == 0).sum()
+            hp = batch.haps
+            non_acgt += ((hp != 65) & (hp != 67) & (hp != 71) & (hp != 84)).sum()
+            # per-batch checksum weighted by the dataset index so that order does not matter
+            per_q = (oh.to(torch.int64) * w).sum(dim=(1, 2, 3))
+            total += (per_q * (batch.idx + 1)).sum()
+            if bi in sample_at:
+                samples.append((batch.idx.cpu().numpy(), hp.cpu().numpy().copy(), oh.cpu().numpy().copy()))
+        torch.cuda.synchronize()
+        assert int(seen.min()) == 1 and int(seen.max()) == 1
+        assert int(zero_rows) == int(non_acgt)
+        return int(total), samples
+
+    t_shuffled, samples = epoch(True, {0, 97, 244})
+    t_ordered, _ = epoch(False, set())
+    assert t_shuffled == t_ordered
+    assert len(samples) == 3
+    for idx, hp, oh in samples:
+        r_idx, s_idx = np.unravel_index(idx, (R, S))
+        regions = full_regions[r_idx]
+        goi = np.ravel_multi_index((r_idx[:, None], s_idx[:, None], np.arange(P)), (R, S, P))
+        to_rc = np.repeat(regions[:, 3] == -1, P)
+        exp, _, exp_oh = oracle.reconstruct_haplotypes_fused(
+            regions, np.zeros_like(goi, dtype=np.int32), goi, go, gv, st.v_starts, st.ilens, st.alt_alleles,
+            st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, L, None, None, to_rc, False, onehot=True, n_threads=8)
+        np.testing.assert_array_equal(hp.ravel(), exp)
+        np.testing.assert_array_equal(oh.reshape(-1, 4), exp_oh)
