@@ -87,7 +87,8 @@ def _static(geno_offsets, geno_v_idxs, v_starts, ilens, alt_alleles, alt_offsets
 
 
 def clear_static_cache() -> None:
-    _STATIC_CACHE.clear()
+    for c in (_STATIC_CACHE, _DIFF_CACHE, _REF_CACHE, _TRACK_CACHE, _ITV_CACHE):
+        c.clear()
 
 
 def _np(t):
@@ -266,11 +267,37 @@ def _track_static(geno_offsets, geno_v_idxs, v_starts, ilens) -> HapsDevice:
     return dev
 
 
+_ITV_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()
+
+
+def _itv_static(itv_starts, itv_ends, itv_values, itv_offsets, device="cuda"):
+    """The interval arrays are per dataset (the reference memmaps them): upload once, with the
+    running maxima of the ends (gvl_intervals_prefix_max), keyed by the host buffers."""
+    arrs = tuple(np.asarray(a) for a in (itv_starts, itv_ends, itv_values, itv_offsets))
+    key = tuple(_key(a) for a in arrs) + (str(device),)
+    ent = _ITV_CACHE.get(key)
+    if ent is None:
+        d = torch.device(device)
+        a = torch.from_numpy(_req(arrs[0], np.int32, "itv_starts", 1)).to(d)
+        b = torch.from_numpy(_req(arrs[1], np.int32, "itv_ends", 1)).to(d)
+        v = torch.from_numpy(_req(arrs[2], np.float32, "itv_values", 1)).to(d)
+        io = torch.from_numpy(_req(arrs[3], np.int64, "itv_offsets", 1)).to(d)
+        pm = _device.intervals_prefix_max(b, io, device) if b.numel() else None
+        ent = (a, b, v, io, pm, arrs)           # arrs: keep the host buffers alive (address key)
+        _ITV_CACHE[key] = ent
+        while len(_ITV_CACHE) > _STATIC_CACHE_MAX:
+            _ITV_CACHE.popitem(last=False)
+    else:
+        _ITV_CACHE.move_to_end(key)
+    return ent[:5]
+
+
 def intervals_to_tracks(offset_idxs, starts, itv_starts, itv_ends, itv_values, itv_offsets, out, out_offsets,
                         parallel=False):
     """In place: paints `out` (src/ffi/mod.rs:188-240)."""
-    res = _device.intervals_to_tracks(offset_idxs, starts, itv_starts, itv_ends, itv_values, itv_offsets,
-                                      _req(out_offsets, np.int64, "out_offsets", 1))
+    a, b, v, io, pm = _itv_static(itv_starts, itv_ends, itv_values, itv_offsets)
+    res = _device.intervals_to_tracks(offset_idxs, starts, a, b, v, io, _req(out_offsets, np.int64, "out_offsets", 1),
+                                      itv_pmax_ends=pm)
     out[...] = _np(res)
 
 
@@ -292,8 +319,9 @@ def intervals_and_realign_track_fused(out, out_offsets, regions, shifts, geno_of
     The scratch track never leaves the device."""
     dev = _track_static(geno_offsets, geno_v_idxs, v_starts, ilens)
     regions = _req(regions, np.int32, "regions", 2)
-    scratch = _device.intervals_to_tracks(offset_idxs, np.ascontiguousarray(regions[:, 1]), itv_starts, itv_ends,
-                                          itv_values, itv_offsets, _req(track_offsets, np.int64, "track_offsets", 1))
+    a, b, v, io, pm = _itv_static(itv_starts, itv_ends, itv_values, itv_offsets)
+    scratch = _device.intervals_to_tracks(offset_idxs, np.ascontiguousarray(regions[:, 1]), a, b, v, io,
+                                          _req(track_offsets, np.int64, "track_offsets", 1), itv_pmax_ends=pm)
     res = _device.realign_tracks(dev, regions, shifts, geno_offset_idx, _req(out_offsets, np.int64, "out_offsets", 1),
                                  scratch, track_offsets, params, strategy_id, base_seed, keep, keep_offsets, to_rc)
     out[...] = _np(res)
