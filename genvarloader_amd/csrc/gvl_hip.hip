@@ -1080,15 +1080,23 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             (f_valid && (d != 0 || alen != 1 || f_pos < 0 || (i64)f_pos + 1 > rfl64(ri.R))) ||
             (lane > 0 && lane < n_var && f_pos == pos_prev));
         is_fast = m_slow == 0 && rs > -(1 << 30) && rs < (1 << 30) && !(A.dbg & 32);
-        if (!is_fast && lane == 0) meta[wave].slow = 1;
+        // tell the workgroup: the slow flag, then one tick of the "decided" counter (meta[0].pad0_)
+        if (lane == 0) {
+            if (!is_fast) meta[wave].slow = 1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __hip_atomic_fetch_add(&meta[0].pad0_, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
-    GVL_STAMP(3);
-    // (uniform over the workgroup: without a packable row nobody waits for anybody)
-    const bool any_packable =
-        __builtin_amdgcn_ballot_w64(lane < WG_WAVES && (rin[lane < WG_WAVES ? lane : 0].flags & 11) == 8) != 0;
-    if (any_packable) __syncthreads();            // every row knows who plans it
+    // Fast rows go on at once.  A slow row waits until every packable row has decided (no
+    // workgroup barrier: the fast waves must not wait for anybody), then the first slow wave
+    // plans all slow rows and the others poll their flag.
     const bool slow_row = packable && !is_fast;
     if (slow_row) {
+        const int n_packable = __builtin_popcountll(
+            __builtin_amdgcn_ballot_w64(lane < WG_WAVES && (rin[lane < WG_WAVES ? lane : 0].flags & 11) == 8));
+        while (__hip_atomic_load(&meta[0].pad0_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < n_packable)
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const u64 m_slow_rows = __builtin_amdgcn_ballot_w64(lane < WG_WAVES && meta[lane < WG_WAVES ? lane : 0].slow != 0);
         if (wave == __builtin_ctzll(m_slow_rows)) {
             __builtin_amdgcn_s_setprio(3);      // the other slow rows wait for this wave
