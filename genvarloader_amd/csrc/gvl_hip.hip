@@ -1087,6 +1087,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             __hip_atomic_fetch_add(&meta[0].pad0_, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
+    GVL_STAMP(3);
     // Fast rows go on at once.  A slow row waits until every packable row has decided (no
     // workgroup barrier: the fast waves must not wait for anybody), then the first slow wave
     // plans all slow rows and the others poll their flag.
