@@ -27,6 +27,8 @@ SYMBOLS = (
     "gvl_get_diffs_sparse",
     "gvl_hap_offsets",
     "gvl_get_reference",
+    "gvl_keep_offsets",
+    "gvl_choose_exonic_variants",
     "gvl_rc_rows",
     "gvl_reverse_rows_4",
     "gvl_onehot",

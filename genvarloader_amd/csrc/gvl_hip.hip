@@ -2028,6 +2028,42 @@ __global__ __launch_bounds__(1024) void offsets_scan_kernel(i64 *offs, i64 n, i6
 }
 
 // ---------------------------------------------------------------------------
+// choose_exonic_variants (src/genotypes/mod.rs:127-176): keep[v] = the variant lies entirely
+// inside its query's [start, end).  Offsets first (counts -> the scan above), then the mask.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void keep_counts_kernel(const i64 *geno_offset_idx, const i64 *go_starts,
+                                                          const i64 *go_stops, i64 n_rows, i64 *keep_offsets) {
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) keep_offsets[0] = 0;
+    if (k >= n_rows) return;
+    const i64 o = geno_offset_idx[k];
+    const i64 n = go_stops[o] - go_starts[o];
+    keep_offsets[k + 1] = n > 0 ? n : 0;
+}
+
+__global__ __launch_bounds__(256) void exonic_keep_kernel(const int *starts, const int *ends, const i64 *geno_offset_idx,
+                                                          i64 n_rows, int ploidy, const int *geno_v_idxs,
+                                                          const i64 *go_starts, const i64 *go_stops, const int *v_starts,
+                                                          const int *ilens, i64 n_variants, const i64 *keep_offsets, u8 *keep) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const i64 k = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;      // one wave per row
+    if (k >= n_rows) return;
+    const i64 q = k / ploidy;
+    const i64 ref_start = starts[q], ref_end = ends[q];
+    const i64 o = geno_offset_idx[k];
+    const i64 o_s = go_starts[o], o_e = go_stops[o];
+    const i64 ks = keep_offsets[k];
+    for (i64 v = o_s + lane; v < o_e; v += WAVE) {
+        i64 vi = geno_v_idxs[v];
+        vi = vi < 0 ? 0 : (vi >= n_variants ? n_variants - 1 : vi);
+        const i64 pos = v_starts[vi];
+        const i64 il = ilens[vi];
+        const i64 end = pos - (il < 0 ? il : 0) + 1;
+        keep[ks + (v - o_s)] = (pos >= ref_start && end <= ref_end) ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Packed variant records.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_variants_kernel(const int *v_starts, const int *ilens,
@@ -3008,6 +3044,42 @@ int gvl_hap_offsets(const gvl_static *st, const gvl_batch *bt, int32_t *diffs, i
     if (rc) return rc;
     hipLaunchKernelGGL(offsets_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (i64 *)out_offsets, D.n_rows, (i64 *)total_and_max);
     return check_launch("gvl_hap_offsets(scan)");
+}
+
+int gvl_keep_offsets(const gvl_static *st, const int64_t *geno_offset_idx, int64_t batch, int64_t ploidy,
+                     int64_t *keep_offsets, int64_t *total_and_max, void *stream) {
+    if (!st || batch < 0 || ploidy <= 0) return fail(GVL_ERR_INVALID, "%s", "gvl_keep_offsets: bad arguments");
+    if (!keep_offsets) return fail(GVL_ERR_INVALID, "%s", "gvl_keep_offsets: NULL array");
+    const i64 n_rows = batch * ploidy;
+    if (n_rows > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_keep_offsets: batch too large");
+    if (n_rows > 0 && (!geno_offset_idx || !st->geno_o_starts || !st->geno_o_stops))
+        return fail(GVL_ERR_INVALID, "%s", "gvl_keep_offsets: NULL array");
+    const unsigned grid = (unsigned)((n_rows + 1 + 255) / 256);
+    keep_counts_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>((const i64 *)geno_offset_idx, (const i64 *)st->geno_o_starts,
+                                                                          (const i64 *)st->geno_o_stops, n_rows, (i64 *)keep_offsets);
+    int rc = check_launch("gvl_keep_offsets(counts)");
+    if (rc) return rc;
+    offsets_scan_kernel<<<dim3(1), dim3(1024), 0, (hipStream_t)stream>>>((i64 *)keep_offsets, n_rows, (i64 *)total_and_max);
+    return check_launch("gvl_keep_offsets(scan)");
+}
+
+int gvl_choose_exonic_variants(const gvl_static *st, const int32_t *starts, const int32_t *ends,
+                               const int64_t *geno_offset_idx, int64_t batch, int64_t ploidy,
+                               const int64_t *keep_offsets, uint8_t *keep, void *stream) {
+    if (!st || batch < 0 || ploidy <= 0) return fail(GVL_ERR_INVALID, "%s", "gvl_choose_exonic_variants: bad arguments");
+    const i64 n_rows = batch * ploidy;
+    if (n_rows == 0) return GVL_OK;
+    if (n_rows > 0x3FFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_choose_exonic_variants: batch too large");
+    if (!starts || !ends || !geno_offset_idx || !keep_offsets || !st->geno_o_starts || !st->geno_o_stops)
+        return fail(GVL_ERR_INVALID, "%s", "gvl_choose_exonic_variants: NULL array");
+    if (st->n_geno > 0 && (!keep || !st->geno_v_idxs || !st->v_starts || !st->ilens || st->n_variants <= 0))
+        return fail(GVL_ERR_INVALID, "%s", "gvl_choose_exonic_variants: NULL variant table / keep");
+    if (st->n_geno == 0) return GVL_OK;
+    const unsigned grid = (unsigned)((n_rows + 3) / 4);
+    exonic_keep_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(
+        starts, ends, (const i64 *)geno_offset_idx, n_rows, (int)ploidy, st->geno_v_idxs, (const i64 *)st->geno_o_starts,
+        (const i64 *)st->geno_o_stops, st->v_starts, st->ilens, st->n_variants, (const i64 *)keep_offsets, keep);
+    return check_launch("gvl_choose_exonic_variants");
 }
 
 int gvl_rc_rows(uint8_t *data, const int64_t *offsets, const uint8_t *to_rc, int64_t n_rows, void *stream) {

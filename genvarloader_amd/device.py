@@ -211,6 +211,25 @@ class HapsDevice:
                                                      C.c_int64(1), _ptr(diffs), _stream_ptr()))
         return diffs
 
+    def choose_exonic_variants(self, starts, ends, geno_offset_idx):
+        """choose_exonic_variants (src/genotypes/mod.rs:127-176) -> (keep u8[total], keep_offsets i64[K+1])
+        device tensors; one host sync for the exactly-sized mask."""
+        d = self.device
+        goi = _dev(geno_offset_idx, torch.int64, d)
+        st_, en_ = _dev(starts, torch.int32, d), _dev(ends, torch.int32, d)
+        B, P = int(goi.shape[0]), int(goi.shape[1])
+        ko = torch.empty(B * P + 1, dtype=torch.int64, device=d)
+        tm = torch.zeros(2, dtype=torch.int64, device=d)
+        with torch.cuda.device(d):
+            _lib.check(self.lib.gvl_keep_offsets(C.byref(self.c), _ptr(goi), C.c_int64(B), C.c_int64(P), _ptr(ko), _ptr(tm),
+                                                 _stream_ptr()))
+            total = int(tm[0].item()) if B * P else 0
+            keep = torch.empty(total, dtype=torch.uint8, device=d)
+            if total:
+                _lib.check(self.lib.gvl_choose_exonic_variants(C.byref(self.c), _ptr(st_), _ptr(en_), _ptr(goi), C.c_int64(B),
+                                                               C.c_int64(P), _ptr(ko), _ptr(keep), _stream_ptr()))
+        return keep, ko
+
     # -------------------------------------------------------------- reconstruct
     def alloc_output(self, bt: DeviceBatch, total: int, *, haps=True, onehot=False, layout="lc",
                      annotate=False, write_offsets=True) -> tuple[ReconOutput, GvlOut]:

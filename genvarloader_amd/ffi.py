@@ -198,6 +198,15 @@ def get_diffs_sparse(geno_offset_idx, geno_v_idxs, geno_offsets, ilens, keep=Non
 _DIFF_CACHE: "OrderedDict[tuple, HapsDevice]" = OrderedDict()
 
 
+def choose_exonic_variants(starts, ends, geno_offset_idx, geno_v_idxs, geno_offsets, v_starts, ilens):
+    """-> (keep bool[total], keep_offsets i64[K+1])   (src/genotypes/mod.rs:127-176; imported next to
+    get_diffs_sparse at _dataset/_genotypes.py:5-9)."""
+    dev = _diffs_static(geno_offsets, geno_v_idxs, v_starts, ilens)
+    keep, ko = dev.choose_exonic_variants(_req(starts, np.int32, "starts", 1), _req(ends, np.int32, "ends", 1),
+                                          _req(geno_offset_idx, np.int64, "geno_offset_idx", 2))
+    return _np(keep).astype(np.bool_), _np(ko)
+
+
 def _diffs_static(geno_offsets, geno_v_idxs, v_starts, ilens) -> HapsDevice:
     arrs = tuple(np.asarray(a) for a in (geno_offsets, geno_v_idxs, v_starts, ilens))
     geno_offsets, geno_v_idxs, v_starts, ilens = arrs

@@ -182,6 +182,18 @@ int gvl_get_reference(const gvl_static *st, const int32_t *regions,
                       const uint8_t *to_rc, uint8_t *out, uint8_t *onehot,
                       void *stream);
 
+/* Keep mask of the spliced path.  Replaces choose_exonic_variants (src/genotypes/mod.rs:127-176):
+ * keep[keep_offsets[k] + j] = variant j of row k lies entirely inside its query's exon
+ * [starts[q], ends[q]) (pos >= start && pos - min(ilen, 0) + 1 <= end), q = k / ploidy.
+ * gvl_keep_offsets first: keep_offsets i64 (batch*ploidy + 1) = running sum of the rows' variant
+ * counts, total_and_max (nullable) = {keep length, largest row}; the caller sizes `keep` from
+ * the total, then gvl_choose_exonic_variants fills it. */
+int gvl_keep_offsets(const gvl_static *st, const int64_t *geno_offset_idx, int64_t batch, int64_t ploidy,
+                     int64_t *keep_offsets, int64_t *total_and_max, void *stream);
+int gvl_choose_exonic_variants(const gvl_static *st, const int32_t *starts, const int32_t *ends,
+                               const int64_t *geno_offset_idx, int64_t batch, int64_t ploidy,
+                               const int64_t *keep_offsets, uint8_t *keep, void *stream);
+
 /* In-place reverse-complement of masked rows.  Replaces rc_flat_rows_inplace
  * (src/reverse.rs:56-69; COMP semantics :9-21,:45-53). */
 int gvl_rc_rows(uint8_t *data, const int64_t *offsets, const uint8_t *to_rc,

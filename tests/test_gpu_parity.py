@@ -96,6 +96,29 @@ def test_golden_get_diffs_sparse(gpu):
         np.testing.assert_array_equal(got, exp, err_msg=f"case {ci}")
 
 
+def test_golden_choose_exonic_variants(gpu, oracle):
+    """Keep mask of the spliced path: the reference's 200 goldens + its Rust KAT
+    (genotypes/mod.rs:215-231), and a synthetic batch against the oracle."""
+    cases = load_ref_cases("choose_exonic_variants")
+    assert len(cases) == 200
+    for ci, (inp, exp) in enumerate(cases):
+        keep, ko = gpu.ffi.choose_exonic_variants(*inp)
+        np.testing.assert_array_equal(keep, exp[0], err_msg=f"case {ci}")
+        np.testing.assert_array_equal(ko, exp[1], err_msg=f"case {ci}")
+    keep, ko = gpu.ffi.choose_exonic_variants(np.array([10], np.int32), np.array([20], np.int32), np.array([[0]], np.int64),
+                                              np.array([0, 1, 2], np.int32), np.array([[0], [3]], np.int64),
+                                              np.array([12, 19, 19], np.int32), np.array([0, 0, -2], np.int32))
+    assert keep.tolist() == [True, True, False] and ko.tolist() == [0, 3]
+    st, bt = _synth(3, (50_000,), 200, 900, indel_frac=0.4, density=1 / 30)
+    exp_keep, exp_ko = oracle.choose_exonic_variants(bt.regions[:, 1] + 100, bt.regions[:, 2] - 300, bt.geno_offset_idx,
+                                                     bt.geno_v_idxs, bt.geno_offsets, st.v_starts, st.ilens)
+    keep, ko = gpu.ffi.choose_exonic_variants(bt.regions[:, 1] + 100, bt.regions[:, 2] - 300, bt.geno_offset_idx,
+                                              bt.geno_v_idxs, bt.geno_offsets, st.v_starts, st.ilens)
+    np.testing.assert_array_equal(keep, exp_keep)
+    np.testing.assert_array_equal(ko, exp_ko)
+    assert 0 < keep.sum() < keep.size
+
+
 def test_golden_get_reference(gpu):
     cases = load_ref_cases("get_reference")
     assert len(cases) == 200
