@@ -207,6 +207,20 @@ def choose_exonic_variants(starts, ends, geno_offset_idx, geno_v_idxs, geno_offs
     return _np(keep).astype(np.bool_), _np(ko)
 
 
+def rc_alleles(byte_data, seq_offsets, var_offsets, to_rc_row):
+    """In place: reverse-complement the alleles of the mask-selected rows (src/ffi/mod.rs:2805-2820 ->
+    variants::rc_alleles_inplace): row r owns alleles var_offsets[r]..var_offsets[r+1], allele a owns
+    bytes seq_offsets[a]..seq_offsets[a+1]; the same rc_row as the haplotype path (gvl_rc_rows)."""
+    seq_offsets = _req(seq_offsets, np.int64, "seq_offsets", 1)
+    var_offsets = _req(var_offsets, np.int64, "var_offsets", 1)
+    per_allele = np.repeat(np.asarray(to_rc_row, np.bool_), np.diff(var_offsets))
+    if per_allele.size == 0 or byte_data.size == 0:
+        return
+    t = torch.from_numpy(np.ascontiguousarray(byte_data, np.uint8)).cuda()
+    _device.rc_flat_rows_inplace(t, seq_offsets, per_allele)
+    byte_data[...] = t.cpu().numpy()
+
+
 def _diffs_static(geno_offsets, geno_v_idxs, v_starts, ilens) -> HapsDevice:
     arrs = tuple(np.asarray(a) for a in (geno_offsets, geno_v_idxs, v_starts, ilens))
     geno_offsets, geno_v_idxs, v_starts, ilens = arrs

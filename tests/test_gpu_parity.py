@@ -138,6 +138,9 @@ def test_golden_rc_alleles_pins_rc_rows(gpu):
         t = gpu.torch.from_numpy(np.ascontiguousarray(data, np.uint8).copy()).cuda()
         gpu.device.rc_flat_rows_inplace(t, seq_offsets, per_allele)
         np.testing.assert_array_equal(t.cpu().numpy(), exp, err_msg=f"case {ci}")
+        buf = np.ascontiguousarray(data, np.uint8).copy()          # and through the reference's signature
+        gpu.ffi.rc_alleles(buf, seq_offsets, var_offsets, mask)
+        np.testing.assert_array_equal(buf, exp, err_msg=f"case {ci} (ffi.rc_alleles)")
 
 
 # ------------------------------------------------------------------ known-answer rows
