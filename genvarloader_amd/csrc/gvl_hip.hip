@@ -12,18 +12,21 @@
 //   docs/source/index.md:109-119    user-side seqpro one-hot
 //
 // Design (DESIGN.md has the long form).  The reference walks a row's variants
-// sequentially and memcpy's reference/allele runs.  Here one WAVE owns one
-// (row, chunk) of output:
-//   1. lanes gather the row's variant records in parallel (one 16-B packed
-//      record + one 8-B allele offset per variant, 64 variants per trip);
-//   2. the wave replays the reference's sequential walk on the scalar unit
-//      (v_readlane -> SGPR state), but instead of copying bytes it emits
-//      SEGMENTS (out_start, kind, source delta) into a 64-entry lane-resident
-//      table; pure SNPs do not split a reference run, they become PATCHES;
-//   3. all 64 lanes then stream the output: 4 bases per lane per trip, one
-//      unaligned dword load of reference bytes (256 B per wave-load), SNP
-//      patches applied in registers, reverse-complement folded into the store
-//      index + LUT, one-hot through a 256-entry LDS LUT, one 16-B store per lane
+// sequentially and memcpy's reference/allele runs.  Here a workgroup of 8 waves owns
+// 8 (row, chunk)s of output, one per wave:
+//   1. PLAN: the row's walk is restated as a SEGMENT table (out_start, kind, source
+//      delta; <= 64 entries in LDS) plus a PATCH list (pure SNPs do not split a
+//      reference run).  Three planners produce it, picked per row:
+//        fast    every kept variant is a SNP: no scan, planned by the row's own wave;
+//        packed  the first "slow" wave plans all slow rows of the workgroup at once,
+//                lane = row x variant, DPP scans in groups of 8 lanes (<= 8 variants);
+//        scans   wave-wide DPP scans, 64 variants per trip (any number of variants);
+//      and a scalar replay of the reference's loop (recon_wave_scalar) takes what the
+//      i32 scans cannot (coordinates >= 2^30, > 64 table entries per chunk).
+//   2. STREAM: all 64 lanes stream the output: 4 bases per lane per trip, one
+//      unaligned dword load of reference bytes (256 B per wave-load), SNP patches
+//      applied in registers, reverse-complement folded into the store index + LUT,
+//      one-hot through a 256-entry LDS LUT, one nontemporal 16-B store per lane
 //      (1 KiB contiguous per wave-store).
 // There is no second pass over HBM for RC or one-hot and no intermediate
 // haplotype buffer unless the caller asks for the bytes too.  Integer
@@ -628,7 +631,9 @@ __device__ __forceinline__ int wave_scan_exclusive(int v, int &inclusive) {
 // ---------------------------------------------------------------------------------
 // Planned path.  A workgroup = 8 waves = 8 rows of one chunk index; wave w owns row w.
 //   P1  lanes 0..7 of wave 0 load the 8 rows' parameters (one lane per row), one barrier
-//   P2  the wave gathers its row's variant records, lane j = variant j
+//   P2  the row's variant records, lane j = variant j; rows with <= 8 variants classify
+//       themselves: fast (SNPs only: the scan-free plan in reconstruct_kernel) or slow
+//       (planned together by the first slow wave: packed_plan); the others run P3 per wave
 //   P3  the reference's sequential walk, restated as wave-wide scans:
 //         * shift: the lead pad absorbs it first; while it is open ref_idx does not move, so
 //           the variants in front of the one that completes it are dropped and that one is
@@ -649,7 +654,7 @@ __device__ __forceinline__ int wave_scan_exclusive(int v, int &inclusive) {
 // ---------------------------------------------------------------------------------
 struct RowIn {
     i64 c_s, R, ref_start, shift, o_s, keep_off, row_base;
-    int n_var, L, rc, flags;     // flags: 1 = no work (row out of range / chunk past the row), 2 = scalar path, 4 = zero fill, 8 = packed plan
+    int n_var, L, rc, flags;     // flags: 1 = no work (row out of range / chunk past the row), 2 = scalar path, 4 = zero fill, 8 = packable (<= 8 variants)
 };
 template <bool ANNOT>
 struct RowPlan {
