@@ -2852,9 +2852,13 @@ int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
     return 0;
 }
 
-// GVL_DBG (read once): test/diagnostic switches.  8 = force the scalar per-wave path for every
-// row (the GPU suite runs once this way); 1/2/4 = ablations (no variants / no stores / no loads)
-// that only make sense for timing; 16 = ignore gvl_static.geno_rec (A/B of the record layout).
+// GVL_DBG (read once; gvl_set_debug_flags overrides it): test/diagnostic switches that remove
+// one way a row can reach its output, so that the GPU suite can be run down every path:
+//     8  every row through the scalar walk (haplotypes and tracks)
+//    32  no scan-free plan for SNP-only rows (they join the packed plan)
+//   512  no packable rows at all (every row runs the per-wave scans)
+//    16  ignore gvl_static.geno_rec (records come from geno_v_idxs -> vrec)
+// and 1 / 2 / 4 = timing ablations (no variants / no stores / no loads).
 int g_debug_override = -1;
 int debug_flags() {
     static const int flags = [] { const char *e = getenv("GVL_DBG"); return e ? atoi(e) : 0; }();
