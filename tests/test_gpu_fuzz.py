@@ -2,7 +2,8 @@
 densities, indel sizes, ploidy 1-3, lengths 1-5000, ragged / fixed, shifts far beyond
 max_shift, keep masks, regions stride 3 / 4, annotations, both one-hot layouts, all five
 insertion-fill strategies, overlapping intervals -- HIP vs oracle, bit-exact.  Once on the
-planned (scan) path and once with every row forced through the scalar path."""
+planned paths (scan-free / packed / per-wave scans, and each of them switched off in turn) and
+once with every row forced through the scalar path."""
 
 import os
 import subprocess
@@ -31,6 +32,16 @@ def test_fuzz_haplotypes_planned_path():
 
 def test_fuzz_haplotypes_scalar_path():
     _run("fuzz.py", 300, 102, dbg=8)
+
+
+def test_fuzz_haplotypes_without_scan_free_plan():
+    """GVL_DBG=32: SNP-only rows go through the packed plan like rows with indels."""
+    _run("fuzz.py", 300, 106, dbg=32)
+
+
+def test_fuzz_haplotypes_per_wave_scans_only():
+    """GVL_DBG=512: no packable rows, every row runs the per-wave scans."""
+    _run("fuzz.py", 300, 107, dbg=512)
 
 
 def test_fuzz_haplotypes_without_genotype_records():
