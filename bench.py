@@ -85,8 +85,8 @@ def cpu_baseline(st, bt, haps: bool, budget_s: float = 12.0) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg4"])
     ap.add_argument("--haps", action="store_true", help="also materialise haplotype bytes (h=1)")
     ap.add_argument("--contig", type=int, default=None, help="override reference contig length (bp)")
