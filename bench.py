@@ -179,6 +179,15 @@ def main() -> None:
     ev1.record(stream)
     torch.cuda.synchronize()
     kern_ms = ev0.elapsed_time(ev1) / args.steps
+    # ---- single-batch latency, host wall clock: launch -> synchronize -----------
+    lat = []
+    for i in range(50):
+        torch.cuda.synchronize()
+        t_a = time.perf_counter()
+        step(i, pipelined=False)
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t_a)
+    single_ms = float(np.median(lat)) * 1e3
     if dist is not None:
         tt = torch.tensor([wall, kern_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -215,6 +224,7 @@ def main() -> None:
                 "kernel_ms": kern_ms, "kernel_ms_how": "HIP events around K back-to-back launches on one stream",
                 "algorithmic_bytes_per_launch": abytes,
                 "pipelined_GBps": abytes * world / (wall / args.steps) / 1e9 / world,
+                "single_batch_wall_ms": single_ms,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
