@@ -9,6 +9,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 T=$R/gpurun_out/${1:-prof}
 mkdir -p $T
 cd /tmp
+[ -x $R/tools/kbench.bin ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 $R/tools/kbench.hip -o $R/tools/kbench.bin
 rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats_default -- python3 $R/bench.py --no-cpu-baseline > $T/stats_default.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats_1stream -- python3 $R/bench.py --no-cpu-baseline --streams 1 > $T/stats_1stream.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
