@@ -2871,14 +2871,31 @@ int log2_exact(i64 v) {
 }
 
 // GVL_TRACE=1: report any HIP call of the loop that holds the host for more than 1 ms.
-bool trace_on() { static const bool on = [] { const char *e = getenv("GVL_TRACE"); return e && atoi(e) != 0; }(); return on; }
+// GVL_TRACE=2: also sum the host time per call site; gvl_loader_destroy prints the averages.
+int trace_level() { static const int lv = [] { const char *e = getenv("GVL_TRACE"); return e ? atoi(e) : 0; }(); return lv; }
+bool trace_on() { return trace_level() != 0; }
 double now_ms() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+struct TraceSite { const char *tag; double sum_ms; long n; };
+TraceSite g_sites[16];
+int g_nsites = 0;
+void trace_add(const char *tag, double dt) {
+    for (int i = 0; i < g_nsites; ++i) if (g_sites[i].tag == tag) { g_sites[i].sum_ms += dt; ++g_sites[i].n; return; }
+    if (g_nsites < 16) g_sites[g_nsites++] = TraceSite{tag, dt, 1};
+}
+void trace_report() {
+    if (trace_level() < 2) return;
+    for (int i = 0; i < g_nsites; ++i)
+        fprintf(stderr, "[gvl trace] %-24s %8ld calls  %7.2f us each\n", g_sites[i].tag, g_sites[i].n,
+                1e3 * g_sites[i].sum_ms / (double)g_sites[i].n);
+    g_nsites = 0;
+}
 template <typename F> hipError_t traced(const char *tag, F f) {
     if (!trace_on()) return f();
     const double t0 = now_ms();
     const hipError_t e = f();
     const double dt = now_ms() - t0;
     if (dt > 1.0) fprintf(stderr, "[gvl trace] %s held the host for %.1f ms\n", tag, dt);
+    if (trace_level() >= 2) trace_add(tag, dt);
     return e;
 }
 }  // namespace
@@ -3316,6 +3333,7 @@ int gvl_loader_create(const gvl_static *st, const gvl_loader_config *cfg, gvl_lo
 
 int gvl_loader_destroy(gvl_loader *ld) {
     if (!ld) return GVL_OK;
+    trace_report();
     for (int i = 0; i < 16; ++i) if (ld->streams[i]) { hipStreamSynchronize(ld->streams[i]); hipStreamDestroy(ld->streams[i]); }
     for (int i = 0; i < 64; ++i) {
         if (ld->done[i]) hipEventDestroy(ld->done[i]);
