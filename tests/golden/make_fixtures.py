@@ -169,6 +169,28 @@ def generate_pyref():
     bt.keep = rng.random(int(bt.keep_offsets[-1])) < 0.8
     out, av, ap = pyref_batch(fb, st, bt, annotate=True)
     save_pyref("dense_annot", st, bt, out, av, ap)
+    # SNP-dominated rows with duplicate positions ("first ALT wins" among SNPs), shifts that end
+    # before / on / after a SNP or run past the contig end, windows over both contig edges, keep
+    # masks that remove a row's only indel -- the cases the GPU build plans without scans
+    rng = np.random.default_rng(20260802 + 12)
+    st = synth.make_static(rng, (9_000,), indel_frac=0.05, density=1 / 25, af_beta=(2.0, 2.0))
+    dup = rng.random(st.v_starts.size) < 0.12
+    st.v_starts[1:][dup[1:]] = st.v_starts[:-1][dup[1:]]          # still sorted
+    bt = synth.make_batch(rng, st, 40, 2, 333, rc_frac=0.5, edge_frac=0.3, slack=40)
+    bt.shifts = rng.integers(0, 25, bt.shifts.shape).astype(np.int32)
+    bt.shifts[rng.random(bt.shifts.shape) < 0.3] = 0
+    bt.shifts[0, 0] = 20_000
+    idx = bt.geno_offset_idx.ravel()
+    n_per = bt.geno_offsets[1, idx] - bt.geno_offsets[0, idx]
+    bt.keep_offsets = np.concatenate([[0], np.cumsum(n_per)]).astype(np.int64)
+    keep = rng.random(int(bt.keep_offsets[-1])) < 0.9
+    for k in range(idx.size):                                      # half the rows lose their indels
+        if k % 2 == 0:
+            vs = bt.geno_v_idxs[bt.geno_offsets[0, idx[k]]:bt.geno_offsets[1, idx[k]]]
+            keep[bt.keep_offsets[k]:bt.keep_offsets[k + 1]] &= st.ilens[vs] == 0
+    bt.keep = keep
+    out, av, ap = pyref_batch(fb, st, bt, annotate=True)
+    save_pyref("snp_dups_shifts", st, bt, out, av, ap)
 
 
 if __name__ == "__main__":

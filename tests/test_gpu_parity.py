@@ -186,7 +186,7 @@ def test_rc_kats(gpu):
 
 
 # ------------------------------------------------------------------ reference numpy fallback vectors
-@pytest.mark.parametrize("name", ["cfg2_small", "cfg3_small", "dense_annot"])
+@pytest.mark.parametrize("name", ["cfg2_small", "cfg3_small", "dense_annot", "snp_dups_shifts"])
 def test_pyref_fixtures(gpu, name):
     d = load_pyref(name)
     annotate = d["expected_annot_v_idxs"] is not None

@@ -88,7 +88,7 @@ def _run_pyref(oracle, d, annotate=False, n_threads=1):
     return out, av, ap
 
 
-@pytest.mark.parametrize("name", ["cfg2_small", "cfg3_small", "dense_annot"])
+@pytest.mark.parametrize("name", ["cfg2_small", "cfg3_small", "dense_annot", "snp_dups_shifts"])
 def test_oracle_equals_reference_numpy_fallback(oracle, name):
     d = load_pyref(name)
     annotate = d["expected_annot_v_idxs"] is not None
