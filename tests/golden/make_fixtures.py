@@ -193,6 +193,62 @@ def generate_pyref():
     save_pyref("snp_dups_shifts", st, bt, out, av, ap)
 
 
+def extract_namespace(path: Path, func_names, const_prefix="_"):
+    """exec several top-level FunctionDefs + the module's simple UPPER_CASE constants in one
+    numpy-only namespace (the functions call each other)."""
+    tree = ast.parse(path.read_text())
+    body = []
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in func_names:
+            node.decorator_list = []
+            body.append(node)
+        elif isinstance(node, ast.Assign) and len(node.targets) == 1 and isinstance(node.targets[0], ast.Name) \
+                and node.targets[0].id.upper() == node.targets[0].id and isinstance(node.value, ast.Constant):
+            body.append(node)
+    ns = {"np": np}
+    exec(compile(ast.Module(body=body, type_ignores=[]), str(path), "exec"), ns)
+    return ns
+
+
+def generate_pyref_tracks():
+    """Track realignment at a realistic shape through the reference's pure-numpy fallback
+    (_dataset/_tracks.py:621-824), all five insertion-fill strategies, keep masks, shifts."""
+    ns = extract_namespace(REF / "python/genvarloader/_dataset/_tracks.py",
+                           {"_xorshift64", "_hash4", "_apply_insertion_fill", "shift_and_realign_track_sparse"})
+    fb = ns["shift_and_realign_track_sparse"]
+    rng = np.random.default_rng(20260802 + 13)
+    st = synth.make_static(rng, (40_000,), indel_frac=0.5, density=1 / 40, max_indel=12)
+    bt = synth.make_batch(rng, st, 10, 2, 900, rc_frac=0.0, random_shifts=True, slack=60)
+    B, P = bt.geno_offset_idx.shape
+    L = bt.output_length
+    tlen = (bt.regions[:, 2] - bt.regions[:, 1]).astype(np.int64) + 80
+    track_offsets = np.concatenate([[0], np.cumsum(tlen)]).astype(np.int64)
+    tracks = np.repeat(rng.random(int(track_offsets[-1]) // 7 + 1).astype(np.float32) * 8, 7)[: int(track_offsets[-1])]
+    idx = bt.geno_offset_idx.ravel()
+    n_per = bt.geno_offsets[1, idx] - bt.geno_offsets[0, idx]
+    keep_offsets = np.concatenate([[0], np.cumsum(n_per)]).astype(np.int64)
+    keep = rng.random(int(keep_offsets[-1])) < 0.85
+    params = {0: 0.0, 1: 0.0, 2: 2.5, 3: 5.0, 4: 3.0}
+    d = dict(v_starts=st.v_starts, ilens=st.ilens, regions=bt.regions, shifts=bt.shifts,
+             geno_offset_idx=bt.geno_offset_idx, geno_offsets=bt.geno_offsets, geno_v_idxs=bt.geno_v_idxs,
+             tracks=tracks, track_offsets=track_offsets, keep=keep, keep_offsets=keep_offsets,
+             output_length=np.int64(L), base_seed=np.uint64(424242))
+    for s_id, par in params.items():
+        for use_keep in (0, 1):
+            out = np.zeros(B * P * L, np.float32)
+            for k in range(B * P):
+                q, h = divmod(k, P)
+                kp = keep[keep_offsets[k]:keep_offsets[k + 1]] if use_keep else None
+                fb(int(idx[k]), bt.geno_v_idxs, bt.geno_offsets, st.v_starts, st.ilens, int(bt.shifts.ravel()[k]),
+                   tracks[track_offsets[q]:track_offsets[q + 1]], int(bt.regions[q, 1]), out[k * L:(k + 1) * L],
+                   np.array([par], np.float64), kp, s_id, 424242, q, h)
+            d[f"expected_s{s_id}_k{use_keep}"] = out
+        d[f"param_s{s_id}"] = np.float64(par)
+    np.savez_compressed(HERE / "pyref_tracks.npz", **d)
+    print(f"pyref_tracks.npz: rows={B * P} L={L} V/row={bt.mean_variants:.2f}")
+
+
 if __name__ == "__main__":
     convert_reference_goldens()
     generate_pyref()
+    generate_pyref_tracks()

@@ -236,3 +236,14 @@ def test_tracks_coordinates_beyond_2_30(ffi, oracle):
         np.testing.assert_array_equal(bits(got), bits(exp))
         outs.append(got)
     np.testing.assert_array_equal(bits(outs[0]), bits(outs[1]))
+
+
+@pytest.mark.parametrize("s_id", [0, 1, 2, 3, 4])
+def test_reference_numpy_fallback_tracks(ffi, s_id):
+    """The GPU realignment against vectors from the reference's own numpy fallback."""
+    from tests.test_oracle_tracks import _pyref_tracks, _run_pyref_tracks
+
+    d = _pyref_tracks()
+    for use_keep in (0, 1):
+        got = _run_pyref_tracks(ffi.shift_and_realign_tracks_sparse, d, s_id, use_keep)
+        np.testing.assert_array_equal(bits(got), bits(d[f"expected_s{s_id}_k{use_keep}"]))

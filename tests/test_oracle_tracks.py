@@ -3,6 +3,7 @@ goldens: tests/parity/test_shift_and_realign_tracks_parity.py, test_intervals_to
 test_prng_parity.py (known answers :58-71 + goldens)."""
 
 import numpy as np
+import pytest
 
 from tests._fixtures import load_ref_cases
 
@@ -47,3 +48,31 @@ def test_intervals_to_tracks_golden(oracle):
         oracle.intervals_to_tracks(*inp[:6], out, inp[6])
         np.testing.assert_array_equal(out.view(np.uint32), np.asarray(exp, np.float32).view(np.uint32),
                                       err_msg=f"case {ci}")
+
+
+def _pyref_tracks():
+    from tests._fixtures import GOLDEN
+
+    z = np.load(GOLDEN / "pyref_tracks.npz")
+    return {k: z[k] for k in z.files}
+
+
+def _run_pyref_tracks(fn, d, s_id, use_keep):
+    B, P = d["geno_offset_idx"].shape
+    L = int(d["output_length"])
+    out_offsets = np.arange(B * P + 1, dtype=np.int64) * L
+    out = np.full(B * P * L, 7.0, np.float32)
+    fn(out, out_offsets, d["regions"], d["shifts"], d["geno_offset_idx"], d["geno_v_idxs"], d["geno_offsets"],
+       d["v_starts"], d["ilens"], d["tracks"], d["track_offsets"], np.array([float(d[f"param_s{s_id}"])]),
+       d["keep"] if use_keep else None, d["keep_offsets"] if use_keep else None, s_id, int(d["base_seed"]))
+    return out
+
+
+@pytest.mark.parametrize("s_id", [0, 1, 2, 3, 4])
+def test_oracle_vs_reference_numpy_fallback_tracks(oracle, s_id):
+    """pyref_tracks.npz: the reference's pure-numpy track fallback (_dataset/_tracks.py:621-824)
+    on a 20-row x 900 batch with shifts, 11 variants per row, with and without keep masks."""
+    d = _pyref_tracks()
+    for use_keep in (0, 1):
+        got = _run_pyref_tracks(oracle.shift_and_realign_tracks_sparse, d, s_id, use_keep)
+        np.testing.assert_array_equal(got.view(np.uint32), d[f"expected_s{s_id}_k{use_keep}"].view(np.uint32))
