@@ -57,8 +57,6 @@ constexpr int TRIP = WAVE * GROUP;         // 256 bases per wave trip
 constexpr int SEG_CAP = 64;                // lane-resident segment table
 constexpr int SEG_FLUSH = 59;              // flush before a step could overflow
 constexpr int PATCH_FLUSH = 62;
-constexpr int CAP_V = 32;                 // variants per row the cooperative planner handles
-constexpr int CAP_P = 32;                 // SNP patches per (row, chunk) in the shared plan
 constexpr int CHUNK_TRIPS = 8;            // trips per chunk on the planned path (chunk_len <= 2048)
 
 enum : u32 { K_REF = 0, K_ALLELE = 1, K_PAD_LEAD = 2, K_PAD_TRAIL = 3 };
@@ -662,7 +660,6 @@ struct RowPlan {
     int s_a[ANNOT ? SEG_CAP : 1], s_b[ANNOT ? SEG_CAP : 1];
     int p_out[WAVE], p_val[WAVE], p_id[ANNOT ? WAVE : 1];
 };
-constexpr u32 GENERAL_HI = 0x80000000u;
 
 // Trip descriptors of one row (what P3b produces), 8 trips per chunk; and the row's table sizes.
 struct TripDesc {
@@ -1546,7 +1543,6 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     // finish one trip: SNP patches, reverse-complement, one-hot LUT, stores
     auto finish = [&](const int p0, const int pc0, const int pcn, u32 wv, int (&av4)[GROUP], int (&ap4)[GROUP]) -> u32 {
         const int p = p0 + GROUP * lane;
-        const bool act = p < limit;
         const bool full = p + GROUP <= limit;
         for (int q = pc0; q < pcn; ++q) {
             const u32 dd = (u32)(pl.p_out[q] - p);
@@ -3334,12 +3330,12 @@ int gvl_loader_create(const gvl_static *st, const gvl_loader_config *cfg, gvl_lo
 int gvl_loader_destroy(gvl_loader *ld) {
     if (!ld) return GVL_OK;
     trace_report();
-    for (int i = 0; i < 16; ++i) if (ld->streams[i]) { hipStreamSynchronize(ld->streams[i]); hipStreamDestroy(ld->streams[i]); }
+    for (int i = 0; i < 16; ++i) if (ld->streams[i]) { (void)hipStreamSynchronize(ld->streams[i]); (void)hipStreamDestroy(ld->streams[i]); }
     for (int i = 0; i < 64; ++i) {
-        if (ld->done[i]) hipEventDestroy(ld->done[i]);
-        if (ld->released[i]) hipEventDestroy(ld->released[i]);
+        if (ld->done[i]) (void)hipEventDestroy(ld->done[i]);
+        if (ld->released[i]) (void)hipEventDestroy(ld->released[i]);
     }
-    if (ld->epoch_ready) hipEventDestroy(ld->epoch_ready);
+    if (ld->epoch_ready) (void)hipEventDestroy(ld->epoch_ready);
     delete ld;
     return GVL_OK;
 }
@@ -3347,7 +3343,7 @@ int gvl_loader_destroy(gvl_loader *ld) {
 int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int32_t drop_last, void *stream) {
     if (!ld || n < 0 || (n > 0 && !order)) return fail(GVL_ERR_INVALID, "%s", "gvl_loader_start_epoch: bad arguments");
     if (ld->submitted != ld->consumed)   // an abandoned epoch: let its batches drain before slots are reused
-        for (int i = 0; i < ld->cfg.in_flight; ++i) hipStreamSynchronize(ld->streams[i]);
+        for (int i = 0; i < ld->cfg.in_flight; ++i) (void)hipStreamSynchronize(ld->streams[i]);
     const i64 bs = ld->cfg.batch_size;
     ld->order = order; ld->n_order = n;
     ld->n_batches = drop_last ? n / bs : (n + bs - 1) / bs;
@@ -3388,7 +3384,7 @@ static int loader_submit(gvl_loader *ld, i64 j) {
     loader_parts(ld, slot, j, &o);
     const gvl_loader_config &c = ld->cfg;
     int rc = GVL_OK;
-    traced("launch prepare_request", [&] {
+    (void)traced("launch prepare_request", [&] {
         rc = gvl_prepare_request(&ld->st, o.idx, o.batch, c.full_regions, c.n_regions, c.n_samples, c.ploidy, c.jitter,
                                  c.rc_neg, c.deterministic, c.output_length, c.seed, ++ld->counter, o.regions,
                                  o.geno_offset_idx, o.to_rc, o.shifts, s);
@@ -3402,7 +3398,7 @@ static int loader_submit(gvl_loader *ld, i64 j) {
     gvl_out oc;
     memset(&oc, 0, sizeof(oc));
     oc.haps = o.haps; oc.onehot = o.onehot; oc.onehot_layout = c.onehot_layout; oc.out_offsets = o.out_offsets;
-    traced("launch reconstruct", [&] { rc = gvl_reconstruct(&ld->st, &bt, &oc, s); return hipSuccess; });
+    (void)traced("launch reconstruct", [&] { rc = gvl_reconstruct(&ld->st, &bt, &oc, s); return hipSuccess; });
     if (rc) return rc;
     if (traced("record done", [&] { return hipEventRecord(ld->done[slot], s); }) != hipSuccess) return fail(GVL_ERR_HIP, "%s", "gvl_loader: hipEventRecord failed");
     ld->slot_used[slot] = true;
