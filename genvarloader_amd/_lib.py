@@ -83,6 +83,7 @@ class GvlLoaderConfig(C.Structure):
         ("rc_neg", C.c_int32), ("deterministic", C.c_int32), ("seed", C.c_uint64),
         ("want_haps", C.c_int32), ("want_onehot", C.c_int32), ("onehot_layout", C.c_int32),
         ("in_flight", C.c_int32), ("n_slots", C.c_int32), ("slot_arenas", C.POINTER(_vp)),
+        ("threaded", C.c_int32),
     ]
 
 

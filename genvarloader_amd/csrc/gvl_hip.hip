@@ -39,6 +39,9 @@
 #include <string.h>
 #include <time.h>
 #include <new>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 #include "gvl_hip.h"
 
@@ -3279,6 +3282,19 @@ struct gvl_loader {
     const int64_t *order; i64 n_order; i64 n_batches;
     i64 submitted, consumed; int prev_slot;
     u64 counter;
+    struct LoaderSync *sync;      // non-NULL: a producer thread submits the batches (cfg.threaded)
+};
+
+// Producer thread state.  `submitted` / `consumed` / `n_batches` / `order` are only touched under
+// `mu` once the thread exists; the HIP calls themselves run outside the lock.
+struct LoaderSync {
+    std::mutex mu;
+    std::condition_variable cv_producer, cv_consumer;
+    std::thread th;
+    bool stop = false, active = false, busy = false;
+    int err = GVL_OK;
+    char msg[512] = "";
+    int device = 0;
 };
 
 static i64 align256(i64 x) { return (x + 255) & ~255ll; }
@@ -3294,6 +3310,9 @@ int64_t gvl_loader_slot_bytes(const gvl_loader_config *cfg, int64_t *part_offset
     }
     return off;
 }
+
+static int loader_submit(gvl_loader *ld, i64 j);
+static void loader_producer_main(gvl_loader *ld);
 
 int gvl_loader_create(const gvl_static *st, const gvl_loader_config *cfg, gvl_loader **out) {
     if (!st || !cfg || !out) return fail(GVL_ERR_INVALID, "%s", "gvl_loader_create: NULL argument");
@@ -3323,12 +3342,29 @@ int gvl_loader_create(const gvl_static *st, const gvl_loader_config *cfg, gvl_lo
     ok = ok && hipEventCreateWithFlags(&ld->epoch_ready, hipEventDisableTiming) == hipSuccess;
     if (!ok) { gvl_loader_destroy(ld); return fail(GVL_ERR_HIP, "%s", "gvl_loader_create: stream / event creation failed"); }
     ld->prev_slot = -1;
+    if (cfg->threaded) {
+        LoaderSync *sy = new (std::nothrow) LoaderSync;
+        if (!sy) { gvl_loader_destroy(ld); return fail(GVL_ERR_HIP, "%s", "gvl_loader_create: out of host memory"); }
+        if (hipGetDevice(&sy->device) != hipSuccess) sy->device = 0;
+        ld->sync = sy;
+        sy->th = std::thread(loader_producer_main, ld);
+    }
     *out = ld;
     return GVL_OK;
 }
 
 int gvl_loader_destroy(gvl_loader *ld) {
     if (!ld) return GVL_OK;
+    if (ld->sync) {
+        {
+            std::lock_guard<std::mutex> lk(ld->sync->mu);
+            ld->sync->stop = true;
+        }
+        ld->sync->cv_producer.notify_all();
+        if (ld->sync->th.joinable()) ld->sync->th.join();
+        delete ld->sync;
+        ld->sync = nullptr;
+    }
     trace_report();
     for (int i = 0; i < 16; ++i) if (ld->streams[i]) { (void)hipStreamSynchronize(ld->streams[i]); (void)hipStreamDestroy(ld->streams[i]); }
     for (int i = 0; i < 64; ++i) {
@@ -3342,6 +3378,13 @@ int gvl_loader_destroy(gvl_loader *ld) {
 
 int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int32_t drop_last, void *stream) {
     if (!ld || n < 0 || (n > 0 && !order)) return fail(GVL_ERR_INVALID, "%s", "gvl_loader_start_epoch: bad arguments");
+    std::unique_lock<std::mutex> lk;
+    if (ld->sync) {      // park the producer: no submit may be in progress while the epoch changes
+        lk = std::unique_lock<std::mutex>(ld->sync->mu);
+        ld->sync->active = false;
+        ld->sync->cv_consumer.wait(lk, [&] { return !ld->sync->busy; });
+        ld->sync->err = GVL_OK;
+    }
     if (ld->submitted != ld->consumed)   // an abandoned epoch: let its batches drain before slots are reused
         for (int i = 0; i < ld->cfg.in_flight; ++i) (void)hipStreamSynchronize(ld->streams[i]);
     const i64 bs = ld->cfg.batch_size;
@@ -3351,6 +3394,11 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
     if (hipEventRecord(ld->epoch_ready, (hipStream_t)stream) != hipSuccess)
         return fail(GVL_ERR_HIP, "%s", "gvl_loader_start_epoch: hipEventRecord failed");
     for (int i = 0; i < 16; ++i) ld->stream_synced[i] = false;
+    if (ld->sync) {
+        ld->sync->active = true;
+        lk.unlock();
+        ld->sync->cv_producer.notify_all();
+    }
     return GVL_OK;
 }
 
@@ -3405,9 +3453,66 @@ static int loader_submit(gvl_loader *ld, i64 j) {
     return GVL_OK;
 }
 
+static void loader_producer_main(gvl_loader *ld) {
+    LoaderSync *sy = ld->sync;
+    (void)hipSetDevice(sy->device);
+    std::unique_lock<std::mutex> lk(sy->mu);
+    for (;;) {
+        sy->cv_producer.wait(lk, [&] {
+            return sy->stop || (sy->active && sy->err == GVL_OK && ld->submitted < ld->n_batches &&
+                                ld->submitted - ld->consumed < ld->cfg.in_flight);
+        });
+        if (sy->stop) break;
+        const i64 j = ld->submitted;
+        sy->busy = true;
+        lk.unlock();
+        const int rc = loader_submit(ld, j);           // HIP calls outside the lock
+        lk.lock();
+        sy->busy = false;
+        if (rc) {
+            sy->err = rc;
+            snprintf(sy->msg, sizeof(sy->msg), "%s", g_err);    // g_err is this thread's
+        } else {
+            ld->submitted = j + 1;
+        }
+        sy->cv_consumer.notify_all();
+    }
+}
+
+static int loader_next_threaded(gvl_loader *ld, hipStream_t cs, gvl_loader_batch *out) {
+    LoaderSync *sy = ld->sync;
+    if (ld->prev_slot >= 0) {
+        if (hipEventRecord(ld->released[ld->prev_slot], cs) != hipSuccess) return fail(GVL_ERR_HIP, "%s", "gvl_loader_next: hipEventRecord failed");
+        ld->prev_slot = -1;
+    }
+    memset(out, 0, sizeof(*out));
+    i64 j;
+    {
+        std::unique_lock<std::mutex> lk(sy->mu);
+        if (ld->consumed >= ld->n_batches) { out->slot = -1; return GVL_OK; }
+        sy->cv_consumer.wait(lk, [&] { return sy->err != GVL_OK || ld->submitted > ld->consumed; });
+        if (sy->err != GVL_OK && ld->submitted <= ld->consumed) {
+            snprintf(g_err, sizeof(g_err), "%s", sy->msg);
+            return sy->err;
+        }
+        j = ld->consumed;
+    }
+    const int slot = (int)(j % ld->cfg.n_slots);
+    if (hipStreamWaitEvent(cs, ld->done[slot], 0) != hipSuccess) return fail(GVL_ERR_HIP, "%s", "gvl_loader_next: hipStreamWaitEvent failed");
+    loader_parts(ld, slot, j, out);
+    ld->prev_slot = slot;
+    {
+        std::lock_guard<std::mutex> lk(sy->mu);
+        ld->consumed = j + 1;           // the window moves: the producer may submit one more
+    }
+    sy->cv_producer.notify_one();
+    return GVL_OK;
+}
+
 int gvl_loader_next(gvl_loader *ld, void *consumer_stream, gvl_loader_batch *out) {
     if (!ld || !out) return fail(GVL_ERR_INVALID, "%s", "gvl_loader_next: NULL argument");
     hipStream_t cs = (hipStream_t)consumer_stream;
+    if (ld->sync) return loader_next_threaded(ld, cs, out);
     if (ld->prev_slot >= 0) {   // the consumer is done with the previous batch once its queued work has run
         if (traced("record released", [&] { return hipEventRecord(ld->released[ld->prev_slot], cs); }) != hipSuccess) return fail(GVL_ERR_HIP, "%s", "gvl_loader_next: hipEventRecord failed");
         ld->prev_slot = -1;

@@ -183,13 +183,14 @@ class DeviceHapsDataset:
 
     def to_dataloader(self, batch_size: int = 1, shuffle: bool = False, sampler=None, drop_last: bool = False,
                       generator: torch.Generator | None = None, in_flight: int = 3, rank: int = 0,
-                      world_size: int = 1, seed: int = 0) -> "DeviceLoader":
+                      world_size: int = 1, seed: int = 0, threaded: bool = False) -> "DeviceLoader":
         """``Dataset.to_dataloader`` (``_impl.py:1963-2072``) for device consumers.  With
         ``world_size > 1`` the epoch is sharded across ranks like ``DistributedSampler``
         (:func:`genvarloader_amd.sharding.epoch_order`): same permutation on every rank, disjoint
-        strided shares, no collective."""
+        strided shares, no collective.  ``threaded=True``: a producer thread inside the library
+        submits the batches (launches overlap the consumer's own host work per batch)."""
         return DeviceLoader(self, batch_size, shuffle, sampler, drop_last, generator, in_flight, rank, world_size,
-                            seed)
+                            seed, threaded)
 
 
 class DeviceLoader:
@@ -206,7 +207,8 @@ class DeviceLoader:
     its memory."""
 
     def __init__(self, ds: DeviceHapsDataset, batch_size=1, shuffle=False, sampler=None, drop_last=False,
-                 generator=None, in_flight=3, rank=0, world_size=1, seed=0):
+                 generator=None, in_flight=3, rank=0, world_size=1, seed=0, threaded=False):
+        self.threaded = bool(threaded)
         self.ds, self.batch_size, self.shuffle, self.drop_last = ds, int(batch_size), shuffle, drop_last
         self.sampler, self.generator = sampler, generator
         self.rank, self.world_size, self.seed, self.epoch = int(rank), int(world_size), int(seed), 0
@@ -233,7 +235,7 @@ class DeviceLoader:
             batch_size=self.batch_size, output_length=ds.output_length, jitter=ds.jitter, rc_neg=int(ds.rc_neg),
             deterministic=int(ds.deterministic), seed=ds.seed, want_haps=int(ds.haps), want_onehot=int(ds.onehot),
             onehot_layout=_lib.GVL_ONEHOT_LC if ds.layout == "lc" else _lib.GVL_ONEHOT_CL, in_flight=self.in_flight,
-            n_slots=n_slots, slot_arenas=None)
+            n_slots=n_slots, slot_arenas=None, threaded=int(self.threaded))
         parts = (C.c_int64 * 7)()
         nbytes = int(lib.gvl_loader_slot_bytes(C.byref(cfg), parts))
         if nbytes <= 0:

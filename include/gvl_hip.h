@@ -299,6 +299,8 @@ typedef struct gvl_loader_config {
     int32_t in_flight;           /* batches submitted ahead, one HIP stream each: 1..16 */
     int32_t n_slots;             /* ring slots: in_flight + 1 .. 64 */
     void *const *slot_arenas;    /* HOST array of n_slots device pointers */
+    int32_t threaded;            /* != 0: a producer thread of the library submits the batches, so that the
+                                    launches overlap the caller's own per-batch host work */
 } gvl_loader_config;
 
 typedef struct gvl_loader_batch {

@@ -271,3 +271,51 @@ def test_cfg5_epoch_full_size_properties_and_sampled_parity(oracle):
             st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, L, None, None, to_rc, False, onehot=True, n_threads=8)
         np.testing.assert_array_equal(hp.ravel(), exp)
         np.testing.assert_array_equal(oh.reshape(-1, 4), exp_oh)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(120)
+def test_threaded_loader_matches_inline_loader_and_survives_abandoned_epochs(oracle):
+    """threaded=True (a producer thread submits the batches): same batches as the inline loop for
+    the same seed, over several epochs, with a lagging consumer, after an epoch abandoned half way,
+    and the loader can be dropped while batches are still in flight."""
+    from genvarloader_amd import HapsDevice
+    from genvarloader_amd.loader import DeviceHapsDataset
+
+    R, S, P, L = 6, 10, 2, 256
+    st, full_regions, go, gv = _grid_dataset(31, R, S, P, L, indel_frac=0.3)
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+    ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, onehot=False, haps=True, jitter=2,
+                           deterministic=False, seed=4)
+
+    def run(threaded, epochs):
+        ds._counter = 0
+        dl = ds.to_dataloader(batch_size=4, shuffle=True, seed=9, in_flight=2, threaded=threaded)
+        res = []
+        lag = torch.zeros(1 << 20, device="cuda")
+        for e in epochs:
+            dl.set_epoch(e)
+            for bi, batch in enumerate(dl):
+                lag.add_(1.0)
+                res.append((batch.idx.clone(), batch.regions.clone(), batch.shifts.clone(), batch.haps.clone()))
+        torch.cuda.synchronize()
+        return dl, res
+
+    _, a = run(False, [0, 1, 2])
+    dl_t, b = run(True, [0, 1, 2])
+    assert len(a) == len(b) == 3 * 15
+    for x, y in zip(a, b):
+        for t, u in zip(x, y):
+            assert torch.equal(t, u)
+    # abandon an epoch half way, start another one, then drop the loader with work in flight
+    it = iter(dl_t)
+    for _ in range(5):
+        next(it)
+    del it
+    dl_t.set_epoch(0)
+    first = next(iter(dl_t))
+    assert torch.equal(first.idx, a[0][0])
+    del dl_t
+    torch.cuda.synchronize()

@@ -19,8 +19,8 @@ dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, i
                  alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv, pad_char=st.pad_char)
 for det in (True, False):
     ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, jitter=0 if det else 16, deterministic=det, seed=1)
-    for in_flight, gen in ((1, None), (3, None), (3, torch.Generator().manual_seed(0)), (4, None)):
-        dl = ds.to_dataloader(batch_size=bs, shuffle=True, generator=gen, in_flight=in_flight)
+    for in_flight, gen, thr in ((1, None, False), (3, None, False), (3, None, True), (3, torch.Generator().manual_seed(0), False)):
+        dl = ds.to_dataloader(batch_size=bs, shuffle=True, generator=gen, in_flight=in_flight, threaded=thr)
         for rep in range(3):                        # first pass warms up
             torch.cuda.synchronize(); t0 = time.perf_counter(); n = 0; t_first = None
             for batch in dl:
@@ -30,6 +30,6 @@ for det in (True, False):
             t_issue = time.perf_counter()
             torch.cuda.synchronize(); t1 = time.perf_counter()
         dt = t1 - t0
-        print(f"deterministic={det} in_flight={in_flight} {'cpu-shuffle' if gen is not None else 'dev-shuffle'}: {n} windows in {dt*1e3:.1f} ms -> {n/dt/1e6:.1f} M windows/s; "
+        print(f"deterministic={det} in_flight={in_flight} {'cpu-shuffle' if gen is not None else 'dev-shuffle'}{' threaded' if thr else ''}: {n} windows in {dt*1e3:.1f} ms -> {n/dt/1e6:.1f} M windows/s; "
               f"first batch after {1e3*(t_first-t0):.1f} ms, loop {1e6*(t_issue-t_first)/max(1,len(dl)-1):.1f} us/batch host, "
               f"steady {1e6*(t1-t_first)/max(1,len(dl)-1):.1f} us per {bs*P}-window batch")
