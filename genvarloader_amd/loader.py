@@ -300,17 +300,18 @@ class DeviceLoader:
                                                   C.c_int32(int(self.drop_last)), C.c_void_p(cur.cuda_stream)))
             nat["order"] = order                       # keep the epoch order alive
             nxt, ref_out, bs = lib.gvl_loader_next, C.byref(out), self.batch_size
-            pos = 0
+            idx_views = order.split(bs) if n else ()          # one C++ loop instead of a slice per batch
+            cur_stream, views, vp = torch.cuda.current_stream, self._slot_views, C.c_void_p
+            i = 0
             while True:
-                rc = nxt(handle, C.c_void_p(torch.cuda.current_stream(d).cuda_stream), ref_out)
+                rc = nxt(handle, vp(cur_stream(d).cuda_stream), ref_out)
                 if rc:
                     _lib.check(rc)
                 if out.slot < 0:
                     return
-                b = out.batch
-                batch = self._slot_views(out.slot, b)
-                batch.idx = order[pos:pos + b]
-                pos += bs
+                batch = views(out.slot, out.batch)
+                batch.idx = idx_views[i]
+                i += 1
                 yield batch
 
     def __del__(self):
