@@ -1925,6 +1925,7 @@ struct DiffArgs {
     const i64 *geno_offset_idx; i64 n_rows; int ploidy;
     const int *geno_v_idxs; const i64 *go_starts; const i64 *go_stops;
     const int *ilens; const int *v_starts; i64 n_variants;
+    const gvl_grec *grec;       // nullable: (pos, ilen) next to the CSR entry, one read instead of three
     const u8 *keep; const i64 *keep_offsets;
     const int *q_starts; const int *q_ends; i64 q_stride;
     int *diffs;
@@ -1932,24 +1933,25 @@ struct DiffArgs {
     i64 output_length; i64 *lengths;
 };
 
-__device__ __forceinline__ i64 row_diff(const DiffArgs &A, i64 k) {
-    const i64 query = k / A.ploidy;
-    const i64 o_idx = A.geno_offset_idx[k];
+// length delta of one haplotype (genotype slot o_idx; keep slice at ks; optional query window)
+__device__ __forceinline__ i64 row_diff_core(const DiffArgs &A, const i64 o_idx, const bool has_keep, const i64 ks,
+                                             const bool has_query, const i64 q_start, const i64 q_end) {
     const i64 o_s = A.go_starts[o_idx], o_e = A.go_stops[o_idx];
-    const bool has_query = A.q_starts && A.q_ends && A.v_starts;   // mod.rs:35
-    const bool has_keep = A.keep && A.keep_offsets;                // mod.rs:36
     i64 acc = 0;
     if (o_e - o_s <= 0) return 0;
-    const i64 ks = has_keep ? A.keep_offsets[k] : 0;
     if (has_query) {                                               // mod.rs:48-85
-        const i64 q_start = A.q_starts[query * A.q_stride];
-        const i64 q_end = A.q_ends[query * A.q_stride];
         i64 ref_idx = q_start;
         for (i64 v = o_s; v < o_e; ++v) {
             if (has_keep && !A.keep[ks + (v - o_s)]) continue;
-            const i64 vi = A.geno_v_idxs[v];
-            const i64 vs = A.v_starts[vi];
-            i64 il = A.ilens[vi];
+            i64 vs, il;
+            if (A.grec) {
+                const int2 r = *reinterpret_cast<const int2 *>(A.grec + v);
+                vs = r.x; il = r.y;
+            } else {
+                const i64 vi = A.geno_v_idxs[v];
+                vs = A.v_starts[vi];
+                il = A.ilens[vi];
+            }
             const i64 v_end = vs - imin(il, 0) + 1;
             if (v_end <= q_start) continue;
             if (vs >= q_end) break;
@@ -1962,10 +1964,20 @@ __device__ __forceinline__ i64 row_diff(const DiffArgs &A, i64 k) {
     } else {                                                       // mod.rs:86-103
         for (i64 v = o_s; v < o_e; ++v) {
             if (has_keep && !A.keep[ks + (v - o_s)]) continue;
-            acc += A.ilens[A.geno_v_idxs[v]];
+            acc += A.grec ? (i64)A.grec[v].ilen : (i64)A.ilens[A.geno_v_idxs[v]];
         }
     }
     return acc;
+}
+
+__device__ __forceinline__ i64 row_diff(const DiffArgs &A, i64 k) {
+    const i64 query = k / A.ploidy;
+    const bool has_query = A.q_starts && A.q_ends && A.v_starts;   // mod.rs:35
+    const bool has_keep = A.keep && A.keep_offsets;                // mod.rs:36
+    const i64 ks = has_keep ? A.keep_offsets[k] : 0;
+    const i64 q_start = has_query ? (i64)A.q_starts[query * A.q_stride] : 0;
+    const i64 q_end = has_query ? (i64)A.q_ends[query * A.q_stride] : 0;
+    return row_diff_core(A, A.geno_offset_idx[k], has_keep, ks, has_query, q_start, q_end);
 }
 
 __global__ __launch_bounds__(256) void diffs_kernel(const DiffArgs A, const int *regions,
@@ -2777,8 +2789,12 @@ struct PrepArgs {
 };
 
 __global__ __launch_bounds__(256) void prepare_request_kernel(const PrepArgs A) {
-    const i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= A.batch) return;
+    // one thread per (query, haplotype): the haplotypes of a query repeat the query's few loads
+    // (same cache lines) instead of walking their variants one after the other in one thread
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.batch * A.ploidy) return;
+    const i64 b = k / A.ploidy;
+    const int p = (int)(k - b * A.ploidy);
     i64 id = A.idx[b];
     const i64 n = A.n_regions * A.n_samples;
     id = id < 0 ? 0 : (id >= n ? n - 1 : id);
@@ -2791,26 +2807,23 @@ __global__ __launch_bounds__(256) void prepare_request_kernel(const PrepArgs A) 
         start += (int)(h % (u64)(2 * A.jitter + 1)) - A.jitter;
         end = start + len;
     }
-    int *dst = A.regions + b * 4;
-    dst[0] = src[0]; dst[1] = start; dst[2] = end; dst[3] = src[3];
-    const u8 rc = (A.rc_neg && src[3] == -1) ? 1 : 0;               // _query.py:173-175
-    for (int p = 0; p < A.ploidy; ++p) {
-        const i64 k = b * A.ploidy + p;
-        A.goi[k] = (r * A.n_samples + s) * A.ploidy + p;            // _haps.py:757-768
-        A.to_rc[k] = rc;
-        int shift = 0;
-        if (!A.deterministic) {                                     // _haps.py:723-730
-            // length delta of this haplotype inside the (jittered) window: genotypes/mod.rs:48-85
-            DiffArgs D = A.D;
-            D.geno_offset_idx = A.goi; D.ploidy = A.ploidy;
-            D.q_starts = A.regions + 1; D.q_ends = A.regions + 2; D.q_stride = 4;
-            const i64 diff = (i64)(int)row_diff(D, k);
-            const i64 max_shift = (diff > 0 ? diff : 0) + ((i64)len - A.output_length > 0 ? (i64)len - A.output_length : 0);
-            const u64 h = hash4_dev(A.seed, A.counter, (u64)k, 0x7368696674ull);
-            shift = (int)(h % (u64)(max_shift + 1));
-        }
-        A.shifts[k] = shift;
+    if (p == 0) {
+        int *dst = A.regions + b * 4;
+        dst[0] = src[0]; dst[1] = start; dst[2] = end; dst[3] = src[3];
     }
+    const u8 rc = (A.rc_neg && src[3] == -1) ? 1 : 0;               // _query.py:173-175
+    const i64 goi = (r * A.n_samples + s) * A.ploidy + p;           // _haps.py:757-768
+    A.goi[k] = goi;
+    A.to_rc[k] = rc;
+    int shift = 0;
+    if (!A.deterministic) {                                         // _haps.py:723-730
+        // length delta of this haplotype inside the (jittered) window: genotypes/mod.rs:48-85
+        const i64 diff = (i64)(int)row_diff_core(A.D, goi, false, 0, true, (i64)start, (i64)end);
+        const i64 max_shift = (diff > 0 ? diff : 0) + ((i64)len - A.output_length > 0 ? (i64)len - A.output_length : 0);
+        const u64 h = hash4_dev(A.seed, A.counter, (u64)k, 0x7368696674ull);
+        shift = (int)(h % (u64)(max_shift + 1));
+    }
+    A.shifts[k] = shift;
 }
 
 // ---------------------------------------------------------------------------
@@ -3026,6 +3039,7 @@ static int fill_diff_args(DiffArgs &D, const gvl_static *st, const gvl_batch *bt
     D.geno_offset_idx = (const i64 *)bt->geno_offset_idx; D.n_rows = bt->batch * bt->ploidy;
     D.ploidy = (int)bt->ploidy;
     D.geno_v_idxs = st->geno_v_idxs; D.go_starts = (const i64 *)st->geno_o_starts;
+    D.grec = (debug_flags() & 16) ? nullptr : st->geno_rec;
     D.go_stops = (const i64 *)st->geno_o_stops; D.ilens = st->ilens; D.v_starts = st->v_starts;
     D.n_variants = st->n_variants; D.keep = bt->keep; D.keep_offsets = (const i64 *)bt->keep_offsets;
     if (bt->batch > 0 && (!D.geno_offset_idx || !D.go_starts || !D.go_stops))
@@ -3256,6 +3270,7 @@ int gvl_prepare_request(const gvl_static *st, const int64_t *idx, int64_t batch,
         if (!st || !st->geno_o_starts || !st->geno_o_stops || (st->n_geno > 0 && (!st->geno_v_idxs || !st->ilens || !st->v_starts)))
             return fail(GVL_ERR_INVALID, "%s", "gvl_prepare_request: random shifts need the genotype CSR + variant table");
         P.D.geno_v_idxs = st->geno_v_idxs; P.D.go_starts = (const i64 *)st->geno_o_starts;
+        P.D.grec = (debug_flags() & 16) ? nullptr : st->geno_rec;
         P.D.go_stops = (const i64 *)st->geno_o_stops; P.D.ilens = st->ilens; P.D.v_starts = st->v_starts;
         P.D.n_variants = st->n_variants; P.D.n_rows = batch * ploidy;
     }
@@ -3263,7 +3278,7 @@ int gvl_prepare_request(const gvl_static *st, const int64_t *idx, int64_t batch,
     P.n_samples = n_samples; P.ploidy = (int)ploidy; P.jitter = (int)jitter; P.rc_neg = rc_neg;
     P.deterministic = deterministic; P.output_length = output_length; P.seed = seed; P.counter = counter;
     P.regions = regions_out; P.goi = (i64 *)geno_offset_idx_out; P.to_rc = to_rc_out; P.shifts = shifts_out;
-    const i64 grid = (batch + 255) / 256;
+    const i64 grid = (batch * ploidy + 255) / 256;
     if (grid > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_prepare_request: batch too large");
     prepare_request_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(P);
     return check_launch("gvl_prepare_request");
