@@ -193,6 +193,102 @@ class DeviceHapsDataset:
                             seed, threaded)
 
 
+@dataclass
+class TrackBatch(Batch):
+    tracks: torch.Tensor | None = None     # (b, n_tracks, P, L) f32, realigned to each haplotype
+
+
+class DeviceHapsTracksDataset(DeviceHapsDataset):
+    """Haplotypes + realigned tracks (BASELINE config 4's shape), everything on the device.
+
+    ``tracks``: ``{name: (itv_starts i32, itv_ends i32, itv_values f32, itv_offsets i64)}`` with one
+    interval list per (region, sample), list index ``region * n_samples + sample`` -- the
+    reference's per-track interval store (``RaggedIntervals``, ``_dataset/_tracks.py``).  Per
+    batch and track: paint the query's intervals into a scratch track of the reference's length
+    ``len - min_p(min(diff, 0))`` (``_reconstruct.py:191``; computed on the device), then realign it to every
+    haplotype with the insertion-fill strategy (``intervals_and_realign_track_fused``,
+    ``src/ffi/mod.rs:2551-2672``); negative-strand rows are reversed.  No host sync per batch.
+    Batches own their memory (random access / custom samplers / ``DeviceLoader``'s Python loop)."""
+
+    def __init__(self, dev, regions, n_samples, ploidy, *, tracks: dict, strategy_id: int = 0, param: float = 0.0,
+                 base_seed: int = 0, **kw):
+        super().__init__(dev, regions, n_samples, ploidy, **kw)
+        from . import device as _device
+
+        d = dev.device
+        self.strategy_id, self.param, self.base_seed = int(strategy_id), float(param), int(base_seed)
+        self.track_names = list(tracks)
+        self._itv = []
+        n_lists = self.n_regions * self.n_samples
+        for name in self.track_names:
+            a, b, v, io = tracks[name]
+            a = torch.as_tensor(np.ascontiguousarray(a, np.int32)).to(d)
+            b = torch.as_tensor(np.ascontiguousarray(b, np.int32)).to(d)
+            v = torch.as_tensor(np.ascontiguousarray(v, np.float32)).to(d)
+            io = torch.as_tensor(np.ascontiguousarray(io, np.int64)).to(d)
+            if int(io.numel()) != n_lists + 1:
+                raise ValueError(f"track {name!r}: itv_offsets must have regions x samples + 1 entries")
+            pm = _device.intervals_prefix_max(b, io, d) if int(b.numel()) else None
+            self._itv.append((a, b, v, io, pm))
+        reg = self.full_regions
+        max_len = int((reg[:, 2] - reg[:, 1]).max().item()) if self.n_regions else 0
+        # scratch track per query: len - min(diff, 0) <= 2 * len (a window cannot lose more than itself)
+        self._stride = 2 * max(max_len + 2 * self.jitter, 1)
+
+    def __getitem__(self, idx) -> TrackBatch:
+        import ctypes as C
+
+        from . import _lib
+        from . import device as _device
+        from .device import _ptr, _stream_ptr
+
+        base = super().__getitem__(idx)
+        dev, d = self.dev, self.dev.device
+        b, P, L = int(base.idx.numel()), self.ploidy, self.output_length
+        if b == 0 or not self._itv:
+            return TrackBatch(base.onehot, base.haps, base.idx, base.regions, base.shifts, base.geno_offset_idx,
+                              base.to_rc, None)
+        K = b * P
+        out_offsets = torch.arange(K + 1, dtype=torch.int64, device=d) * L
+        qs = base.regions[:, 1].contiguous()
+        qe = base.regions[:, 2].contiguous()
+        # the reference's scratch track length per query (_reconstruct.py:191): len - min_p(min(diff, 0))
+        diffs = dev.get_diffs_sparse(base.geno_offset_idx, q_starts=qs, q_ends=qe)
+        tlen = (qe - qs).to(torch.int64) - diffs.min(dim=1).values.clamp(max=0).to(torch.int64)
+        track_offsets = torch.zeros(b + 1, dtype=torch.int64, device=d)
+        torch.cumsum(tlen, 0, out=track_offsets[1:])
+        offset_idxs = base.idx                                   # list index = region * S + sample = dataset index
+        bt = dev.prepare_batch(base.regions, base.shifts, base.geno_offset_idx, -1, None, None, base.to_rc,
+                               out_offsets, max_row_len=L)
+        par = (C.c_double * 1)(self.param)
+        tracks = torch.empty((len(self._itv), K * L), dtype=torch.float32, device=d)
+        scratch = torch.empty(b * self._stride, dtype=torch.float32, device=d)
+        with torch.cuda.device(d):
+            for t, (a, e, v, io, pm) in enumerate(self._itv):
+                _lib.check(dev.lib.gvl_intervals_to_tracks(
+                    _ptr(offset_idxs), _ptr(qs), C.c_int64(1), C.c_int64(b), _ptr(a), _ptr(e), _ptr(v), _ptr(io),
+                    C.c_int64(int(a.numel())), _ptr(pm), _ptr(scratch), _ptr(track_offsets), C.c_int64(self._stride),
+                    _stream_ptr()))
+                _lib.check(dev.lib.gvl_realign_tracks(
+                    C.byref(dev.c), C.byref(bt.c), _ptr(scratch), _ptr(track_offsets), par, C.c_int64(self.strategy_id),
+                    C.c_uint64(self.base_seed & 0xFFFFFFFFFFFFFFFF), _ptr(tracks[t]), _stream_ptr()))
+        out = TrackBatch(base.onehot, base.haps, base.idx, base.regions, base.shifts, base.geno_offset_idx, base.to_rc,
+                         tracks.view(len(self._itv), b, P, L).permute(1, 0, 2, 3))
+        out._arena = base._arena
+        out._keep = (bt, scratch, out_offsets, track_offsets, qs)
+        return out
+
+    def to_dataloader(self, batch_size: int = 1, shuffle: bool = False, sampler=None, drop_last: bool = False,
+                      generator=None, in_flight: int = 2, **kw) -> "DeviceLoader":
+        """Tracks go through the Python submit loop (each batch owns its memory)."""
+        if sampler is None:
+            n = len(self)
+            order = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
+            sampler = [order[s:s + batch_size] for s in range(0, n, batch_size)
+                       if not (drop_last and s + batch_size > n)]
+        return DeviceLoader(self, batch_size, False, sampler, drop_last, None, in_flight)
+
+
 class DeviceLoader:
     """Iterates batches of a :class:`DeviceHapsDataset`, ``in_flight`` batches ahead, each on
     its own HIP stream; the consumer's current stream waits on the batch's event.

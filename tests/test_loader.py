@@ -319,3 +319,59 @@ def test_threaded_loader_matches_inline_loader_and_survives_abandoned_epochs(ora
     assert torch.equal(first.idx, a[0][0])
     del dl_t
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_haps_tracks_dataset_matches_oracle(oracle):
+    """cfg4's dataset shape at a small size: haplotypes + two realigned tracks per batch from dataset
+    indices, against the oracle's fused paint + realign for the same request."""
+    from genvarloader_amd import HapsDevice
+    from genvarloader_amd.loader import DeviceHapsTracksDataset
+
+    R, S, P, L = 5, 6, 2, 700
+    st, full_regions, go, gv = _grid_dataset(41, R, S, P, L, indel_frac=0.4, slack=30)
+    rng = np.random.default_rng(4)
+    tracks = {}
+    for name in ("cov", "atac"):
+        starts, ends, vals, offs = [], [], [], [0]
+        for r in range(R):
+            for s_ in range(S):
+                pos = int(full_regions[r, 1]) - int(rng.integers(0, 60))
+                while pos < int(full_regions[r, 2]) + 40:
+                    w, gap = int(rng.geometric(1 / 20)), int(rng.integers(0, 6))
+                    starts.append(pos + gap); ends.append(pos + gap + w); vals.append(float(rng.random() * 5)); pos += gap + w
+                offs.append(len(starts))
+        tracks[name] = (np.array(starts, np.int32), np.array(ends, np.int32), np.array(vals, np.float32), np.array(offs, np.int64))
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+    for strategy, param in ((0, 0.0), (4, 3.0)):
+        ds = DeviceHapsTracksDataset(dev, full_regions, S, P, tracks=tracks, strategy_id=strategy, param=param,
+                                     base_seed=11, output_length=L, onehot=False, haps=True)
+        seen = 0
+        for batch in ds.to_dataloader(batch_size=7, shuffle=True, generator=torch.Generator().manual_seed(1)):
+            idx = batch.idx.cpu().numpy()
+            r_idx, s_idx = np.unravel_index(idx, (R, S))
+            regions = full_regions[r_idx]
+            goi = np.ravel_multi_index((r_idx[:, None], s_idx[:, None], np.arange(P)), (R, S, P))
+            to_rc = np.repeat(regions[:, 3] == -1, P)
+            shifts = np.zeros_like(goi, dtype=np.int32)
+            exp_h, _ = oracle.reconstruct_haplotypes_fused(
+                regions, shifts, goi, go, gv, st.v_starts, st.ilens, st.alt_alleles, st.alt_offsets, st.ref,
+                st.ref_offsets, st.pad_char, L, None, None, to_rc, False)
+            np.testing.assert_array_equal(batch.haps.cpu().numpy().ravel(), exp_h)
+            diffs = oracle.get_diffs_sparse(goi, gv, go, st.ilens, None, None, regions[:, 1], regions[:, 2], st.v_starts)
+            tlen = (regions[:, 2] - regions[:, 1]).astype(np.int64) - np.minimum(diffs.min(axis=1), 0)
+            track_offsets = np.concatenate([[0], np.cumsum(tlen)]).astype(np.int64)
+            out_offsets = np.arange(len(idx) * P + 1, dtype=np.int64) * L
+            assert batch.tracks.shape == (len(idx), 2, P, L)
+            for t, name in enumerate(("cov", "atac")):
+                a, e, v, io = tracks[name]
+                exp = np.zeros(len(idx) * P * L, np.float32)
+                oracle.intervals_and_realign_track_fused(
+                    exp, out_offsets, regions, shifts, goi, gv, go, st.v_starts, st.ilens, idx.astype(np.int64), a, e, v, io,
+                    track_offsets, np.array([param]), strategy, 11, None, None, to_rc)
+                got = batch.tracks[:, t].contiguous().cpu().numpy().ravel()
+                np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32), err_msg=f"{name} strategy {strategy}")
+            seen += len(idx)
+        assert seen == R * S
