@@ -53,8 +53,8 @@ GVLO_EXPORT void gvlo_reconstruct_row(
         shifted = min64(shift, raw);
         int64_t n = raw - shifted;
         int64_t e = min64(n, length); /* Rust would panic if n > length */
-        for (int64_t j = 0; j < e; j++) {
-            out[j] = pad_char;
+        if (e > 0) memset(out, pad_char, (size_t)e); /* out[..n].fill(pad_char) */
+        for (int64_t j = 0; (av || ap) && j < e; j++) {
             if (av) av[j] = -1;
             if (ap) ap[j] = -1;
         }
@@ -104,18 +104,25 @@ GVLO_EXPORT void gvlo_reconstruct_row(
         /* reference run up to the variant: mod.rs:153-175 */
         int64_t n = v_pos - ref_idx;
         if (out_idx + n >= length) break; /* NB ">=" */
-        for (int64_t j = 0; j < n; j++) {
-            int64_t r = ref_idx + j;
-            out[out_idx + j] = (r >= 0 && r < ref_len) ? ref[r] : pad_char;
+        if (ref_idx >= 0 && ref_idx + n <= ref_len) {
+            /* copy_from_slice(&ref_[ref_idx..ref_idx + n]): mod.rs:164 */
+            if (n > 0) memcpy(out + out_idx, ref + ref_idx, (size_t)n);
+        } else { /* out of contract (the Rust slice would panic): clamp */
+            for (int64_t j = 0; j < n; j++) {
+                int64_t r = ref_idx + j;
+                out[out_idx + j] = (r >= 0 && r < ref_len) ? ref[r] : pad_char;
+            }
+        }
+        for (int64_t j = 0; (av || ap) && j < n; j++) {
             if (av) av[out_idx + j] = -1;
-            if (ap) ap[out_idx + j] = (int32_t)r;
+            if (ap) ap[out_idx + j] = (int32_t)(ref_idx + j);
         }
         out_idx += n;
 
         /* the allele, truncated to the space left: mod.rs:178-190 */
         int64_t w = min64(v_len, length - out_idx);
-        for (int64_t j = 0; j < w; j++) {
-            out[out_idx + j] = allele[j];
+        if (w > 0) memcpy(out + out_idx, allele, (size_t)w);
+        for (int64_t j = 0; (av || ap) && j < w; j++) {
             if (av) av[out_idx + j] = (int32_t)variant;
             if (ap) ap[out_idx + j] = (int32_t)v_pos;
         }
@@ -136,15 +143,15 @@ GVLO_EXPORT void gvlo_reconstruct_row(
         int64_t w = min64(unfilled, ref_len - ref_idx);
         int64_t end = out_idx;
         if (w > 0) {
-            for (int64_t j = 0; j < w; j++) {
-                out[out_idx + j] = ref[ref_idx + j];
+            memcpy(out + out_idx, ref + ref_idx, (size_t)w);
+            for (int64_t j = 0; (av || ap) && j < w; j++) {
                 if (av) av[out_idx + j] = -1;
                 if (ap) ap[out_idx + j] = (int32_t)(ref_idx + j);
             }
             end = out_idx + w;
         }
-        for (int64_t j = end; j < length; j++) {
-            out[j] = pad_char;
+        if (end < length) memset(out + end, pad_char, (size_t)(length - end));
+        for (int64_t j = end; (av || ap) && j < length; j++) {
             if (av) av[j] = -1;
             if (ap) ap[j] = INT32_MAX;
         }
@@ -230,14 +237,23 @@ typedef struct {
     uint8_t *onehot;
 } batch_args;
 
+static uint32_t g_oh_lut[256];
+static pthread_once_t g_oh_once = PTHREAD_ONCE_INIT;
+static void oh_lut_init(void)
+{
+    /* little-endian dword {b=='A', b=='C', b=='G', b=='T'} */
+    g_oh_lut['A'] = 0x00000001u;
+    g_oh_lut['C'] = 0x00000100u;
+    g_oh_lut['G'] = 0x00010000u;
+    g_oh_lut['T'] = 0x01000000u;
+}
+
 static void onehot_row(const uint8_t *in, int64_t n, uint8_t *out)
 {
+    pthread_once(&g_oh_once, oh_lut_init);
     for (int64_t j = 0; j < n; j++) {
-        uint8_t b = in[j];
-        out[4 * j + 0] = (b == 'A');
-        out[4 * j + 1] = (b == 'C');
-        out[4 * j + 2] = (b == 'G');
-        out[4 * j + 3] = (b == 'T');
+        uint32_t d = g_oh_lut[in[j]];
+        memcpy(out + 4 * j, &d, 4);
     }
 }
 
@@ -262,6 +278,12 @@ static void batch_row(const batch_args *a, int64_t k)
     if (a->onehot) onehot_row(a->out + out_s, out_e - out_s, a->onehot + 4 * out_s);
 }
 
+/* Persistent worker pool.  rayon's global pool (sized once from RAYON_NUM_THREADS,
+ * _threads.py:102-115) keeps its workers parked between par_iter calls; so does this
+ * one: workers sleep on a condition variable, a job is (fn, n rows, chunk) with an
+ * atomic cursor, the caller works too and then waits for the stragglers.  Rows are
+ * handed out in chunks of n / (threads * 8) like rayon's adaptive splitting of the
+ * row range (reconstruct/mod.rs:424-539). */
 typedef struct {
     const void *args;
     void (*fn)(const void *, int64_t);
@@ -270,16 +292,79 @@ typedef struct {
     int64_t next; /* atomic cursor */
 } pool_job;
 
-static void *pool_worker(void *p)
+static pthread_mutex_t g_job_mu = PTHREAD_MUTEX_INITIALIZER; /* one job at a time */
+static struct {
+    pthread_mutex_t mu;
+    pthread_cond_t cv_work, cv_done;
+    pthread_t *th;
+    int n_workers;      /* threads besides the caller */
+    uint64_t generation; /* bumped per job */
+    int pending;         /* workers that have not finished the current job */
+    int stop;
+    pool_job *job;
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER,
+            NULL, 0, 0, 0, 0, NULL};
+
+static void job_drain(pool_job *job)
 {
-    pool_job *job = (pool_job *)p;
     for (;;) {
         int64_t s = __atomic_fetch_add(&job->next, job->chunk, __ATOMIC_RELAXED);
         if (s >= job->n) break;
         int64_t e = min64(s + job->chunk, job->n);
         for (int64_t k = s; k < e; k++) job->fn(job->args, k);
     }
+}
+
+static void *pool_worker(void *unused)
+{
+    (void)unused;
+    uint64_t seen = 0;
+    pthread_mutex_lock(&g_pool.mu);
+    for (;;) {
+        while (!g_pool.stop && g_pool.generation == seen) pthread_cond_wait(&g_pool.cv_work, &g_pool.mu);
+        if (g_pool.stop) break;
+        seen = g_pool.generation;
+        pool_job *job = g_pool.job;
+        pthread_mutex_unlock(&g_pool.mu);
+        job_drain(job);
+        pthread_mutex_lock(&g_pool.mu);
+        if (--g_pool.pending == 0) pthread_cond_signal(&g_pool.cv_done);
+    }
+    pthread_mutex_unlock(&g_pool.mu);
     return NULL;
+}
+
+static void pool_shutdown_locked(void)
+{
+    g_pool.stop = 1;
+    pthread_cond_broadcast(&g_pool.cv_work);
+    pthread_mutex_unlock(&g_pool.mu);
+    for (int t = 0; t < g_pool.n_workers; t++) pthread_join(g_pool.th[t], NULL);
+    pthread_mutex_lock(&g_pool.mu);
+    free(g_pool.th);
+    g_pool.th = NULL;
+    g_pool.n_workers = 0;
+    g_pool.stop = 0;
+}
+
+/* (Re)size the pool to `n_threads` (the caller counts as one). */
+GVLO_EXPORT int gvlo_pool_resize(int n_threads)
+{
+    int want = n_threads > 1 ? n_threads - 1 : 0;
+    pthread_mutex_lock(&g_pool.mu);
+    if (want != g_pool.n_workers) {
+        if (g_pool.n_workers) pool_shutdown_locked();
+        if (want) {
+            g_pool.th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)want);
+            int started = 0;
+            for (int t = 0; g_pool.th && t < want; t++)
+                if (pthread_create(&g_pool.th[started], NULL, pool_worker, NULL) == 0) started++;
+            g_pool.n_workers = started;
+        }
+    }
+    int n = g_pool.n_workers + 1;
+    pthread_mutex_unlock(&g_pool.mu);
+    return n;
 }
 
 static void run_rows(const void *args, void (*fn)(const void *, int64_t),
@@ -289,14 +374,21 @@ static void run_rows(const void *args, void (*fn)(const void *, int64_t),
         for (int64_t k = 0; k < n; k++) fn(args, k);
         return;
     }
-    pool_job job = {args, fn, n, max64(1, n / ((int64_t)n_threads * 8)), 0};
-    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
-    int started = 0;
-    for (int t = 0; t < n_threads - 1; t++)
-        if (pthread_create(&th[started], NULL, pool_worker, &job) == 0) started++;
-    pool_worker(&job);
-    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
-    free(th);
+    pthread_mutex_lock(&g_job_mu);
+    int have = gvlo_pool_resize(n_threads);
+    pool_job job = {args, fn, n, max64(1, n / ((int64_t)have * 8)), 0};
+    pthread_mutex_lock(&g_pool.mu);
+    g_pool.job = &job;
+    g_pool.pending = g_pool.n_workers;
+    g_pool.generation++;
+    pthread_cond_broadcast(&g_pool.cv_work);
+    pthread_mutex_unlock(&g_pool.mu);
+    job_drain(&job);
+    pthread_mutex_lock(&g_pool.mu);
+    while (g_pool.pending > 0) pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
+    g_pool.job = NULL;
+    pthread_mutex_unlock(&g_pool.mu);
+    pthread_mutex_unlock(&g_job_mu);
 }
 
 static void batch_row_thunk(const void *a, int64_t k) { batch_row((const batch_args *)a, k); }

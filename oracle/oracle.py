@@ -54,6 +54,50 @@ def lib() -> C.CDLL:
     return _LIB
 
 
+def build_native(out_dir: str | os.PathLike | None = None) -> C.CDLL:
+    """A second copy of the oracle compiled ``-march=native`` for THIS host, written to a
+    scratch directory (never over ``libgvl_oracle.so``, which is x86-64-v3 so that it runs on
+    every box the tree travels to).  Used by ``bench.py``'s ``cpu_baseline`` only."""
+    import tempfile
+
+    d = Path(out_dir) if out_dir else Path(tempfile.mkdtemp(prefix="gvl_oracle_native_"))
+    d.mkdir(parents=True, exist_ok=True)
+    so = d / "libgvl_oracle_native.so"
+    srcs = [str(s) for s in sorted(_HERE.glob("gvl_oracle*.c"))]
+    subprocess.run(["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-fvisibility=hidden", *srcs,
+                    "-o", str(so), "-shared", "-pthread", "-lm"], check=True, capture_output=True)
+    l = C.CDLL(str(so))
+    l.gvlo_choose_exonic_variants.restype = C.c_int64
+    return l
+
+
+class BatchCall:
+    """``reconstruct_haplotypes_from_sparse`` (+ fused RC / one-hot) with every argument
+    converted ONCE, so that a timing loop measures the C code and not numpy conversions.
+    ``run(n_threads)`` is one pass over the batch."""
+
+    def __init__(self, out, out_offsets, regions, shifts, geno_offset_idx, geno_offsets, geno_v_idxs,
+                 v_starts, ilens, alt_alleles, alt_offsets, ref, ref_offsets, pad_char, *, to_rc=None,
+                 onehot_out=None, library: C.CDLL | None = None):
+        self.lib = library or lib()
+        go = _starts_stops(geno_offsets)
+        self.keep = dict(
+            out=out, oo=_c(out_offsets, np.int64), reg=_c(regions, np.int32), sh=_c(shifts, np.int32),
+            goi=_c(geno_offset_idx, np.int64), go0=np.ascontiguousarray(go[0]), go1=np.ascontiguousarray(go[1]),
+            gv=_c(geno_v_idxs, np.int32), vs=_c(v_starts, np.int32), il=_c(ilens, np.int32),
+            aa=_c(alt_alleles, np.uint8), ao=_c(alt_offsets, np.int64), rf=_c(ref, np.uint8),
+            ro=_c(ref_offsets, np.int64), rc=_c(to_rc, np.bool_), oh=onehot_out)
+        k = self.keep
+        batch, ploidy = k["goi"].shape
+        self.args = [_p(k["out"]), _p(k["oo"]), _p(k["reg"]), C.c_int64(k["reg"].shape[1]), C.c_int64(batch),
+                     C.c_int64(ploidy), _p(k["sh"]), _p(k["goi"]), _p(k["go0"]), _p(k["go1"]), _p(k["gv"]),
+                     _p(k["vs"]), _p(k["il"]), _p(k["aa"]), _p(k["ao"]), _p(k["rf"]), _p(k["ro"]),
+                     C.c_uint8(int(pad_char)), None, None, None, None, _p(k["rc"]), _p(k["oh"])]
+
+    def run(self, n_threads: int = 1) -> None:
+        self.lib.gvlo_reconstruct_batch(*self.args, C.c_int(int(n_threads)))
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
