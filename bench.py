@@ -1,20 +1,42 @@
 #!/usr/bin/env python3
 """bench.py -- haplotype windows/sec + achieved HBM GB/s on MI355X.
 
-A "step" is one pass of the hot path over one synthetic batch: ONE launch of the
-fused reconstruct -> reverse-complement -> one-hot kernel through the C-ABI
-(``gvl_reconstruct``) with every input already resident in HBM.  The default
-workload is BASELINE.json ``configs[2]`` -- 4096 windows x 2048 bp, SNP+indel,
-reverse-complement on half the rows, uint8 one-hot output -- which is the
-configuration the metric is quoted on ("4096x2048bp SNP+indel one-hot");
-``--workload cfg2`` gives the SNP-only ``configs[1]``.
+A "step" is one pass of the hot path over one synthetic batch: ONE launch of the fused
+reconstruct -> reverse-complement -> one-hot kernel through the C-ABI (``gvl_reconstruct``)
+with every input already resident in HBM.  The default workload is BASELINE.json
+``configs[2]`` -- 4096 windows x 2048 bp, SNP+indel, reverse-complement on half the rows,
+uint8 one-hot output -- the configuration the metric is quoted on ("4096x2048bp SNP+indel
+one-hot"); ``--workload cfg2`` gives the SNP-only ``configs[1]``, ``--workload cfg4`` the
+Enformer-length haplotypes + track realignment, ``--workload cfg1 --cpu-only`` the reference's
+CPU-runnable plumbing case.
 
     python bench.py --gpus N --steps K --warmup W
 
-For N > 1 the driver launches one rank per GPU (torch.distributed.run); rows are
-independent, so each rank processes its own 4096-window batch (weak scaling, no
-data-path collective) and ``value`` = windows all ranks processed / max-over-ranks time.
-Rank 0 prints ONE JSON line.
+Inputs are COLD by default: the dataset is genome scale (``--scale hg38``: 3.09 Gbp reference,
+10 M variants, a sparse-genotype CSR + inline records > 1 GB, 8.4 M queries drawn across the
+whole genome) and every step takes the next of ``--rotate`` (default 64) distinct batches, so
+no step finds its reference windows, variant records or request arrays in L2 / Infinity Cache.
+``--scale small --rotate 1`` is round 1's cache-hot measurement (64 Mbp contig, one batch).
+
+Timing.  After W warmup steps:
+  * contract region: barrier + synchronize, EXACTLY K steps, synchronize + barrier, host clock
+    -> ``wall_ms_per_step`` (at small K this is mostly launch / synchronize latency);
+  * the same K-step region is then repeated (each one again bracketed by barrier +
+    synchronize) until >= ``--min-region-ms`` of GPU time has been sampled; inside a region
+    the launches are queued behind a short gate kernel and HIP events on the work streams
+    give the region's GPU time (first kernel start -> last kernel end).  ``ms_per_step`` =
+    median region / K, ``value`` = windows of all ranks / that time (max over ranks per
+    region).  This is what makes ``--steps 20`` and ``--steps 2000`` agree;
+  * ``roofline``: K back-to-back launches on ONE stream between two HIP events, repeated the
+    same way -> the kernel's own average duration (what ``rocprofv3 --kernel-trace --stats``
+    reports) -> ``achieved`` = algorithmic bytes per launch / that.
+
+For N > 1 the driver launches one rank per GPU (torch.distributed.run); rows are independent,
+so each rank processes its own 4096-window batches (weak scaling, no data-path collective)
+and ``value`` = windows all ranks processed / max-over-ranks time.  ``--strong`` splits ONE
+4096-window batch into contiguous query blocks (``sharding.shard_batch``) instead;
+``--gather`` additionally times the optional RCCL all-gather of the ranks' one-hot shards
+(``gather_ms``; never inside ``value``).  Rank 0 prints ONE JSON line.
 """
 
 from __future__ import annotations
@@ -32,7 +54,8 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 measured copy ceiling
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0      # measured float4-copy ceiling (same guide)
 
 
 def algorithmic_bytes_per_window(L: int, mean_variants: float, haps: bool, onehot: bool) -> float:
@@ -40,70 +63,181 @@ def algorithmic_bytes_per_window(L: int, mean_variants: float, haps: bool, oneho
     return L * (1 + (1 if haps else 0) + (4 if onehot else 0)) + 28.0 * mean_variants + 61.0
 
 
-def cpu_baseline(st, bt, haps: bool, budget_s: float = 12.0) -> dict:
+def cpu_baseline(st, bt, budget_s: float = 12.0, thread_counts=None) -> dict:
     """The oracle (C restatement of the reference's Rust/rayon path: reconstruct ->
-    rc_flat_rows -> one-hot) timed on the host cores over the same batch."""
+    rc_flat_rows -> one-hot, rows handed to a persistent worker pool) timed on the host cores
+    over one full batch, at several thread counts (1 and nproc at least).
+    The gate ``should_parallelize`` (_threads.py:122-127) would be ON for this batch
+    (8 MiB of output >> its 32 KiB threshold), so threads > 1 is what the reference runs."""
     from oracle import oracle
 
-    try:  # the shipped .so is x86-64-v3; rebuild for this host's CPU when gcc is here
-        oracle.build(march="native")
+    try:      # a -march=native copy in a scratch dir; the tree's x86-64-v3 .so stays as it is
+        lib = oracle.build_native()
+        march = "native"
     except Exception:
-        pass
-    threads = oracle.default_threads()
-    K = bt.n_windows
-    L = bt.output_length
+        lib, march = None, "x86-64-v3"
+    nproc = oracle.default_threads()
+    if thread_counts is None:
+        thread_counts = sorted({1, 8, 32, nproc} & set(range(1, nproc + 1)) | {1, nproc})
+    K, L = bt.n_windows, bt.output_length
     out = np.empty(K * L, np.uint8)
     oh = np.empty((K * L, 4), np.uint8)
     oo = np.arange(K + 1, dtype=np.int64) * L
-    go = np.ascontiguousarray(bt.geno_offsets)
-
-    def run():
-        oracle.reconstruct_haplotypes_from_sparse(
-            out, oo, bt.regions, bt.shifts, bt.geno_offset_idx, go, bt.geno_v_idxs, st.v_starts,
-            st.ilens, st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets, st.pad_char,
-            bt.keep, bt.keep_offsets, None, None, True, to_rc=bt.to_rc, onehot_out=oh,
-            n_threads=threads)
-
-    run()  # warm
-    times = []
-    t_end = time.perf_counter() + budget_s
-    while len(times) < 3 or time.perf_counter() < t_end:
-        t0 = time.perf_counter()
-        run()
-        times.append(time.perf_counter() - t0)
-        if len(times) >= 2000:
-            break
-    med = float(np.median(times))
+    call = oracle.BatchCall(out, oo, bt.regions, bt.shifts, bt.geno_offset_idx, bt.geno_offsets, bt.geno_v_idxs,
+                            st.v_starts, st.ilens, st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets,
+                            st.pad_char, to_rc=bt.to_rc, onehot_out=oh, library=lib)
+    sweep = {}
+    per = budget_s / max(len(thread_counts), 1)
+    total_iters, total_s = 0, 0.0
+    for nt in thread_counts:
+        call.run(nt)  # warm (and sizes the pool)
+        times = []
+        t_end = time.perf_counter() + per
+        while len(times) < 3 or time.perf_counter() < t_end:
+            t0 = time.perf_counter()
+            call.run(nt)
+            times.append(time.perf_counter() - t0)
+            if len(times) >= 2000:
+                break
+        med = float(np.median(times))
+        sweep[str(nt)] = {"windows_per_s": K / med, "ms_per_batch": med * 1e3, "iterations": len(times),
+                          "hap_GBps": K * L / med / 1e9}
+        total_iters += len(times)
+        total_s += sum(times)
+    best = max(sweep, key=lambda k: sweep[k]["windows_per_s"])
     return {
-        "value": K / med, "unit": "windows/s", "cores": threads, "kind": "port",
-        "sample": f"full batch ({K} windows x {L} bp, reconstruct+RC+one-hot), "
-                  f"{len(times)} iterations over {sum(times):.1f} s, median",
-        "ms_per_batch": med * 1e3,
+        "value": sweep[best]["windows_per_s"], "unit": "windows/s", "cores": int(best), "kind": "port",
+        "sample": f"one full batch ({K} windows x {L} bp, reconstruct+RC+one-hot) per iteration, "
+                  f"{total_iters} iterations over {total_s:.1f} s, median per thread count; best of the sweep",
+        "ms_per_batch": sweep[best]["ms_per_batch"], "host_cores": nproc, "march": march,
+        "single_thread_windows_per_s": sweep["1"]["windows_per_s"],
+        "single_thread_hap_GBps": sweep["1"]["hap_GBps"],
+        "threads_sweep": sweep,
+        "parallel_gate": "on (should_parallelize: 8 MiB batch >> 32 KiB threshold); threads=1 row = gate off",
     }
+
+
+def cpu_only(args) -> None:
+    """BASELINE.json configs[0]: 1024 windows x 1024 bp, SNP-only, CPU path only (no GPU)."""
+    from genvarloader_amd import synth
+
+    st, bt = synth.make_config(args.workload)
+    res = cpu_baseline(st, bt, args.cpu_budget)
+    K, L = bt.n_windows, bt.output_length
+    print(json.dumps({
+        "metric": "haplotype windows/sec", "value": res["value"], "unit": "windows/s", "n_gpus": 0,
+        "steps": None, "warmup": None, "ms_per_step": res["ms_per_batch"], "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {K} windows x {L} bp, CPU oracle only (the reference's "
+                               "Rust/rayon path restated in C; plumbing case, no GPU)"},
+        "cpu_baseline": res}), flush=True)
+
+
+class Timer:
+    """Repeated K-step regions, each bracketed by barrier + synchronize; GPU time of a region from
+    HIP events on the work streams, the launches queued behind a gate kernel."""
+
+    def __init__(self, torch, dist, backend, streams, min_region_ms, max_regions):
+        self.torch, self.dist, self.backend = torch, dist, backend
+        self.streams = streams
+        self.min_ms, self.max_regions = float(min_region_ms), int(max_regions)
+        self.gate = torch.cuda.Stream()
+        # calibrate torch.cuda._sleep (spins on the shader clock)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(100_000)
+        torch.cuda.synchronize()
+        e0.record(); torch.cuda._sleep(2_000_000); e1.record(); torch.cuda.synchronize()
+        self.cycles_per_us = 2_000_000 / max(e0.elapsed_time(e1) * 1e3, 1.0)
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def allmax(self, vals):
+        if self.dist is None:
+            return list(vals)
+        torch = self.torch
+        t = torch.tensor(list(vals), dtype=torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(x) for x in t.cpu()]
+
+    def region(self, step, K, streams):
+        """One bracketed region of exactly K steps -> (GPU ms, host wall ms)."""
+        torch = self.torch
+        ev_g = torch.cuda.Event()
+        e0 = [torch.cuda.Event(enable_timing=True) for _ in streams]
+        e1 = [torch.cuda.Event(enable_timing=True) for _ in streams]
+        self.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gate_us = 30.0 + 5.0 * min(K, 64)
+        with torch.cuda.stream(self.gate):
+            torch.cuda._sleep(int(gate_us * self.cycles_per_us))
+            ev_g.record(self.gate)
+        for s, e in zip(streams, e0):
+            s.wait_event(ev_g)
+            e.record(s)
+        for i in range(K):
+            step(i)
+        for s, e in zip(streams, e1):
+            e.record(s)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        self.barrier()
+        used = min(K, len(streams))
+        gpu_ms = max(a.elapsed_time(b) for a in e0[:used] for b in e1[:used])
+        return gpu_ms, (t1 - t0) * 1e3
+
+    def measure(self, step, K, streams):
+        """Repeat the region until >= min_ms of GPU time is sampled -> (median GPU ms of a
+        region, max over ranks per region; number of regions)."""
+        first, _ = self.region(step, K, streams)
+        first = self.allmax([first])[0]
+        n = int(min(self.max_regions, max(5, np.ceil(self.min_ms / max(first, 1e-6)))))
+        spans = [self.region(step, K, streams)[0] for _ in range(n)]
+        spans = self.allmax(spans)
+        return float(np.median(spans)), n, spans
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg4"])
+    ap.add_argument("--scale", default="hg38", choices=["hg38", "small"],
+                    help="dataset size: hg38 = 3.09 Gbp / > 1 GB of genotype records (cold inputs); small = 64 Mbp")
+    ap.add_argument("--rotate", type=int, default=64, help="distinct batches the steps cycle through (1 = cache-hot)")
+    ap.add_argument("--queries", type=int, default=None, help="override the number of queries in the dataset")
     ap.add_argument("--haps", action="store_true", help="also materialise haplotype bytes (h=1)")
-    ap.add_argument("--contig", type=int, default=None, help="override reference contig length (bp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-only", action="store_true", help="time the CPU oracle only (cfg1 plumbing case); no GPU")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
-    ap.add_argument("--slots", type=int, default=2, help="output ring slots")
     ap.add_argument("--streams", type=int, default=4,
                     help="batches kept in flight (one HIP stream each) in the timed region")
+    ap.add_argument("--min-region-ms", type=float, default=20.0)
+    ap.add_argument("--max-regions", type=int, default=400)
+    ap.add_argument("--strong", action="store_true", help="N > 1: split ONE batch across the ranks (strong scaling)")
+    ap.add_argument("--gather", action="store_true", help="N > 1: also time the RCCL all-gather of the one-hot shards")
+    ap.add_argument("--no-hot", action="store_true", help="skip the extra cache-hot kernel timing")
     args = ap.parse_args()
+
+    if args.cpu_only:
+        cpu_only(args)
+        return
+    if args.workload == "cfg4":
+        from tools import bench_cfg4  # haplotypes + tracks: its own step definition
+
+        bench_cfg4.main(args)
+        return
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 with torch.distributed.run")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     # GVL_BENCH_DEVICE / GVL_BENCH_BACKEND exist only so that the N > 1 code path can be smoke
     # tested on a 1-GPU box (several ranks sharing GPU 0 over gloo); the driver never sets them.
@@ -118,120 +252,183 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus
 
-    from genvarloader_amd import HapsDevice, synth
+    from genvarloader_amd import HapsDevice, sharding, synth
 
-    # ---- synthetic dataset + this rank's batch (rows shard across ranks) -------------
+    # ---- synthetic dataset (per rank; --strong: the same one on every rank) ---------------
     cfg_idx = int(args.workload[3:])
-    st, bt = synth.make_config(args.workload, seed=20260802 + cfg_idx + 1000 * rank, contig=args.contig)
-    K, L = bt.n_windows, bt.output_length
-    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
-                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=bt.geno_offsets,
-                     geno_v_idxs=bt.geno_v_idxs, pad_char=st.pad_char, device=f"cuda:{dev_index}")
-    dbt = dev.prepare_batch(bt.regions, bt.shifts, bt.geno_offset_idx, L, to_rc=bt.to_rc)
-    slots = [dev.alloc_output(dbt, K * L, haps=args.haps, onehot=True) for _ in range(max(1, args.slots))]
+    seed = 20260802 + cfg_idx + (0 if args.strong else 1000 * rank)
+    t_gen = time.perf_counter()
+    ds = synth.make_genome(args.scale, args.workload, device=f"cuda:{dev_index}", seed=seed, n_queries=args.queries)
+    dev = HapsDevice(**ds.static_kwargs(), device=f"cuda:{dev_index}")
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+    P, L = ds.ploidy, ds.length
+    K_full = synth.CONFIGS[args.workload]["windows"]
+    n_rot = max(1, args.rotate)
+    qsets = ds.draw_batches(n_rot, K_full // P, seed=seed + 7)
+    rc_on = synth.CONFIGS[args.workload]["rc_frac"] > 0
+
+    def make_dbt(q):
+        r = ds.request(q, rc=rc_on)
+        if args.strong and world > 1:
+            lo, hi = sharding.shard_bounds(int(q.numel()), world, rank)
+            r = dict(regions=r["regions"][lo:hi].contiguous(), shifts=r["shifts"][lo:hi].contiguous(),
+                     geno_offset_idx=r["geno_offset_idx"][lo:hi].contiguous(),
+                     to_rc=None if r["to_rc"] is None else r["to_rc"][lo * P:hi * P].contiguous())
+        return dev.prepare_batch(r["regions"], r["shifts"], r["geno_offset_idx"], L, to_rc=r["to_rc"])
+
+    batches = [make_dbt(qsets[i]) for i in range(n_rot)]
+    K = batches[0].n_rows                      # windows per step on this rank
     stream = torch.cuda.current_stream()
     streams = [stream] + [torch.cuda.Stream() for _ in range(max(0, args.streams - 1))]
-    while len(slots) < len(streams) + 1:      # an output slot per batch in flight (+1 being consumed)
-        slots.append(dev.alloc_output(dbt, K * L, haps=args.haps, onehot=True))
+    n_slots = len(streams) + 1                 # an output slot per batch in flight (+1 being consumed)
+    slots = [dev.alloc_output(batches[0], K * L, haps=args.haps, onehot=True) for _ in range(n_slots)]
+    mean_v = float(np.mean([float((dev.geno_offsets[1][b.geno_offset_idx.reshape(-1)]
+                                   - dev.geno_offsets[0][b.geno_offset_idx.reshape(-1)]).double().mean())
+                            for b in batches[: min(8, n_rot)]]))
+    counter = [0]
 
-    def step(i: int, pipelined: bool = True) -> None:
+    def step_pipelined(i: int) -> None:
         # a batch is independent of the previous one: the loader keeps `--streams` batches in
         # flight on separate HIP streams, so the latency-bound head of one batch (parameter
         # and variant gathers, scans) overlaps the store-bound tail of another
-        dev.launch(dbt, slots[i % len(slots)][1], streams[i % len(streams)] if pipelined else stream)
+        j = counter[0]
+        counter[0] += 1
+        dev.launch(batches[j % n_rot], slots[j % n_slots][1], streams[i % len(streams)])
 
-    def barrier() -> None:
-        if dist is not None:
-            dist.barrier()
+    def step_single(i: int) -> None:
+        j = counter[0]
+        counter[0] += 1
+        dev.launch(batches[j % n_rot], slots[j % n_slots][1], stream)
 
-    def join() -> None:
-        for st_ in streams[1:]:
-            stream.wait_stream(st_)
+    def step_hot(i: int) -> None:
+        dev.launch(batches[0], slots[i % n_slots][1], stream)
 
-    # ---- warmup, then EXACTLY K timed steps ---------------------------------------------
+    tm = Timer(torch, dist, backend, streams, args.min_region_ms, args.max_regions)
+    steps = args.steps
+
+    # ---- warmup, then the contract region: EXACTLY K steps between barrier + synchronize ----
     for i in range(args.warmup):
-        step(i)
-    join()
+        step_pipelined(i)
     torch.cuda.synchronize()
-    barrier()
+    tm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    join()
+    for i in range(steps):
+        step_pipelined(i)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    barrier()
-    torch.cuda.synchronize()
-    wall = t1 - t0
+    tm.barrier()
+    wall = tm.allmax([t1 - t0])[0]
 
-    # ---- the kernel's own duration: same K launches back to back on ONE stream, HIP events on
-    # that stream (this is what `rocprofv3 --kernel-trace --stats` reports per launch) -----------
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    for i in range(min(args.warmup, 10)):
-        step(i, pipelined=False)
-    torch.cuda.synchronize()
-    ev0.record(stream)
-    for i in range(args.steps):
-        step(i, pipelined=False)
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    kern_ms = ev0.elapsed_time(ev1) / args.steps
-    # ---- single-batch latency, host wall clock: launch -> synchronize -----------
+    # ---- the same region repeated; GPU time per region from HIP events ---------------------
+    region_ms, n_regions, spans = tm.measure(step_pipelined, steps, streams)
+    # ---- the kernel's own duration: K launches back to back on ONE stream ---------------------
+    kern_region_ms, n_kregions, _ = tm.measure(step_single, steps, [stream])
+    kern_ms = kern_region_ms / steps
+    hot_ms = None
+    if not args.no_hot:
+        hot_ms = tm.measure(step_hot, steps, [stream])[0] / steps
+    # ---- single-batch latency, host wall clock: launch -> synchronize --------
     lat = []
     for i in range(50):
         torch.cuda.synchronize()
         t_a = time.perf_counter()
-        step(i, pipelined=False)
+        step_single(i)
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - t_a)
     single_ms = float(np.median(lat)) * 1e3
+
+    # ---- optional: the final gather of the ranks' one-hot shards (never inside `value`) --------
+    gather_ms = None
+    if args.gather and dist is not None:
+        oh = slots[0][0].onehot.view(K, L, 4)
+        if backend != "nccl":
+            oh = oh.cpu()
+        ts = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            tm.barrier()
+            ta = time.perf_counter()
+            g = sharding.all_gather_rows(oh)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - ta)
+        assert g.shape[1:] == oh.shape[1:] and g.shape[0] >= K
+        gather_ms = tm.allmax([float(np.median(ts)) * 1e3])[0]
+
+    k_all = K
     if dist is not None:
-        tt = torch.tensor([wall, kern_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, kern_ms = float(tt[0]), float(tt[1])
+        t = torch.tensor([K], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        k_all = int(t.item())
 
     if rank == 0:
-        abytes = algorithmic_bytes_per_window(L, bt.mean_variants, args.haps, True) * K
+        ms_per_step = region_ms / steps
+        abytes = algorithmic_bytes_per_window(L, mean_v, args.haps, True) * K
         achieved = abytes / (kern_ms * 1e-3) / 1e9
+        pipelined = abytes / (ms_per_step * 1e-3) / 1e9
         traffic = None
         tf = REPO / "profiles" / "traffic.json"
         if tf.exists():
             try:
-                traffic = json.loads(tf.read_text()).get(f"{args.workload}{'+haps' if args.haps else ''}")
+                traffic = json.loads(tf.read_text()).get(
+                    f"{args.workload}{'+haps' if args.haps else ''}@{args.scale}" + ("" if n_rot > 1 else "@hot"))
             except Exception:
                 traffic = None
+        sizes = ds.nbytes()
         res = {
-            "metric": "haplotype windows/sec", "value": world * K * args.steps / wall, "unit": "windows/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": "haplotype windows/sec", "value": k_all / (ms_per_step * 1e-3), "unit": "windows/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: {K} windows x {L} bp per GPU, "
+                "workload": f"{args.workload}: {K_full} windows x {L} bp per " + ("job" if args.strong else "GPU") + ", "
                             + ("SNP+indel, reverse-complement on half the rows" if cfg_idx >= 3 else "SNP-only")
                             + ", uint8 one-hot (K,L,4)" + (" + haplotype bytes" if args.haps else ""),
-                "windows_per_batch": K, "length_bp": L, "ploidy": 2,
-                "mean_variants_per_window": round(bt.mean_variants, 3),
-                "reference_bp": int(st.ref.size), "parallelism": f"rows sharded over {world} GPU(s)",
-                "batches_in_flight": len(streams),
+                "windows_per_step_per_rank": K, "length_bp": L, "ploidy": P,
+                "mean_variants_per_window": round(mean_v, 3),
+                "scale": args.scale, "reference_bp": int(ds.ref.numel()), "n_variants": int(ds.v_starts.numel()),
+                "genotype_entries": int(ds.geno_v_idxs.numel()), "dataset_queries": int(ds.n_queries),
+                "dataset_bytes": sizes, "inline_record_bytes": 0 if dev.geno_rec is None else int(dev.geno_rec.numel()) * 4,
+                "rotating_batches": n_rot,
+                "inputs": "cold (every step a different batch, dataset >> Infinity Cache)" if n_rot > 1 and args.scale == "hg38"
+                          else ("rotating" if n_rot > 1 else "cache-hot (one batch re-launched)"),
+                "parallelism": f"world_size {world}: " + ("one batch split into contiguous query blocks" if args.strong
+                                                          else "rows sharded over the ranks, one full batch per rank per step"),
+                "batches_in_flight": len(streams), "dataset_build_s": round(t_gen, 2),
+            },
+            "timing": {
+                "how": "median of repeated K-step regions, each between barrier+synchronize; GPU time of a region from "
+                       "HIP events on the work streams (launches queued behind a gate kernel)",
+                "regions": n_regions, "region_ms_min": min(spans), "region_ms_max": max(spans),
+                "wall_ms_per_step": wall / steps * 1e3,
+                "wall_how": "host clock around ONE K-step region incl. launch + synchronize latency",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac_of_copy_ceiling": achieved / HBM_COPY_GBS,
                 "kernel": "reconstruct_kernel<OH_LC, haps=%s, annot=false>" % ("true" if args.haps else "false"),
-                "kernel_ms": kern_ms, "kernel_ms_how": "HIP events around K back-to-back launches on one stream",
+                "kernel_ms": kern_ms,
+                "kernel_ms_how": "HIP events around K back-to-back launches on one stream (rotating batches), median region",
+                "kernel_ms_hot": hot_ms, "hot_frac": None if hot_ms is None else abytes / (hot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": abytes,
-                "pipelined_GBps": abytes * world / (wall / args.steps) / 1e9 / world,
+                "pipelined_GBps": pipelined, "pipelined_frac": pipelined / HBM_PEAK_GBS,
+                "pipelined_frac_of_copy_ceiling": pipelined / HBM_COPY_GBS,
                 "single_batch_wall_ms": single_ms,
             },
         }
+        if gather_ms is not None:
+            res["gather_ms"] = gather_ms
+            res["gather_bytes_per_rank"] = K * L * 4
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(st, bt, args.haps, args.cpu_budget)
+            res["cpu_baseline"] = cpu_baseline(ds.host_static(), ds.host_batch(qsets[0], rc=rc_on), args.cpu_budget)
         print(json.dumps(res), flush=True)
 
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

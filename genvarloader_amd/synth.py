@@ -281,3 +281,207 @@ def make_config(name: str, seed: int | None = None, ploidy: int = 2, contig: int
                     random_shifts=random_shifts)
     bt.meta["config"] = name
     return st, bt
+
+
+# --- genome-scale dataset, generated on the device ------------------------------------
+# bench.py's default: a reference, variant table and sparse-genotype CSR too large for any
+# cache of the part (256 MiB Infinity Cache), with batches drawn across the whole genome, so
+# that "achieved HBM GB/s" is measured on cold inputs.  Same recipe as the numpy generators
+# above, written with torch ops so that 3.1 Gbp take a second on the GPU; it
+# also runs on CPU tensors at small sizes (tests).
+
+# GRCh38 primary assembly, chr1..22, X, Y (bp)
+HG38_CONTIGS = (248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636,
+                138394717, 133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345,
+                83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415)
+
+SCALES = {
+    # name: (contig lengths, queries in the dataset)
+    "small": ((64 << 20,), 1 << 16),      # SURVEY 8(d)'s 64 Mbp contig: everything cache resident
+    "hg38": (HG38_CONTIGS, 1 << 23),      # 3.09 Gbp; 8.4 M queries x 2 haplotypes -> CSR + records > 1 GB
+}
+
+
+class GenomeDataset:
+    """Reference + variant table + a (queries x ploidy) sparse-genotype CSR as torch tensors on
+    ``device``.  Query ``q`` owns genotype slots ``q * P .. q * P + P - 1`` (the reference's
+    ``ravel_multi_index`` layout with one sample per region, ``_haps.py:757-768``)."""
+
+    def __init__(self, device="cuda", contigs=(64 << 20,), n_queries=1 << 16, ploidy=2, length=2048, slack=32,
+                 indel_frac=0.15, rc_frac=0.5, density=1.0 / 300.0, n_frac=0.01, af_beta=(0.6, 0.9),
+                 max_indel=30, lookback=40, seed=0):
+        import torch
+
+        d = torch.device(device)
+        self.device = d
+        g = torch.Generator(device=d)
+        g.manual_seed(int(seed))
+        nrng = np.random.default_rng(int(seed))
+        contigs = [int(c) for c in contigs]
+        self.ploidy, self.length, self.slack, self.pad_char = int(ploidy), int(length), int(slack), ord("N")
+        ro = np.zeros(len(contigs) + 1, np.int64)
+        ro[1:] = np.cumsum(contigs)
+        total = int(ro[-1])
+        self.ref_offsets = torch.from_numpy(ro).to(d)
+        lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=d)
+
+        # ---- reference: uniform ACGT, n_frac N; in slabs so that the temporaries stay small
+        ref = torch.empty(total, dtype=torch.uint8, device=d)
+        slab = 1 << 27
+        for s in range(0, total, slab):
+            n = min(slab, total - s)
+            codes = torch.randint(0, 4, (n,), dtype=torch.int32, device=d, generator=g)
+            seg = lut.index_select(0, codes)
+            if n_frac > 0:
+                seg[torch.rand(n, device=d, generator=g) < n_frac] = ord("N")
+            ref[s:s + n] = seg
+        self.ref = ref
+
+        # ---- variant table, contig by contig (positions sorted inside a contig)
+        vs_l, il_l, alt_l, alen_l, vc_l = [], [], [], [], []
+        for c, clen in enumerate(contigs):
+            n = int(nrng.poisson(clen * density))
+            if n == 0:
+                continue
+            pos = torch.unique(torch.randint(0, clen, (n,), dtype=torch.int64, device=d, generator=g))
+            n = int(pos.numel())
+            u = torch.rand(n, device=d, generator=g).clamp_min(1e-12)
+            mag = (torch.floor(torch.log(u) / np.log(1.0 - 0.35)) + 1).clamp(1, max_indel).to(torch.int64)
+            sign = torch.where(torch.rand(n, device=d, generator=g) < 0.5, -1, 1)
+            is_indel = torch.rand(n, device=d, generator=g) < indel_frac
+            il = torch.where(is_indel, mag * sign, torch.zeros_like(mag))
+            room = clen - 1 - pos                           # a deletion may not run past the contig end
+            il = torch.where(il < 0, -torch.minimum(-il, room), il)
+            alen = 1 + il.clamp_min(0)
+            off = torch.zeros(n + 1, dtype=torch.int64, device=d)
+            torch.cumsum(alen, 0, out=off[1:])
+            alt = lut.index_select(0, torch.randint(0, 4, (int(off[-1]),), dtype=torch.int32, device=d, generator=g))
+            base = ref[int(ro[c]) + pos]
+            code = ((base == ord("C")).to(torch.int64) + 2 * (base == ord("G")).to(torch.int64)
+                    + 3 * (base == ord("T")).to(torch.int64))          # N -> 0 like the numpy generator
+            alt_snp = lut[(code + torch.randint(1, 4, (n,), dtype=torch.int64, device=d, generator=g)) % 4]
+            alt[off[:-1]] = torch.where(il == 0, alt_snp, base)       # SNP: another base; indel: the anchor
+            vs_l.append(pos.to(torch.int32)); il_l.append(il.to(torch.int32)); alt_l.append(alt)
+            alen_l.append(alen); vc_l.append(torch.full((n,), c, dtype=torch.int32, device=d))
+        cat = (lambda xs, dt: torch.cat(xs) if xs else torch.zeros(0, dtype=dt, device=d))
+        self.v_starts, self.ilens = cat(vs_l, torch.int32), cat(il_l, torch.int32)
+        self.alt_alleles = cat(alt_l, torch.uint8)
+        v_contig = cat(vc_l, torch.int32)
+        alen = cat(alen_l, torch.int64)
+        nv = int(self.v_starts.numel())
+        self.alt_offsets = torch.zeros(nv + 1, dtype=torch.int64, device=d)
+        torch.cumsum(alen, 0, out=self.alt_offsets[1:])
+        af = torch.from_numpy(nrng.beta(af_beta[0], af_beta[1], nv).astype(np.float32)).to(d)
+        gpos = self.ref_offsets[v_contig.to(torch.int64)] + self.v_starts.to(torch.int64)   # sorted
+
+        # ---- queries: regions drawn across the whole genome (contig ~ length)
+        M, P = int(n_queries), self.ploidy
+        span = self.length + 2 * self.slack
+        w = torch.tensor(contigs, dtype=torch.float64, device=d)
+        qc = torch.multinomial(w / w.sum(), M, replacement=True, generator=g)
+        clen = torch.tensor(contigs, dtype=torch.int64, device=d)[qc]
+        start = (torch.rand(M, device=d, generator=g, dtype=torch.float64) * (clen - span).clamp_min(1)).to(torch.int64)
+        end = start + span
+        strand = torch.where(torch.rand(M, device=d, generator=g) < rc_frac, -1, 1)
+        self.full_regions = torch.stack([qc, start, end, strand], dim=1).to(torch.int32).contiguous()
+        self.n_queries = M
+
+        # ---- sparse genotypes: every haplotype carries each variant with pos in
+        # [start - lookback, end) on its contig with that variant's allele frequency
+        c_s, c_e = self.ref_offsets[qc], self.ref_offsets[qc + 1]
+        lo = torch.searchsorted(gpos, torch.maximum(c_s + start - lookback, c_s))
+        hi = torch.searchsorted(gpos, torch.minimum(c_s + end, c_e))
+        K = M * P
+        n_cand = (hi - lo).clamp_min(0).repeat_interleave(P)
+        row_lo = lo.repeat_interleave(P)
+        cand_off = torch.zeros(K + 1, dtype=torch.int64, device=d)
+        torch.cumsum(n_cand, 0, out=cand_off[1:])
+        tot = int(cand_off[-1])
+        row_of = torch.repeat_interleave(torch.arange(K, device=d), n_cand)
+        v_of = row_lo[row_of] + (torch.arange(tot, device=d) - cand_off[row_of])
+        carried = torch.rand(tot, device=d, generator=g) < af[v_of]
+        self.geno_v_idxs = v_of[carried].to(torch.int32)
+        counts = torch.bincount(row_of[carried], minlength=K)
+        offs = torch.zeros(K + 1, dtype=torch.int64, device=d)
+        torch.cumsum(counts, 0, out=offs[1:])
+        self.geno_offsets = torch.stack([offs[:-1], offs[1:]]).contiguous()
+        self.mean_variants = float(self.geno_v_idxs.numel()) / max(K, 1)
+        self._host_static = None
+
+    # -- what HapsDevice takes
+    def static_kwargs(self) -> dict:
+        return dict(ref=self.ref, ref_offsets=self.ref_offsets, v_starts=self.v_starts, ilens=self.ilens,
+                    alt_alleles=self.alt_alleles, alt_offsets=self.alt_offsets, geno_offsets=self.geno_offsets,
+                    geno_v_idxs=self.geno_v_idxs, pad_char=self.pad_char)
+
+    def nbytes(self) -> dict:
+        t = lambda x: int(x.numel()) * x.element_size()
+        return dict(reference=t(self.ref), variant_table=t(self.v_starts) + t(self.ilens) + t(self.alt_alleles)
+                    + t(self.alt_offsets), genotype_csr=t(self.geno_offsets) + t(self.geno_v_idxs),
+                    regions=t(self.full_regions))
+
+    def draw_batches(self, n_batches: int, queries_per_batch: int, seed: int = 1):
+        """``n_batches`` disjoint random sets of query ids (int64 (n_batches, b) on the device)."""
+        import torch
+
+        g = torch.Generator(device=self.device)
+        g.manual_seed(int(seed))
+        need = n_batches * queries_per_batch
+        if need <= self.n_queries:
+            q = torch.randperm(self.n_queries, device=self.device, generator=g)[:need]
+        else:
+            q = torch.randint(0, self.n_queries, (need,), device=self.device, generator=g)
+        return q.view(n_batches, queries_per_batch)
+
+    def request(self, q, rc: bool = True) -> dict:
+        """Per-batch arrays (``ReconstructionRequest``) for query ids ``q``: shifts = 0."""
+        import torch
+
+        P = self.ploidy
+        q = q.to(torch.int64)
+        reg = self.full_regions.index_select(0, q)
+        goi = (q * P)[:, None] + torch.arange(P, device=self.device, dtype=torch.int64)[None, :]
+        to_rc = (reg[:, 3] == -1).repeat_interleave(P).to(torch.uint8) if rc else None
+        return dict(regions=reg, shifts=torch.zeros((q.numel(), P), dtype=torch.int32, device=self.device),
+                    geno_offset_idx=goi.contiguous(), to_rc=to_rc)
+
+    def host_static(self) -> SynthStatic:
+        if self._host_static is None:
+            h = lambda x: x.cpu().numpy()
+            self._host_static = SynthStatic(h(self.ref), h(self.ref_offsets), h(self.v_starts), h(self.ilens),
+                                            h(self.alt_alleles), h(self.alt_offsets), np.zeros(0, np.int32),
+                                            np.zeros(0, np.float32))
+        return self._host_static
+
+    def host_batch(self, q, rc: bool = True) -> SynthBatch:
+        """The same batch for the CPU oracle: the rows' CSR slices compacted (geno_offset_idx = arange)."""
+        import torch
+
+        P = self.ploidy
+        r = self.request(q, rc)
+        goi = r["geno_offset_idx"].reshape(-1)
+        o_s, o_e = self.geno_offsets[0][goi], self.geno_offsets[1][goi]
+        n = o_e - o_s
+        K = int(goi.numel())
+        offs = torch.zeros(K + 1, dtype=torch.int64, device=self.device)
+        torch.cumsum(n, 0, out=offs[1:])
+        row_of = torch.repeat_interleave(torch.arange(K, device=self.device), n)
+        src = o_s[row_of] + (torch.arange(int(offs[-1]), device=self.device) - offs[row_of])
+        gv = self.geno_v_idxs[src]
+        go = torch.stack([offs[:-1], offs[1:]])
+        h = lambda x: None if x is None else x.cpu().numpy()
+        return SynthBatch(regions=h(r["regions"]), shifts=h(r["shifts"]),
+                          geno_offset_idx=np.arange(K, dtype=np.int64).reshape(-1, P), geno_offsets=h(go),
+                          geno_v_idxs=h(gv), to_rc=None if r["to_rc"] is None else h(r["to_rc"]).astype(bool),
+                          output_length=self.length, meta=dict(B=K // P, P=P, length=self.length))
+
+
+def make_genome(scale: str = "small", workload: str = "cfg3", device="cuda", seed: int | None = None,
+                n_queries: int | None = None, contigs=None) -> GenomeDataset:
+    """BASELINE.json cfg1/cfg2/cfg3 over a ``SCALES`` genome."""
+    cfg = CONFIGS[workload]
+    cg, nq = SCALES[scale]
+    idx = int(workload[3:])
+    return GenomeDataset(device=device, contigs=contigs or cg, n_queries=n_queries or nq, length=cfg["length"],
+                         indel_frac=cfg["indel_frac"], rc_frac=cfg["rc_frac"],
+                         seed=20260802 + idx if seed is None else seed)

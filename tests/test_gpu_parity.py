@@ -35,6 +35,24 @@ def gpu():
     return g
 
 
+# Every row can reach its output several ways (scan-free plan, packed plan, per-wave scans,
+# scalar walk; records from the genotype-inline layout or from geno_v_idxs -> vrec).  The
+# reference's parity suite runs every schedule against the same goldens
+# (tests/parity/test_rayon_equivalence.py:31-62); here every reference vector goes down every
+# kernel path: gvl_set_debug_flags removes one way at a time.
+KERNEL_PATHS = {0: "default", 8: "scalar-walk", 16: "no-inline-records", 32: "no-scan-free-plan", 512: "per-wave-scans"}
+
+
+@pytest.fixture(params=sorted(KERNEL_PATHS), ids=[KERNEL_PATHS[k] for k in sorted(KERNEL_PATHS)])
+def kpath(request, gpu):
+    from genvarloader_amd import _lib
+
+    lib = _lib.load()
+    lib.gvl_set_debug_flags(int(request.param))
+    yield request.param
+    lib.gvl_set_debug_flags(-1)
+
+
 def make_dev(g, st, bt):
     return g.device.HapsDevice(
         ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
@@ -79,7 +97,7 @@ def check_batch(g, oracle, st, bt, layout="lc", annotate=False):
 
 
 # ------------------------------------------------------------------ reference goldens
-def test_golden_reconstruct_haplotypes_from_sparse(gpu):
+def test_golden_reconstruct_haplotypes_from_sparse(gpu, kpath):
     cases = load_ref_cases("reconstruct_haplotypes_from_sparse")
     assert len(cases) == 200
     for ci, (inp, exp) in enumerate(cases):
@@ -88,7 +106,7 @@ def test_golden_reconstruct_haplotypes_from_sparse(gpu):
         np.testing.assert_array_equal(out, exp, err_msg=f"case {ci}")
 
 
-def test_golden_get_diffs_sparse(gpu):
+def test_golden_get_diffs_sparse(gpu, kpath):
     cases = load_ref_cases("get_diffs_sparse")
     assert len(cases) == 200
     for ci, (inp, exp) in enumerate(cases):
@@ -145,7 +163,7 @@ def test_golden_rc_alleles_pins_rc_rows(gpu):
 
 # ------------------------------------------------------------------ known-answer rows
 @pytest.mark.parametrize("kat", ROW_KATS, ids=[k[0] for k in ROW_KATS])
-def test_row_kats(gpu, kat):
+def test_row_kats(gpu, kat, kpath):
     (_, v_idxs, v_starts, ilens, shift, alt, alt_off, ref, ref_start, L, pad, keep,
      exp, exp_av, exp_ap) = kat
     n = len(v_idxs)
@@ -187,7 +205,7 @@ def test_rc_kats(gpu):
 
 # ------------------------------------------------------------------ reference numpy fallback vectors
 @pytest.mark.parametrize("name", ["cfg2_small", "cfg3_small", "dense_annot", "snp_dups_shifts"])
-def test_pyref_fixtures(gpu, name):
+def test_pyref_fixtures(gpu, name, kpath):
     d = load_pyref(name)
     annotate = d["expected_annot_v_idxs"] is not None
     args = (d["regions"], d["shifts"], d["geno_offset_idx"], d["geno_offsets"], d["geno_v_idxs"],
@@ -224,7 +242,7 @@ def test_lengths_snp_indel_rc(gpu, oracle, L):
 
 
 @pytest.mark.parametrize("layout", ["lc", "cl"])
-def test_cfg2_full(gpu, oracle, layout):
+def test_cfg2_full(gpu, oracle, layout, kpath):
     from genvarloader_amd import synth
 
     st, bt = synth.make_config("cfg2", contig=8 << 20)
@@ -232,7 +250,7 @@ def test_cfg2_full(gpu, oracle, layout):
     check_batch(gpu, oracle, st, bt, layout=layout)
 
 
-def test_cfg3_full_with_properties(gpu, oracle):
+def test_cfg3_full_with_properties(gpu, oracle, kpath):
     from genvarloader_amd import synth
 
     st, bt = synth.make_config("cfg3", contig=8 << 20, random_shifts=True)
@@ -256,7 +274,7 @@ def test_cfg3_full_with_properties(gpu, oracle):
     assert int(out.onehot.sum()) == n_acgt
 
 
-def test_cfg1_plumbing(gpu, oracle):
+def test_cfg1_plumbing(gpu, oracle, kpath):
     from genvarloader_amd import synth
 
     st, bt = synth.make_config("cfg1", contig=4 << 20, ploidy=1)

@@ -20,11 +20,26 @@ def ffi():
     return f
 
 
+# the realignment walk has two implementations (wave-scan planner / scalar replay) and the
+# variant records two sources: every reference vector goes down each of them
+TRACK_PATHS = {0: "default", 8: "scalar-walk", 16: "no-inline-records"}
+
+
+@pytest.fixture(params=sorted(TRACK_PATHS), ids=[TRACK_PATHS[k] for k in sorted(TRACK_PATHS)])
+def tpath(request, ffi):
+    from genvarloader_amd import _lib
+
+    lib = _lib.load()
+    lib.gvl_set_debug_flags(int(request.param))
+    yield request.param
+    lib.gvl_set_debug_flags(-1)
+
+
 def bits(a):
     return np.asarray(a, np.float32).view(np.uint32)
 
 
-def test_golden_shift_and_realign_tracks_sparse(ffi):
+def test_golden_shift_and_realign_tracks_sparse(ffi, tpath):
     cases = load_ref_cases("shift_and_realign_tracks_sparse")
     assert len(cases) == 200
     for ci, (inp, exp) in enumerate(cases):
@@ -105,7 +120,7 @@ def test_tracks_long_rows_chunked(ffi, oracle):
     np.testing.assert_array_equal(bits(got), bits(exp))
 
 
-def test_cfg4_full_haps_and_track(ffi, oracle):
+def test_cfg4_full_haps_and_track(ffi, oracle, tpath):
     """BASELINE configs[3]: 256 windows x 131072 bp, SNP+indel, haplotype one-hot + one
     realigned track (Repeat5p), full size."""
     import time
@@ -239,7 +254,7 @@ def test_tracks_coordinates_beyond_2_30(ffi, oracle):
 
 
 @pytest.mark.parametrize("s_id", [0, 1, 2, 3, 4])
-def test_reference_numpy_fallback_tracks(ffi, s_id):
+def test_reference_numpy_fallback_tracks(ffi, s_id, tpath):
     """The GPU realignment against vectors from the reference's own numpy fallback."""
     from tests.test_oracle_tracks import _pyref_tracks, _run_pyref_tracks
 
