@@ -179,12 +179,13 @@ class Timer:
             e.record(s)
         for i in range(K):
             step(i)
+        getattr(step, "flush", lambda: None)()
         for s, e in zip(streams, e1):
             e.record(s)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         self.barrier()
-        used = min(K, len(streams))
+        used = min(-(-K // getattr(step, "group", 1)), len(streams))
         gpu_ms = max(a.elapsed_time(b) for a in e0[:used] for b in e1[:used])
         return gpu_ms, (t1 - t0) * 1e3
 
@@ -214,7 +215,9 @@ def main() -> None:
     ap.add_argument("--cpu-only", action="store_true", help="time the CPU oracle only (cfg1 plumbing case); no GPU")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--streams", type=int, default=4,
-                    help="batches kept in flight (one HIP stream each) in the timed region")
+                    help="HIP streams the launches of the timed region rotate over")
+    ap.add_argument("--many", type=int, default=1,
+                    help="batches per launch in the timed region (gvl_reconstruct_many; a step is still ONE batch)")
     ap.add_argument("--min-region-ms", type=float, default=20.0)
     ap.add_argument("--max-regions", type=int, default=400)
     ap.add_argument("--strong", action="store_true", help="N > 1: split ONE batch across the ranks (strong scaling)")
@@ -283,7 +286,8 @@ def main() -> None:
     K = batches[0].n_rows                      # windows per step on this rank
     stream = torch.cuda.current_stream()
     streams = [stream] + [torch.cuda.Stream() for _ in range(max(0, args.streams - 1))]
-    n_slots = len(streams) + 1                 # an output slot per batch in flight (+1 being consumed)
+    G = max(1, min(8, args.many))
+    n_slots = (len(streams) + 1) * G           # an output slot per batch in flight (+1 launch being consumed)
     slots = [dev.alloc_output(batches[0], K * L, haps=args.haps, onehot=True) for _ in range(n_slots)]
     mean_v = float(np.mean([float((dev.geno_offsets[1][b.geno_offset_idx.reshape(-1)]
                                    - dev.geno_offsets[0][b.geno_offset_idx.reshape(-1)]).double().mean())
@@ -298,6 +302,33 @@ def main() -> None:
         counter[0] += 1
         dev.launch(batches[j % n_rot], slots[j % n_slots][1], streams[i % len(streams)])
 
+    class ManyStepper:
+        """--many G: steps are gathered into launches of G batches (gvl_reconstruct_many), launch g on
+        stream g % streams; flush() sends the partial last group of a region."""
+
+        def __init__(self):
+            self.pending, self.g, self.cache, self.group = 0, 0, {}, G
+
+        def pack(self, g, size):
+            key = (g % (n_rot // G if n_rot >= G else 1), size, g % (len(streams) + 1))
+            p = self.cache.get(key)
+            if p is None:
+                b0, s0 = key[0] * G, key[2] * G
+                p = self.cache[key] = dev.pack_many([batches[(b0 + i) % n_rot] for i in range(size)],
+                                                    [slots[s0 + i][1] for i in range(size)])
+            return p
+
+        def __call__(self, i):
+            self.pending += 1
+            if self.pending == G:
+                self.flush()
+
+        def flush(self):
+            if self.pending:
+                dev.launch_many(self.pack(self.g, self.pending), streams[self.g % len(streams)])
+                self.g += 1
+                self.pending = 0
+
     def step_single(i: int) -> None:
         j = counter[0]
         counter[0] += 1
@@ -308,16 +339,26 @@ def main() -> None:
 
     tm = Timer(torch, dist, backend, streams, args.min_region_ms, args.max_regions)
     steps = args.steps
+    if G > 1:
+        step_pipelined = ManyStepper()
+        for g in range(max(1, n_rot // G) * (len(streams) + 1)):     # build the argument arrays ahead of the timed code
+            step_pipelined.pack(g, G)
+        if steps % G:
+            for g in range(max(1, n_rot // G) * (len(streams) + 1)):
+                step_pipelined.pack(g, steps % G)
+    flush = getattr(step_pipelined, "flush", lambda: None)
 
     # ---- warmup, then the contract region: EXACTLY K steps between barrier + synchronize ----
     for i in range(args.warmup):
         step_pipelined(i)
+    flush()
     torch.cuda.synchronize()
     tm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
         step_pipelined(i)
+    flush()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     tm.barrier()
@@ -397,7 +438,8 @@ def main() -> None:
                           else ("rotating" if n_rot > 1 else "cache-hot (one batch re-launched)"),
                 "parallelism": f"world_size {world}: " + ("one batch split into contiguous query blocks" if args.strong
                                                           else "rows sharded over the ranks, one full batch per rank per step"),
-                "batches_in_flight": len(streams), "dataset_build_s": round(t_gen, 2),
+                "streams": len(streams), "batches_per_launch": G, "batches_in_flight": len(streams) * G,
+                "dataset_build_s": round(t_gen, 2),
             },
             "timing": {
                 "how": "median of repeated K-step regions, each between barrier+synchronize; GPU time of a region from "

@@ -23,7 +23,9 @@ SYMBOLS = (
     "gvl_last_error",
     "gvl_pack_variants",
     "gvl_pack_genotypes",
+    "gvl_pack_slots",
     "gvl_reconstruct",
+    "gvl_reconstruct_many",
     "gvl_get_diffs_sparse",
     "gvl_hap_offsets",
     "gvl_get_reference",
@@ -37,13 +39,14 @@ SYMBOLS = (
     "gvl_realign_tracks",
     "gvl_prepare_request",
     "gvl_loader_slot_bytes",
+    "gvl_loader_table_bytes",
     "gvl_loader_create",
     "gvl_loader_start_epoch",
     "gvl_loader_next",
     "gvl_loader_destroy",
 )
 
-ABI_VERSION = 2          # include/gvl_hip.h: GVL_ABI_VERSION
+ABI_VERSION = 3          # include/gvl_hip.h: GVL_ABI_VERSION
 GVL_ONEHOT_LC = 0
 GVL_ONEHOT_CL = 1
 
@@ -58,6 +61,7 @@ class GvlStatic(C.Structure):
         ("n_variants", _i64), ("alt_len", _i64), ("vrec", _vp),
         ("geno_o_starts", _vp), ("geno_o_stops", _vp), ("n_geno_offsets", _i64),
         ("geno_v_idxs", _vp), ("n_geno", _i64), ("pad_char", C.c_uint8), ("geno_rec", _vp),
+        ("slot_rec", _vp),
     ]
 
 
@@ -83,7 +87,7 @@ class GvlLoaderConfig(C.Structure):
         ("rc_neg", C.c_int32), ("deterministic", C.c_int32), ("seed", C.c_uint64),
         ("want_haps", C.c_int32), ("want_onehot", C.c_int32), ("onehot_layout", C.c_int32),
         ("in_flight", C.c_int32), ("n_slots", C.c_int32), ("slot_arenas", C.POINTER(_vp)),
-        ("threaded", C.c_int32),
+        ("threaded", C.c_int32), ("group", C.c_int32),
     ]
 
 
@@ -135,9 +139,10 @@ def load() -> C.CDLL:
         fn = getattr(lib, name, None)
         if fn is None:
             raise GvlError(f"{p} does not export {name}")
-        if name not in ("gvl_last_error", "gvl_loader_slot_bytes"):
+        if name not in ("gvl_last_error", "gvl_loader_slot_bytes", "gvl_loader_table_bytes"):
             fn.restype = C.c_int
     lib.gvl_loader_slot_bytes.restype = C.c_int64
+    lib.gvl_loader_table_bytes.restype = C.c_int64
     _LIB = lib
     return lib
 

@@ -149,6 +149,8 @@ struct ReconArgs {
     const gvl_vrec *vrec; const i64 *alt_offsets; const u8 *alt_alleles; i64 alt_len;
     i64 n_variants;
     const i64 *go_starts; const i64 *go_stops; const int *geno_v_idxs; const gvl_grec *grec;
+    const gvl_srec *srec;   // slot-major records (nullable): 8 per genotype slot, no CSR hop
+    int n_contigs; i64 n_geno_offsets;
     // batch
     const int *regions; i64 regions_stride; const int *shifts; const i64 *geno_offset_idx;
     const u8 *keep; const i64 *keep_offsets; const u8 *to_rc; const i64 *out_offsets;
@@ -655,7 +657,8 @@ __device__ __forceinline__ int wave_scan_exclusive(int v, int &inclusive) {
 // ---------------------------------------------------------------------------------
 struct RowIn {
     i64 c_s, R, ref_start, shift, o_s, keep_off, row_base;
-    int n_var, L, rc, flags;     // flags: 1 = no work (row out of range / chunk past the row), 2 = scalar path, 4 = zero fill, 8 = packable (<= 8 variants)
+    int n_var, L, rc, flags;     // flags: 1 = no work (row out of range / chunk past the row), 2 = scalar path, 4 = zero fill, 8 = packable (<= 8 variants),
+                                 // 16 = records come from the slot-major table (o_s = the slot, n_var = 8 until the line is read)
 };
 template <bool ANNOT>
 struct RowPlan {
@@ -700,7 +703,7 @@ __device__ __forceinline__ int seg8_scan_exclusive(int v, int j) {
 // ---------------------------------------------------------------------------------
 template <bool ANNOT>
 __device__ __forceinline__ void packed_plan(const ReconArgs &A, const RowIn *rin, RowPlan<ANNOT> *plan, TripDesc *desc,
-                                            RowMeta *meta, const int lane, const int lo_clip, const bool has_keep) {
+                                            RowMeta *meta, const i32x4 *lrec, const int lane, const int lo_clip, const bool has_keep) {
     const int r = lane >> 3, j = lane & 7, seg_base = lane & ~7;
     const RowIn &ri = rin[r];
     RowPlan<ANNOT> &pl = plan[r];
@@ -719,9 +722,16 @@ __device__ __forceinline__ void packed_plan(const ReconArgs &A, const RowIn *rin
 
     // ---- P2: records ----------------------------------------------------------------
     int pos = 0, d = 0, alen = 0, inl = 0, vi = 0; i64 a0 = 0;
+    const bool ell = (rflags & 16) != 0;               // slot-major records: 8 entries at srec[slot * 8]
     bool valid = elig && j < n_var;
     if (valid) {
-        if (A.grec) {
+        if (ell) {
+            const i32x4 rec = lrec[lane];                  // parked in LDS by P1: lane = row x 8 + entry
+            const u32 e = (u32)rec.z;
+            valid = e != GVL_SREC_EMPTY;
+            pos = rec.x; d = rec.y; alen = (int)(e >> 8); inl = (int)(e & 0xFF); vi = 0;
+            a0 = (i64)(u32)rec.w;                          // no alt_offsets hop
+        } else if (A.grec) {
             const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.grec + (o_s + j));
             pos = rec.x; d = rec.y; alen = (int)((u32)rec.z >> 8); inl = rec.z & 0xFF; vi = rec.w;
             if (!(d == 0 && alen == 1)) a0 = A.alt_offsets[vi];
@@ -732,10 +742,10 @@ __device__ __forceinline__ void packed_plan(const ReconArgs &A, const RowIn *rin
             a0 = A.alt_offsets[v];
             pos = rec.x; d = rec.y; alen = rec.z; inl = rec.w; vi = v;
         }
-        if (has_keep) valid = A.keep[ri.keep_off + j] != 0;
+        if (valid && has_keep) valid = A.keep[ri.keep_off + j] != 0;
     }
     const bool weird = valid && (pos < 0 || pos >= (1 << 30) || d <= -(1 << 30) || d >= (1 << 30) || alen < 0 ||
-                                 alen >= (A.grec ? 0xFFFFFF : (1 << 30)));
+                                 alen >= ((ell || A.grec) ? 0xFFFFFF : (1 << 30)));
     ok = ok && seg_byte(__builtin_amdgcn_ballot_w64(weird)) == 0;
     if (!ok) valid = false;
 
@@ -968,6 +978,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     __shared__ RowPlan<ANNOT> plan[WG_WAVES];
     __shared__ TripDesc desc[WG_WAVES];
     __shared__ RowMeta meta[WG_WAVES];
+    __shared__ i32x4 lrec[WG_WAVES * GVL_SLOT_RECS];   // slot-major records of the 8 rows (read once, by wave 0)
 
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
@@ -984,58 +995,91 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         luts.oh_rc[tid] = __builtin_bswap32(d);
         luts.comp[tid] = comp_byte((u32)tid);
     }
-    // ---- P1: row parameters, one lane per row --------------------------------------
-    if (tid < WG_WAVES) {
+    // ---- P1 (wave 0): row parameters, one lane per row; then -- second memory level, side by side --
+    // the contig bounds and the rows' slot-major variant records (lane = row x 8 + entry: the eight
+    // 128-byte lines of the workgroup in ONE wave-load), all parked in LDS.  After the barrier no wave
+    // needs a global read before its plan, so the reference bytes it requests next (below) stay in
+    // flight behind nothing.
+    const bool use_srec = A.srec != nullptr && !A.ref_only && planned_ok && !(A.dbg & 512) && !ANNOT;
+    if (tid < WAVE) {
+        // Every load of a level is issued before anything waits (no branch in between: an absent
+        // array is replaced by a pointer that is always readable, and a lane without a row reads
+        // row 0), so P1 costs two memory round trips, not one per array.
+        const i64 k_raw = (i64)blockIdx.x * WG_WAVES + tid;
+        const bool row_lane = tid < WG_WAVES && k_raw < A.n_rows;
+        const i64 k = row_lane ? k_raw : 0;
+        const i64 query = A.ploidy_shift >= 0 ? (k >> A.ploidy_shift) : (i64)((u32)k / (u32)A.ploidy);
+        const int *reg = A.regions + query * A.regions_stride;
+        const int *const dmy4 = A.regions;                                       // >= 12 readable bytes
+        const i64 *const dmy8 = reinterpret_cast<const i64 *>(A.ref_offsets);    // >= 8 readable bytes
+        // ---- level 1
+        const int l_c = reg[0], l_start = reg[1], l_end = reg[2];
+        const int l_shift = *(A.ref_only ? dmy4 : A.shifts + k);
+        const i64 l_oidx = *(A.ref_only ? dmy8 : A.geno_offset_idx + k);
+        const u8 l_rc = *(A.to_rc ? A.to_rc + k : reinterpret_cast<const u8 *>(dmy4));
+        const i64 l_oo0 = *(A.out_offsets ? A.out_offsets + k : dmy8);
+        const i64 l_oo1 = *(A.out_offsets ? A.out_offsets + k + 1 : dmy8);
+        const i64 l_ko = *(has_keep && !A.ref_only ? A.keep_offsets + k : dmy8);
         RowIn ri;
-        ri.c_s = ri.R = ri.ref_start = ri.shift = ri.o_s = ri.keep_off = ri.row_base = 0;
-        ri.n_var = ri.L = ri.rc = 0;
-        ri.flags = 1;
-        const i64 k = (i64)blockIdx.x * WG_WAVES + tid;
-        if (k < A.n_rows) {
-            const i64 query = A.ploidy_shift >= 0 ? (k >> A.ploidy_shift) : (i64)((u32)k / (u32)A.ploidy);
-            const int *reg = A.regions + query * A.regions_stride;
-            const i64 c_idx = reg[0];
-            ri.ref_start = reg[1];
-            i64 o_idx = 0;
-            int fl = 0;
-            if (!A.ref_only) {
-                ri.shift = A.shifts[k];
-                o_idx = A.geno_offset_idx[k];
-            } else if (ri.ref_start >= (i64)reg[2]) {
-                fl |= 4;                                 // reference/mod.rs:16-18
-            }
-            ri.rc = A.to_rc ? (int)A.to_rc[k] : 0;
-            if (A.out_offsets) {
-                ri.row_base = A.out_offsets[k];
-                ri.L = (int)(A.out_offsets[k + 1] - ri.row_base);
-            } else {
-                ri.row_base = k * A.fixed_len;
-                ri.L = (int)A.fixed_len;
-            }
-            if (A.out_offsets_w && chunk == 0) {
-                A.out_offsets_w[k] = ri.row_base;
-                if (k == A.n_rows - 1) A.out_offsets_w[k + 1] = ri.row_base + ri.L;
-            }
-            if (lo_clip >= ri.L) {
-                fl |= 1;
-            } else {
-                ri.c_s = A.ref_offsets[c_idx];
-                ri.R = A.ref_offsets[c_idx + 1] - ri.c_s;
-                if (!A.ref_only) {
-                    ri.o_s = A.go_starts[o_idx];
-                    const i64 nv = A.go_stops[o_idx] - ri.o_s;
-                    ri.n_var = nv < 0 ? 0 : (nv > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)nv);
-                    if (A.dbg & 1) ri.n_var = 0;
-                    if (has_keep) ri.keep_off = A.keep_offsets[k];
-                }
-                if (ri.shift < 0 || ri.shift >= (1 << 30) || !planned_ok) fl |= 2;
-                else if (ri.n_var <= 8 && !(A.dbg & 512)) fl |= 8;      // planned by wave 0 with the other rows
-            }
-            ri.flags = fl;
+        ri.c_s = ri.R = ri.o_s = 0;
+        ri.n_var = 0;
+        ri.ref_start = l_start;
+        ri.shift = A.ref_only ? 0 : (i64)l_shift;
+        ri.keep_off = (has_keep && !A.ref_only) ? l_ko : 0;
+        ri.rc = A.to_rc ? (int)l_rc : 0;
+        ri.row_base = A.out_offsets ? l_oo0 : k * A.fixed_len;
+        ri.L = A.out_offsets ? (int)(l_oo1 - l_oo0) : (int)A.fixed_len;
+        const i64 o_idx = A.ref_only ? 0 : l_oidx;
+        int fl = 0;
+        if (A.ref_only && (i64)l_start >= (i64)l_end) fl |= 4;                   // reference/mod.rs:16-18
+        const bool shift_ok = !(ri.shift < 0 || ri.shift >= (1 << 30));
+        if (!shift_ok || !planned_ok) fl |= 2;
+        if (use_srec && shift_ok && !(A.dbg & 1)) fl |= 16;
+        if (!row_lane || lo_clip >= ri.L) fl = 1;
+        if (row_lane && A.out_offsets_w && chunk == 0) {
+            A.out_offsets_w[k] = ri.row_base;
+            if (k == A.n_rows - 1) A.out_offsets_w[k + 1] = ri.row_base + ri.L;
         }
-        rin[tid] = ri;
-        RowMeta m0; m0.nseg = m0.npatch = m0.bad = m0.slow = m0.ready = m0.pad0_ = m0.pad1_ = m0.pad2_ = 0;
-        meta[tid] = m0;
+        // ---- level 2: contig bounds, CSR bounds (rows that do not use the slot-major records), and the
+        // rows' slot-major records, lane (r, j) = entry j of row r's slot
+        const i64 c_idx = (l_c >= 0 && l_c < A.n_contigs) ? (i64)l_c : 0;       // (out of contract otherwise: clamp)
+        const bool csr = !A.ref_only && !(fl & 17);
+        const i64 o_safe = (csr && o_idx >= 0 && o_idx < A.n_geno_offsets) ? o_idx : 0;
+        const i64 l_cs = A.ref_offsets[c_idx], l_ce = A.ref_offsets[c_idx + 1];
+        const i64 l_gs = *(csr ? A.go_starts + o_safe : dmy8);
+        const i64 l_ge = *(csr ? A.go_stops + o_safe : dmy8);
+        if (use_srec) {
+            const int r = lane >> 3;
+            const int fl_r = bperm(r, fl);
+            const u32 o_lo = (u32)bperm(r, (int)(u32)(u64)o_idx), o_hi = (u32)bperm(r, (int)(u32)((u64)o_idx >> 32));
+            const i64 o_r = (i64)(((u64)o_hi << 32) | o_lo);
+            const bool want = (fl_r & 17) == 16 && o_r >= 0 && o_r < A.n_geno_offsets;
+            i32x4 rec = *reinterpret_cast<const i32x4 *>(A.srec + ((want ? o_r : 0) * GVL_SLOT_RECS + (lane & 7)));
+            if (!want) { rec.x = 0; rec.y = 0; rec.z = (int)GVL_SREC_EMPTY; rec.w = 0; }
+            lrec[lane] = rec;
+        }
+        if (fl != 1) {
+            ri.c_s = l_cs;
+            ri.R = l_ce - l_cs;
+            if (fl & 16) {
+                // the variant count is known once the line is read (a slot with more than 8 falls
+                // back to the CSR)
+                ri.o_s = o_idx;
+                ri.n_var = GVL_SLOT_RECS;
+            } else if (csr) {
+                ri.o_s = l_gs;
+                const i64 nv = l_ge - l_gs;
+                ri.n_var = nv < 0 ? 0 : (nv > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)nv);
+                if (A.dbg & 1) ri.n_var = 0;
+            }
+            if (!(fl & 2) && ri.n_var <= 8 && !(A.dbg & 512)) fl |= 8;           // packable: planned with the other rows
+        }
+        ri.flags = fl;
+        if (tid < WG_WAVES) {
+            rin[tid] = ri;
+            RowMeta m0; m0.nseg = m0.npatch = m0.bad = m0.slow = m0.ready = m0.pad0_ = m0.pad1_ = m0.pad2_ = 0;
+            meta[tid] = m0;
+        }
     }
     GVL_STAMP(1);
     __syncthreads();
@@ -1059,35 +1103,105 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     //  * the other packable rows are SLOW: the first slow wave plans all of them at once
     //    (packed_plan), the other slow waves wait for their flag.
     //  * rows with more than 8 variants run the per-wave scans (P2 + P3 further down).
-    const bool packable = (flags & 11) == 8;
+    bool packable = (flags & 11) == 8;
+    int row_n_var = rfl(ri.n_var);        // (a slot-major row that overflows its line re-reads these from the CSR)
+    i64 row_o_s = rfl64(ri.o_s);
+
+    // ---- the "one reference run" reading of the row: n_lead pad bytes, then the contig from the
+    // shifted origin r0, then pad.  It depends on the row parameters only, it is exact for a row
+    // without indels and for the part of any row in front of its first indel -- so its reference
+    // bytes are requested NOW, next to the variant records, instead of after the plan: one dependent
+    // memory level less for SNP-only rows, and a prefetch into L2 for the others.
+    int g_n_lead = 0, g_t_end = 0, g_r0 = 0; i64 g_delta = 0; bool g_ok = false;
+    {
+        const i64 rs = rfl64(ri.ref_start);
+        if (!(flags & 3) && rs > -(1 << 30) && rs < (1 << 30)) {
+            const int ref_start = (int)rs;
+            const i64 R = rfl64(ri.R);
+            const int shift_i = (int)rfl64(ri.shift);
+            const int raw = ref_start < 0 ? -ref_start : 0;
+            const int shifted0 = shift_i < raw ? shift_i : raw;
+            g_n_lead = (raw - shifted0 < L) ? raw - shifted0 : L;
+            g_r0 = (int)imin((i64)(ref_start < 0 ? 0 : ref_start) + (shift_i - shifted0), R);
+            g_t_end = g_n_lead;
+            const int u = L - g_n_lead;
+            if (u > 0) {
+                const int w = (int)imin((i64)u, R - g_r0);
+                if (w > 0) g_t_end = g_n_lead + w;
+            }
+            g_delta = c_s + g_r0 - g_n_lead;
+            g_ok = true;
+        }
+    }
+    const int lane4 = GROUP * lane;
+    // slot-major records of this row: parked in LDS by wave 0 (no global read, no vmcnt wait).  Then the
+    // speculative reference reads: on the slot-major path nothing between here and pass A waits for a
+    // global load, so they stay in flight while the row is classified and planned.
+    const bool ell = (flags & 16) != 0 && packable;
+    i32x4 srec_v = {0, 0, 0, 0};
+    if (ell) srec_v = lrec[wave * GVL_SLOT_RECS + (lane & (GVL_SLOT_RECS - 1))];
+    const bool sp_on = g_ok && !(flags & 4) && !(A.dbg & (4 | 128)) && (ell || row_n_var == 0);
+    // lane u decides for trip u (full trips only), one ballot; the loads then differ by an immediate
+    // offset only.  (The scalar unit is shared by the waves of a CU: per-trip scalar arithmetic in the
+    // head of every wave is what this avoids.)
+    const u8 *const sp_base = A.ref + (g_delta + lo_clip) + (u32)lane4;
+    u32 spmask = 0;
+    if (sp_on) {
+        const int p0 = lo_clip + lane * TRIP;
+        const bool inside = lane < CHUNK_TRIPS && p0 >= g_n_lead && p0 + TRIP <= g_t_end && p0 + TRIP <= hi_clip &&
+                            g_delta + p0 >= 0 && g_delta + p0 + TRIP <= A.ref_len;
+        spmask = (u32)__builtin_amdgcn_ballot_w64(inside);
+    }
+    u32 wq[CHUNK_TRIPS];
+#pragma unroll
+    for (int u = 0; u < CHUNK_TRIPS; ++u) {
+        wq[u] = 0;
+        if ((spmask >> u) & 1u) wq[u] = load_u32_unaligned(sp_base + u * TRIP);
+    }
+
     int f_pos = 0, f_inl = 0, f_vi = 0;
     bool f_valid = false, is_fast = false;
     if (packable) {
-        const int n_var = rfl(ri.n_var);
-        const i64 o_s = rfl64(ri.o_s);
         int d = 0, alen = 0;
-        f_valid = lane < n_var;
-        if (f_valid) {
-            if (A.grec) {
-                const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.grec + (o_s + lane));
-                f_pos = rec.x; d = rec.y; alen = (int)((u32)rec.z >> 8); f_inl = rec.z & 0xFF; f_vi = rec.w;
-            } else {
-                int v = A.geno_v_idxs[o_s + lane];
-                v = v < 0 ? 0 : ((i64)v >= A.n_variants ? (int)(A.n_variants - 1) : v);
-                const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.vrec + v);
-                f_pos = rec.x; d = rec.y; alen = rec.z; f_inl = rec.w & 0xFF; f_vi = v;
+        bool rec_valid;
+        if (ell) {
+            const u32 e = (u32)srec_v.z;
+            if ((u32)rdl((int)e, 0) == GVL_SREC_OVERFLOW) {
+                // more than 8 variants: this row is read through the CSR by the per-wave scans
+                packable = false;
+                flags &= ~(8 | 16);
+                const i64 o_idx = row_o_s;
+                row_o_s = rfl64(A.go_starts[o_idx]);
+                const i64 nv = rfl64(A.go_stops[o_idx]) - row_o_s;
+                row_n_var = nv < 0 ? 0 : (nv > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)nv);
             }
-            if (has_keep) f_valid = A.keep[rfl64(ri.keep_off) + lane] != 0;
+            rec_valid = lane < GVL_SLOT_RECS && e != GVL_SREC_EMPTY;
+            f_pos = srec_v.x; d = srec_v.y; alen = (int)(e >> 8); f_inl = (int)(e & 0xFF); f_vi = 0;
+        } else {
+            rec_valid = lane < row_n_var;
+            if (rec_valid) {
+                if (A.grec) {
+                    const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.grec + (row_o_s + lane));
+                    f_pos = rec.x; d = rec.y; alen = (int)((u32)rec.z >> 8); f_inl = rec.z & 0xFF; f_vi = rec.w;
+                } else {
+                    int v = A.geno_v_idxs[row_o_s + lane];
+                    v = v < 0 ? 0 : ((i64)v >= A.n_variants ? (int)(A.n_variants - 1) : v);
+                    const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.vrec + v);
+                    f_pos = rec.x; d = rec.y; alen = rec.z; f_inl = rec.w & 0xFF; f_vi = v;
+                }
+            }
         }
+        f_valid = rec_valid;
+        if (f_valid && has_keep) f_valid = A.keep[rfl64(ri.keep_off) + lane] != 0;
         const i64 rs = rfl64(ri.ref_start);
         const int pos_prev = dpp_mov<0x138, 0xf>(-1, f_pos);               // wave_shr:1
         const u64 m_slow = __builtin_amdgcn_ballot_w64(
             (f_valid && (d != 0 || alen != 1 || f_pos < 0 || (i64)f_pos + 1 > rfl64(ri.R))) ||
-            (lane > 0 && lane < n_var && f_pos == pos_prev));
-        is_fast = m_slow == 0 && rs > -(1 << 30) && rs < (1 << 30) && !(A.dbg & 32);
+            (lane > 0 && rec_valid && f_pos == pos_prev));
+        is_fast = packable && m_slow == 0 && rs > -(1 << 30) && rs < (1 << 30) && !(A.dbg & 32);
         // tell the workgroup: the slow flag, then one tick of the "decided" counter (meta[0].pad0_)
         if (lane == 0) {
-            if (!is_fast) meta[wave].slow = 1;
+            if (packable && !is_fast) meta[wave].slow = 1;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __hip_atomic_fetch_add(&meta[0].pad0_, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -1106,7 +1220,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         const u64 m_slow_rows = __builtin_amdgcn_ballot_w64(lane < WG_WAVES && meta[lane < WG_WAVES ? lane : 0].slow != 0);
         if (wave == __builtin_ctzll(m_slow_rows)) {
             __builtin_amdgcn_s_setprio(3);      // the other slow rows wait for this wave
-            packed_plan<ANNOT>(A, rin, plan, desc, meta, lane, lo_clip, has_keep);
+            packed_plan<ANNOT>(A, rin, plan, desc, meta, lrec, lane, lo_clip, has_keep);
         } else {
             while (__hip_atomic_load(&meta[wave].ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
                 __builtin_amdgcn_s_sleep(2);
@@ -1122,13 +1236,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         // whichever way the shift completes (:115-146) or runs out (:200-205), ref_idx lands on
         // ref_idx0 + shift; SNP i sits at n_lead + (pos_i - r0) iff pos_i >= r0 and that is
         // inside the row (:154-158).
-        const int ref_start = (int)rfl64(ri.ref_start);
-        const i64 R = rfl64(ri.R);
-        const int shift_i = (int)rfl64(ri.shift);
-        const int raw = ref_start < 0 ? -ref_start : 0;
-        const int shifted0 = shift_i < raw ? shift_i : raw;
-        const int n_lead = (raw - shifted0 < L) ? raw - shifted0 : L;
-        const int r0 = (int)imin((i64)(ref_start < 0 ? 0 : ref_start) + (shift_i - shifted0), R);
+        const int n_lead = g_n_lead, r0 = g_r0, t_end = g_t_end;      // (is_fast implies g_ok)
         const int ao = n_lead + (f_pos - r0);
         const bool app = f_valid && f_pos >= r0 && (f_pos - r0) < (L - n_lead);
         const u64 m_p = __builtin_amdgcn_ballot_w64(app && ao >= lo_clip && ao < hi_clip);
@@ -1139,14 +1247,6 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         }
         npatch = __builtin_popcountll(m_p);
         const int lead_kept = (n_lead > 0 && n_lead > lo_clip && 0 < hi_clip) ? 1 : 0;
-        int t_end = n_lead;
-        {
-            const int u = L - n_lead;
-            if (u > 0) {
-                const int w = (int)imin((i64)u, R - r0);
-                if (w > 0) t_end = n_lead + w;
-            }
-        }
         const bool tail_pad = t_end < L && L > lo_clip && t_end < hi_clip;
         const bool tail_ref = t_end > n_lead && t_end > lo_clip && n_lead < hi_clip;
         nseg = lead_kept + (tail_ref ? 1 : 0) + (tail_pad ? 1 : 0);
@@ -1174,8 +1274,8 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
 
     if (!(flags & 3) && !packable) {
         // ---- P2 + P3, 64 variants per trip with carries between trips ------------------------
-        const int n_var = rfl(ri.n_var);
-        const i64 o_s = rfl64(ri.o_s);
+        const int n_var = row_n_var;
+        const i64 o_s = row_o_s;
         const int ref_start = (int)rfl64(ri.ref_start);
         const i64 R = rfl64(ri.R);
         const i64 keep_off = has_keep ? rfl64(ri.keep_off) : 0;
@@ -1701,14 +1801,19 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     if (mmask) { mu_a = __builtin_ctz(mmask); mmask &= mmask - 1; multi_issue(mu_a, wa); }
     if (mmask) { mu_b = __builtin_ctz(mmask); mmask &= mmask - 1; multi_issue(mu_b, wb); }
     // pass A: class-0 trips, 4 bytes per lane from one scalar base (computed in P3b)
-    u32 wq[CHUNK_TRIPS];
-    const int lane4 = GROUP * lane;
+    {
+        // trips whose speculative read is the one the plan asks for (lane u holds trip u's descriptor)
+        const u64 want = ((u64)d_ldhi << 32) | d_ldlo;
+        const u64 spec = (u64)(A.ref + (g_delta + lo_clip)) + (u64)(u32)(lane * TRIP);
+        const u32 have = spmask & (u32)__builtin_amdgcn_ballot_w64(lane < CHUNK_TRIPS && d_cls == 0 && want == spec);
+        const u32 todo = umask & ~have;
 #pragma unroll
-    for (int u = 0; u < CHUNK_TRIPS; ++u) {
-        wq[u] = 0;
-        if ((umask >> u) & 1u) {
-            const u8 *src = reinterpret_cast<const u8 *>(((u64)(u32)rdl((int)d_ldhi, u) << 32) | (u32)rdl((int)d_ldlo, u));
-            if (lane4 < limit - (lo_clip + u * TRIP) && !(A.dbg & 4)) wq[u] = load_u32_unaligned(src + (u32)lane4);
+        for (int u = 0; u < CHUNK_TRIPS; ++u) {
+            if ((todo >> u) & 1u) {
+                const u8 *src = reinterpret_cast<const u8 *>(((u64)(u32)rdl((int)d_ldhi, u) << 32) | (u32)rdl((int)d_ldlo, u));
+                wq[u] = 0;
+                if (lane4 < limit - (lo_clip + u * TRIP) && !(A.dbg & 4)) wq[u] = load_u32_unaligned(src + (u32)lane4);
+            }
         }
     }
     if (mu_a >= 0) multi_finish(mu_a, wa);
@@ -2110,6 +2215,38 @@ __global__ __launch_bounds__(256) void pack_genotypes_kernel(const int *geno_v_i
     gvl_grec g;
     g.pos = r.x; g.ilen = r.y; g.alen_inl = (alen << 8) | ((u32)r.w & 0xFFu); g.v_idx = v;
     out[i] = g;
+}
+
+// slot-major records: 8 lanes per genotype slot, one 128-byte line each
+__global__ __launch_bounds__(256) void pack_slots_kernel(const i64 *go_starts, const i64 *go_stops, i64 n_slots,
+                                                          const int *geno_v_idxs, const gvl_vrec *vrec,
+                                                          const i64 *alt_offsets, i64 n_variants, gvl_srec *out) {
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 o = t >> 3;
+    const int j = (int)(t & 7);
+    if (o >= n_slots) return;
+    const i64 o_s = go_starts[o];
+    const i64 n = go_stops[o] - o_s;
+    gvl_srec r;
+    r.pos = 0; r.ilen = 0; r.alen_inl = GVL_SREC_EMPTY; r.a0 = 0;
+    bool over = n > GVL_SLOT_RECS;
+    int v = 0;
+    i32x4 vr = {0, 0, 0, 0};
+    if (!over && j < n) {
+        v = geno_v_idxs[o_s + j];
+        v = v < 0 ? 0 : ((i64)v >= n_variants ? (int)(n_variants - 1) : v);
+        vr = *reinterpret_cast<const i32x4 *>(vrec + v);
+    }
+    // an allele too long for the 24-bit field sends the whole slot through the CSR
+    const bool big = !over && j < n && (vr.z < 0 || vr.z >= 0xFFFFFF);
+    over = over || (__builtin_amdgcn_ballot_w64(big) >> ((threadIdx.x & 63) & ~7) & 0xFFull) != 0;
+    if (over) {
+        if (j == 0) r.alen_inl = GVL_SREC_OVERFLOW;
+    } else if (j < n) {
+        r.pos = vr.x; r.ilen = vr.y; r.alen_inl = ((u32)vr.z << 8) | ((u32)vr.w & 0xFFu);
+        r.a0 = (u32)(u64)alt_offsets[v];
+    }
+    out[t] = r;
 }
 
 // ---------------------------------------------------------------------------
@@ -2803,7 +2940,9 @@ __global__ __launch_bounds__(256) void prepare_request_kernel(const PrepArgs A) 
     int start = src[1], end = src[2];
     const int len = end - start;
     if (A.jitter > 0) {                                              // _query.py:166-171
-        const u64 h = hash4_dev(A.seed, A.counter, (u64)b, 0x6a69747465ull);
+        // keyed by the DATASET index (not the row's place in the batch): ranks / batches that hold
+        // different samples draw independently, whoever holds sample `id` in this epoch draws the same
+        const u64 h = hash4_dev(A.seed, A.counter, (u64)id, 0x6a69747465ull);
         start += (int)(h % (u64)(2 * A.jitter + 1)) - A.jitter;
         end = start + len;
     }
@@ -2820,7 +2959,7 @@ __global__ __launch_bounds__(256) void prepare_request_kernel(const PrepArgs A) 
         // length delta of this haplotype inside the (jittered) window: genotypes/mod.rs:48-85
         const i64 diff = (i64)(int)row_diff_core(A.D, goi, false, 0, true, (i64)start, (i64)end);
         const i64 max_shift = (diff > 0 ? diff : 0) + ((i64)len - A.output_length > 0 ? (i64)len - A.output_length : 0);
-        const u64 h = hash4_dev(A.seed, A.counter, (u64)k, 0x7368696674ull);
+        const u64 h = hash4_dev(A.seed, A.counter, (u64)(id * A.ploidy + p), 0x7368696674ull);
         shift = (int)(h % (u64)(max_shift + 1));
     }
     A.shifts[k] = shift;
@@ -2870,6 +3009,8 @@ int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
 //    32  no scan-free plan for SNP-only rows (they join the packed plan)
 //   512  no packable rows at all (every row runs the per-wave scans)
 //    16  ignore gvl_static.geno_rec (records come from geno_v_idxs -> vrec)
+//    64  ignore gvl_static.slot_rec (rows find their records through the CSR)
+//   128  no speculative reference reads in front of the plan
 // and 1 / 2 / 4 = timing ablations (no variants / no stores / no loads).
 int g_debug_override = -1;
 int debug_flags() {
@@ -2946,16 +3087,31 @@ int gvl_pack_genotypes(const gvl_static *st, gvl_grec *grec_out, void *stream) {
     return check_launch("gvl_pack_genotypes");
 }
 
-int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *out, void *stream) {
+int gvl_pack_slots(const gvl_static *st, gvl_srec *srec_out, void *stream) {
+    if (!st || st->n_geno_offsets < 0 || st->n_variants < 0) return fail(GVL_ERR_INVALID, "%s", "gvl_pack_slots: bad arguments");
+    if (st->n_geno_offsets == 0) return GVL_OK;
+    if (st->alt_len >= (1ll << 32)) return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_pack_slots: alt_alleles of 4 GiB or more (use the CSR path)");
+    if (!st->geno_o_starts || !st->geno_o_stops || !srec_out || (st->n_geno > 0 && (!st->geno_v_idxs || !st->vrec || !st->alt_offsets || st->n_variants == 0)))
+        return fail(GVL_ERR_INVALID, "%s", "gvl_pack_slots: NULL array (vrec from gvl_pack_variants is required)");
+    const i64 grid = (st->n_geno_offsets * GVL_SLOT_RECS + 255) / 256;
+    if (grid > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_pack_slots: too many slots");
+    pack_slots_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(
+        (const i64 *)st->geno_o_starts, (const i64 *)st->geno_o_stops, st->n_geno_offsets, st->geno_v_idxs, st->vrec,
+        (const i64 *)st->alt_offsets, st->n_variants, srec_out);
+    return check_launch("gvl_pack_slots");
+}
+
+// validate one batch and fill its kernel arguments; `variant` = which template instance it needs
+static int fill_recon_args(const gvl_static *st, const gvl_batch *bt, const gvl_out *out, ReconArgs &A, int *chunks,
+                           int *variant) {
     if (!st || !bt || !out) return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: NULL struct");
     if (bt->batch < 0 || bt->ploidy <= 0) return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: bad batch/ploidy");
     if (!out->haps && !out->onehot) return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: no output buffer");
-    if (bt->batch == 0) return GVL_OK;
     if ((st->ref_len > 0 && !st->ref) || !st->ref_offsets || !st->geno_o_starts || !st->geno_o_stops)
         return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: NULL static array");
     if (st->n_geno > 0 && (!st->vrec || !st->alt_offsets || !st->geno_v_idxs))
         return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: NULL variant table (vrec from gvl_pack_variants is required)");
-    if (!bt->regions || !bt->shifts || !bt->geno_offset_idx || bt->regions_stride < 3)
+    if (bt->batch > 0 && (!bt->regions || !bt->shifts || !bt->geno_offset_idx || bt->regions_stride < 3))
         return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: NULL/invalid batch array");
     if (bt->output_length < 0 && !bt->out_offsets)
         return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: ragged mode needs out_offsets (gvl_hap_offsets)");
@@ -2965,8 +3121,8 @@ int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *ou
         return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_reconstruct: channel-major one-hot needs fixed-length rows");
     if (out->onehot_layout != GVL_ONEHOT_LC && out->onehot_layout != GVL_ONEHOT_CL)
         return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: bad onehot_layout");
+    if (bt->batch * bt->ploidy > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: batch too large for one launch");
 
-    ReconArgs A;
     memset(&A, 0, sizeof(A));
     A.ref = st->ref; A.ref_len = st->ref_len; A.ref_offsets = (const i64 *)st->ref_offsets;
     A.vrec = st->vrec; A.alt_offsets = (const i64 *)st->alt_offsets; A.alt_alleles = st->alt_alleles;
@@ -2974,6 +3130,9 @@ int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *ou
     A.go_starts = (const i64 *)st->geno_o_starts; A.go_stops = (const i64 *)st->geno_o_stops;
     A.geno_v_idxs = st->geno_v_idxs;
     A.grec = (debug_flags() & 16) ? nullptr : st->geno_rec;
+    A.srec = (debug_flags() & (64 | 512 | 8)) ? nullptr : st->slot_rec;
+    A.n_geno_offsets = st->n_geno_offsets;
+    A.n_contigs = (int)(st->n_contigs < 0 ? 0 : (st->n_contigs > 0x7FFFFFFFll ? 0x7FFFFFFF : st->n_contigs));
     A.regions = bt->regions; A.regions_stride = bt->regions_stride; A.shifts = bt->shifts;
     A.geno_offset_idx = (const i64 *)bt->geno_offset_idx;
     A.keep = bt->keep; A.keep_offsets = (const i64 *)bt->keep_offsets; A.to_rc = bt->to_rc;
@@ -2986,23 +3145,54 @@ int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *ou
     i64 ml = bt->out_offsets ? bt->max_row_len : bt->output_length;
     if (bt->out_offsets && bt->output_length > ml) ml = bt->output_length;
     if (ml < 0) ml = 0;
-    int chunks = 1;
-    if (pick_chunk(ml, &chunks, &A.chunk_len)) return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: too many chunks");
+    if (pick_chunk(ml, chunks, &A.chunk_len)) return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: too many chunks");
     A.ref_only = 0;
     A.dbg = debug_flags();
     A.pad = st->pad_char;
     A.haps = out->haps; A.onehot = out->onehot;
     A.av = out->annot_v_idxs; A.ap = out->annot_ref_pos; A.out_offsets_w = (i64 *)out->out_offsets;
     A.stamps = g_stamps;
-
-    const i64 grid = (A.n_rows + WG_WAVES - 1) / WG_WAVES;
-    if (grid <= 0) return GVL_OK;
-    if (A.n_rows > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: batch too large for one launch");
     const bool annot = out->annot_v_idxs || out->annot_ref_pos;
     const int oh = !out->onehot ? OH_NONE : (out->onehot_layout == GVL_ONEHOT_CL ? OH_CL : OH_LC);
-    recon_fn fn = recon_table(oh, out->haps != nullptr, annot);
+    *variant = oh | ((out->haps != nullptr) ? 4 : 0) | (annot ? 8 : 0);
+    return GVL_OK;
+}
+
+static int launch_recon(const ReconArgs &A, int chunks, int variant, void *stream) {
+    const i64 grid = (A.n_rows + WG_WAVES - 1) / WG_WAVES;
+    if (grid <= 0) return GVL_OK;
+    recon_fn fn = recon_table(variant & 3, (variant & 4) != 0, (variant & 8) != 0);
     fn<<<dim3((unsigned)grid, (unsigned)chunks), dim3(WG_THREADS), 0, (hipStream_t)stream>>>(A);
     return check_launch("gvl_reconstruct");
+}
+
+int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *out, void *stream) {
+    ReconArgs A;
+    int chunks = 1, variant = 0;
+    const int rc = fill_recon_args(st, bt, out, A, &chunks, &variant);
+    if (rc) return rc;
+    return launch_recon(A, chunks, variant, stream);
+}
+
+// Measured and not done as ONE launch (blockIdx.z = batch, per-batch arguments indexed in the kernarg
+// segment): the indirection cost 1.2-1.8 us per batch (scalar loads of the arguments at their use
+// instead of one preload) and the batches of one launch overlapped no better than launches on
+// separate streams.  The entry point stays: one host call, all arguments validated before the
+// first launch, back-to-back launches on `stream`.
+int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_out *outs, int32_t n, void *stream) {
+    if (n < 0 || n > GVL_MANY_MAX || (n > 0 && (!bts || !outs))) return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct_many: bad arguments (n <= GVL_MANY_MAX)");
+    ReconArgs A[GVL_MANY_MAX];
+    int chunks[GVL_MANY_MAX], variant[GVL_MANY_MAX];
+    for (int i = 0; i < n; ++i) {
+        chunks[i] = 1; variant[i] = 0;
+        const int rc = fill_recon_args(st, &bts[i], &outs[i], A[i], &chunks[i], &variant[i]);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < n; ++i) {
+        const int rc = launch_recon(A[i], chunks[i], variant[i], stream);
+        if (rc) return rc;
+    }
+    return GVL_OK;
 }
 
 int gvl_get_reference(const gvl_static *st, const int32_t *regions, int64_t regions_stride,
@@ -3018,6 +3208,7 @@ int gvl_get_reference(const gvl_static *st, const int32_t *regions, int64_t regi
     memset(&A, 0, sizeof(A));
     A.ref = st->ref; A.ref_len = st->ref_len; A.ref_offsets = (const i64 *)st->ref_offsets;
     A.regions = regions; A.regions_stride = regions_stride;
+    A.n_contigs = (int)(st->n_contigs < 0 ? 0 : (st->n_contigs > 0x7FFFFFFFll ? 0x7FFFFFFF : st->n_contigs));
     A.to_rc = to_rc; A.out_offsets = (const i64 *)out_offsets; A.fixed_len = -1;
     A.n_rows = n_rows; A.ploidy = 1; A.ploidy_shift = 0;
     int chunks = 1;
@@ -3285,19 +3476,27 @@ int gvl_prepare_request(const gvl_static *st, const int64_t *idx, int64_t batch,
 }
 
 // ---- native batch loop ---------------------------------------------------------------
+// Epoch level: gvl_loader_start_epoch turns the WHOLE epoch order into request arrays with one launch
+// of the prep kernel (the "epoch table": regions / geno_offset_idx / shifts / to_rc for every query of
+// the epoch, 26 + 13 P bytes per query), so that a batch costs the host one launch, one event record
+// and at most two stream waits -- per GROUP of `group` batches (gvl_reconstruct_many).
 struct gvl_loader {
     gvl_static st;
     gvl_loader_config cfg;
     void *arenas[64];
     int64_t part[7];
     hipStream_t streams[16];
-    hipEvent_t done[64], released[64], epoch_ready;
-    bool slot_used[64];
+    hipEvent_t done[64], released[64], epoch_ready;    // per slot SET (group of `G` slots)
+    bool set_used[64];
     bool stream_synced[16];
-    const int64_t *order; i64 n_order; i64 n_batches;
-    i64 submitted, consumed; int prev_slot;
-    u64 counter;
-    struct LoaderSync *sync;      // non-NULL: a producer thread submits the batches (cfg.threaded)
+    const int64_t *order; i64 n_order; i64 n_batches, n_groups;
+    i64 submitted, consumed;      // submitted: GROUPS handed to the GPU; consumed: BATCHES handed to the caller
+    i64 released_groups;          // groups whose release has been recorded on the consumer's stream
+    int G, n_sets;
+    u64 counter;                  // epochs started (keys the random draws together with cfg.seed)
+    // epoch table (the caller's memory, like the slots): request arrays of every query of the epoch
+    int *e_regions; i64 *e_goi; int *e_shifts; u8 *e_to_rc;
+    struct LoaderSync *sync;      // non-NULL: a producer thread submits the groups (cfg.threaded)
 };
 
 // Producer thread state.  `submitted` / `consumed` / `n_batches` / `order` are only touched under
@@ -3326,13 +3525,29 @@ int64_t gvl_loader_slot_bytes(const gvl_loader_config *cfg, int64_t *part_offset
     return off;
 }
 
-static int loader_submit(gvl_loader *ld, i64 j);
+int64_t gvl_loader_table_bytes(const gvl_loader_config *cfg, int64_t n, int64_t *part_offsets) {
+    if (!cfg || cfg->ploidy <= 0 || n < 0) return -1;
+    const i64 P = cfg->ploidy;
+    const i64 sizes[4] = {16 * n, 8 * n * P, 4 * n * P, n * P};
+    i64 off = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (part_offsets) part_offsets[i] = off;
+        off += align256(sizes[i]);
+    }
+    return off > 0 ? off : 256;
+}
+
+static int loader_submit(gvl_loader *ld, i64 g);
 static void loader_producer_main(gvl_loader *ld);
 
 int gvl_loader_create(const gvl_static *st, const gvl_loader_config *cfg, gvl_loader **out) {
     if (!st || !cfg || !out) return fail(GVL_ERR_INVALID, "%s", "gvl_loader_create: NULL argument");
-    if (cfg->in_flight < 1 || cfg->in_flight > 16 || cfg->n_slots < cfg->in_flight + 1 || cfg->n_slots > 64)
-        return fail(GVL_ERR_INVALID, "%s", "gvl_loader_create: need 1 <= in_flight <= 16 and in_flight < n_slots <= 64");
+    const int G = cfg->group <= 0 ? 1 : cfg->group;
+    if (G > GVL_MANY_MAX) return fail(GVL_ERR_INVALID, "%s", "gvl_loader_create: group > GVL_MANY_MAX");
+    if (cfg->in_flight < 1 || cfg->in_flight > 16 || cfg->n_slots > 64 || cfg->n_slots % G != 0 ||
+        cfg->n_slots / G < cfg->in_flight + 1)
+        return fail(GVL_ERR_INVALID, "%s", "gvl_loader_create: need 1 <= in_flight <= 16, n_slots <= 64 a multiple of group, "
+                                           "n_slots / group >= in_flight + 1");
     if (!cfg->full_regions || !cfg->slot_arenas || cfg->n_regions <= 0 || cfg->n_samples <= 0 || cfg->batch_size <= 0 ||
         cfg->ploidy <= 0 || cfg->output_length <= 0 || (!cfg->want_haps && !cfg->want_onehot))
         return fail(GVL_ERR_INVALID, "%s", "gvl_loader_create: bad config");
@@ -3340,6 +3555,7 @@ int gvl_loader_create(const gvl_static *st, const gvl_loader_config *cfg, gvl_lo
     if (!ld) return fail(GVL_ERR_HIP, "%s", "gvl_loader_create: out of host memory");
     memset(ld, 0, sizeof(*ld));
     ld->st = *st; ld->cfg = *cfg;
+    ld->G = G; ld->n_sets = cfg->n_slots / G;
     gvl_loader_slot_bytes(cfg, ld->part);
     for (int i = 0; i < cfg->n_slots; ++i) {
         ld->arenas[i] = cfg->slot_arenas[i];
@@ -3351,12 +3567,11 @@ int gvl_loader_create(const gvl_static *st, const gvl_loader_config *cfg, gvl_lo
     ld->cfg.slot_arenas = nullptr;
     bool ok = true;
     for (int i = 0; i < cfg->in_flight && ok; ++i) ok = hipStreamCreateWithFlags(&ld->streams[i], hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i < cfg->n_slots && ok; ++i)
+    for (int i = 0; i < ld->n_sets && ok; ++i)
         ok = hipEventCreateWithFlags(&ld->done[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&ld->released[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&ld->epoch_ready, hipEventDisableTiming) == hipSuccess;
     if (!ok) { gvl_loader_destroy(ld); return fail(GVL_ERR_HIP, "%s", "gvl_loader_create: stream / event creation failed"); }
-    ld->prev_slot = -1;
     if (cfg->threaded) {
         LoaderSync *sy = new (std::nothrow) LoaderSync;
         if (!sy) { gvl_loader_destroy(ld); return fail(GVL_ERR_HIP, "%s", "gvl_loader_create: out of host memory"); }
@@ -3391,8 +3606,10 @@ int gvl_loader_destroy(gvl_loader *ld) {
     return GVL_OK;
 }
 
-int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int32_t drop_last, void *stream) {
-    if (!ld || n < 0 || (n > 0 && !order)) return fail(GVL_ERR_INVALID, "%s", "gvl_loader_start_epoch: bad arguments");
+int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int32_t drop_last, void *table, void *stream) {
+    if (!ld || n < 0 || (n > 0 && (!order || !table)) || ((uintptr_t)table & 255))
+        return fail(GVL_ERR_INVALID, "%s", "gvl_loader_start_epoch: bad arguments (table: gvl_loader_table_bytes() bytes, 256-byte aligned)");
+    if (n > (1ll << 31)) return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_loader_start_epoch: more than 2^31 queries per epoch (shard the order)");
     std::unique_lock<std::mutex> lk;
     if (ld->sync) {      // park the producer: no submit may be in progress while the epoch changes
         lk = std::unique_lock<std::mutex>(ld->sync->mu);
@@ -3400,13 +3617,39 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
         ld->sync->cv_consumer.wait(lk, [&] { return !ld->sync->busy; });
         ld->sync->err = GVL_OK;
     }
-    if (ld->submitted != ld->consumed)   // an abandoned epoch: let its batches drain before slots are reused
-        for (int i = 0; i < ld->cfg.in_flight; ++i) (void)hipStreamSynchronize(ld->streams[i]);
-    const i64 bs = ld->cfg.batch_size;
+    hipStream_t s = (hipStream_t)stream;
+    const gvl_loader_config &c = ld->cfg;
+    const bool abandoned = ld->submitted * ld->G < ld->n_batches || ld->consumed < ld->n_batches;
+    if (abandoned)   // an abandoned epoch's batches still read their table and fill their slots: let them drain
+        for (int i = 0; i < c.in_flight; ++i) (void)hipStreamSynchronize(ld->streams[i]);
+    // the previous epoch's last batches were handed to the consumer: the new table contents must not
+    // overtake whatever is still queued on them
+    for (int i = 0; i < ld->n_sets; ++i)
+        if (ld->set_used[i] && hipStreamWaitEvent(s, ld->done[i], 0) != hipSuccess)
+            return fail(GVL_ERR_HIP, "%s", "gvl_loader_start_epoch: hipStreamWaitEvent failed");
+    {
+        int64_t po[4];
+        gvl_loader_table_bytes(&c, n, po);
+        u8 *base = (u8 *)table;
+        ld->e_regions = (int *)(base + po[0]);
+        ld->e_goi = (i64 *)(base + po[1]);
+        ld->e_shifts = (int *)(base + po[2]);
+        ld->e_to_rc = base + po[3];
+    }
+    const i64 bs = c.batch_size;
     ld->order = order; ld->n_order = n;
     ld->n_batches = drop_last ? n / bs : (n + bs - 1) / bs;
-    ld->submitted = ld->consumed = 0;
-    if (hipEventRecord(ld->epoch_ready, (hipStream_t)stream) != hipSuccess)
+    ld->n_groups = (ld->n_batches + ld->G - 1) / ld->G;
+    ld->submitted = ld->consumed = ld->released_groups = 0;
+    ++ld->counter;
+    const i64 n_used = drop_last ? ld->n_batches * bs : n;
+    if (n_used > 0) {
+        const int rc = gvl_prepare_request(&ld->st, order, n_used, c.full_regions, c.n_regions, c.n_samples, c.ploidy, c.jitter,
+                                           c.rc_neg, c.deterministic, c.output_length, c.seed, ld->counter, ld->e_regions,
+                                           (int64_t *)ld->e_goi, ld->e_to_rc, ld->e_shifts, s);
+        if (rc) return rc;
+    }
+    if (hipEventRecord(ld->epoch_ready, s) != hipSuccess)
         return fail(GVL_ERR_HIP, "%s", "gvl_loader_start_epoch: hipEventRecord failed");
     for (int i = 0; i < 16; ++i) ld->stream_synced[i] = false;
     if (ld->sync) {
@@ -3417,55 +3660,62 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
     return GVL_OK;
 }
 
-static int loader_parts(gvl_loader *ld, int slot, i64 j, gvl_loader_batch *o) {
-    const i64 bs = ld->cfg.batch_size;
+static int loader_parts(gvl_loader *ld, i64 j, gvl_loader_batch *o) {
+    const i64 bs = ld->cfg.batch_size, P = ld->cfg.ploidy;
+    const int slot = (int)(j % ld->cfg.n_slots);
     u8 *base = (u8 *)ld->arenas[slot];
     o->slot = slot;
     o->batch = (j + 1) * bs <= ld->n_order ? bs : ld->n_order - j * bs;
     o->idx = ld->order + j * bs;
     o->onehot = ld->cfg.want_onehot ? base + ld->part[0] : nullptr;
     o->haps = ld->cfg.want_haps ? base + ld->part[1] : nullptr;
-    o->regions = (int *)(base + ld->part[2]);
-    o->geno_offset_idx = (int64_t *)(base + ld->part[3]);
-    o->shifts = (int *)(base + ld->part[4]);
-    o->to_rc = base + ld->part[5];
+    // the request arrays of the batch are rows of the epoch table
+    o->regions = ld->e_regions + 4 * j * bs;
+    o->geno_offset_idx = (int64_t *)(ld->e_goi + j * bs * P);
+    o->shifts = ld->e_shifts + j * bs * P;
+    o->to_rc = ld->e_to_rc + j * bs * P;
     o->out_offsets = (int64_t *)(base + ld->part[6]);
     return 0;
 }
 
-static int loader_submit(gvl_loader *ld, i64 j) {
-    const int slot = (int)(j % ld->cfg.n_slots);
-    const int si = (int)(j % ld->cfg.in_flight);
+// submit GROUP g: batches [g G, min((g + 1) G, n_batches)) in one launch
+static int loader_submit(gvl_loader *ld, i64 g) {
+    const int set = (int)(g % ld->n_sets);
+    const int si = (int)(g % ld->cfg.in_flight);
     hipStream_t s = ld->streams[si];
     if (!ld->stream_synced[si]) {
         if (traced("wait epoch_ready", [&] { return hipStreamWaitEvent(s, ld->epoch_ready, 0); }) != hipSuccess) return fail(GVL_ERR_HIP, "%s", "gvl_loader: hipStreamWaitEvent failed");
         ld->stream_synced[si] = true;
     }
-    if (ld->slot_used[slot] && traced("wait released", [&] { return hipStreamWaitEvent(s, ld->released[slot], 0); }) != hipSuccess)
+    if (ld->set_used[set] && traced("wait released", [&] { return hipStreamWaitEvent(s, ld->released[set], 0); }) != hipSuccess)
         return fail(GVL_ERR_HIP, "%s", "gvl_loader: hipStreamWaitEvent failed");
-    gvl_loader_batch o;
-    loader_parts(ld, slot, j, &o);
     const gvl_loader_config &c = ld->cfg;
+    gvl_batch bts[GVL_MANY_MAX];
+    gvl_out ocs[GVL_MANY_MAX];
+    int m = 0;
+    for (i64 j = g * ld->G; j < (g + 1) * ld->G && j < ld->n_batches; ++j, ++m) {
+        gvl_loader_batch o;
+        loader_parts(ld, j, &o);
+        gvl_batch &bt = bts[m];
+        memset(&bt, 0, sizeof(bt));
+        bt.regions = o.regions; bt.regions_stride = 4; bt.shifts = o.shifts; bt.geno_offset_idx = o.geno_offset_idx;
+        bt.batch = o.batch; bt.ploidy = c.ploidy; bt.to_rc = c.rc_neg ? o.to_rc : nullptr;
+        bt.output_length = c.output_length; bt.max_row_len = c.output_length;
+        gvl_out &oc = ocs[m];
+        memset(&oc, 0, sizeof(oc));
+        oc.haps = o.haps; oc.onehot = o.onehot; oc.onehot_layout = c.onehot_layout; oc.out_offsets = o.out_offsets;
+    }
     int rc = GVL_OK;
-    (void)traced("launch prepare_request", [&] {
-        rc = gvl_prepare_request(&ld->st, o.idx, o.batch, c.full_regions, c.n_regions, c.n_samples, c.ploidy, c.jitter,
-                                 c.rc_neg, c.deterministic, c.output_length, c.seed, ++ld->counter, o.regions,
-                                 o.geno_offset_idx, o.to_rc, o.shifts, s);
-        return hipSuccess; });
+    (void)traced("launch reconstruct", [&] { rc = gvl_reconstruct_many(&ld->st, bts, ocs, m, s); return hipSuccess; });
     if (rc) return rc;
-    gvl_batch bt;
-    memset(&bt, 0, sizeof(bt));
-    bt.regions = o.regions; bt.regions_stride = 4; bt.shifts = o.shifts; bt.geno_offset_idx = o.geno_offset_idx;
-    bt.batch = o.batch; bt.ploidy = c.ploidy; bt.to_rc = c.rc_neg ? o.to_rc : nullptr;
-    bt.output_length = c.output_length; bt.max_row_len = c.output_length;
-    gvl_out oc;
-    memset(&oc, 0, sizeof(oc));
-    oc.haps = o.haps; oc.onehot = o.onehot; oc.onehot_layout = c.onehot_layout; oc.out_offsets = o.out_offsets;
-    (void)traced("launch reconstruct", [&] { rc = gvl_reconstruct(&ld->st, &bt, &oc, s); return hipSuccess; });
-    if (rc) return rc;
-    if (traced("record done", [&] { return hipEventRecord(ld->done[slot], s); }) != hipSuccess) return fail(GVL_ERR_HIP, "%s", "gvl_loader: hipEventRecord failed");
-    ld->slot_used[slot] = true;
+    if (traced("record done", [&] { return hipEventRecord(ld->done[set], s); }) != hipSuccess) return fail(GVL_ERR_HIP, "%s", "gvl_loader: hipEventRecord failed");
+    ld->set_used[set] = true;
     return GVL_OK;
+}
+
+// may group `g` be handed to the GPU?  at most in_flight groups beyond the ones fully handed out
+static bool loader_may_submit(const gvl_loader *ld) {
+    return ld->submitted < ld->n_groups && ld->submitted < ld->consumed / ld->G + ld->cfg.in_flight;
 }
 
 static void loader_producer_main(gvl_loader *ld) {
@@ -3473,77 +3723,74 @@ static void loader_producer_main(gvl_loader *ld) {
     (void)hipSetDevice(sy->device);
     std::unique_lock<std::mutex> lk(sy->mu);
     for (;;) {
-        sy->cv_producer.wait(lk, [&] {
-            return sy->stop || (sy->active && sy->err == GVL_OK && ld->submitted < ld->n_batches &&
-                                ld->submitted - ld->consumed < ld->cfg.in_flight);
-        });
+        sy->cv_producer.wait(lk, [&] { return sy->stop || (sy->active && sy->err == GVL_OK && loader_may_submit(ld)); });
         if (sy->stop) break;
-        const i64 j = ld->submitted;
+        const i64 g = ld->submitted;
         sy->busy = true;
         lk.unlock();
-        const int rc = loader_submit(ld, j);           // HIP calls outside the lock
+        const int rc = loader_submit(ld, g);           // HIP calls outside the lock
         lk.lock();
         sy->busy = false;
         if (rc) {
             sy->err = rc;
             snprintf(sy->msg, sizeof(sy->msg), "%s", g_err);    // g_err is this thread's
         } else {
-            ld->submitted = j + 1;
+            ld->submitted = g + 1;
         }
         sy->cv_consumer.notify_all();
     }
 }
 
-static int loader_next_threaded(gvl_loader *ld, hipStream_t cs, gvl_loader_batch *out) {
-    LoaderSync *sy = ld->sync;
-    if (ld->prev_slot >= 0) {
-        if (hipEventRecord(ld->released[ld->prev_slot], cs) != hipSuccess) return fail(GVL_ERR_HIP, "%s", "gvl_loader_next: hipEventRecord failed");
-        ld->prev_slot = -1;
+// the consumer moves past batch `consumed - 1`: if that was the last batch of its group, the group's
+// slots may be refilled once the consumer's queued work has run
+static int loader_release_prev(gvl_loader *ld, hipStream_t cs) {
+    const i64 c = ld->consumed;
+    if (c > 0 && (c % ld->G == 0 || c == ld->n_batches) && ld->released_groups * ld->G < c) {
+        const i64 g = (c - 1) / ld->G;
+        if (traced("record released", [&] { return hipEventRecord(ld->released[g % ld->n_sets], cs); }) != hipSuccess)
+            return fail(GVL_ERR_HIP, "%s", "gvl_loader_next: hipEventRecord failed");
+        ld->released_groups = g + 1;
     }
-    memset(out, 0, sizeof(*out));
-    i64 j;
-    {
-        std::unique_lock<std::mutex> lk(sy->mu);
-        if (ld->consumed >= ld->n_batches) { out->slot = -1; return GVL_OK; }
-        sy->cv_consumer.wait(lk, [&] { return sy->err != GVL_OK || ld->submitted > ld->consumed; });
-        if (sy->err != GVL_OK && ld->submitted <= ld->consumed) {
-            snprintf(g_err, sizeof(g_err), "%s", sy->msg);
-            return sy->err;
-        }
-        j = ld->consumed;
-    }
-    const int slot = (int)(j % ld->cfg.n_slots);
-    if (hipStreamWaitEvent(cs, ld->done[slot], 0) != hipSuccess) return fail(GVL_ERR_HIP, "%s", "gvl_loader_next: hipStreamWaitEvent failed");
-    loader_parts(ld, slot, j, out);
-    ld->prev_slot = slot;
-    {
-        std::lock_guard<std::mutex> lk(sy->mu);
-        ld->consumed = j + 1;           // the window moves: the producer may submit one more
-    }
-    sy->cv_producer.notify_one();
     return GVL_OK;
 }
 
 int gvl_loader_next(gvl_loader *ld, void *consumer_stream, gvl_loader_batch *out) {
     if (!ld || !out) return fail(GVL_ERR_INVALID, "%s", "gvl_loader_next: NULL argument");
     hipStream_t cs = (hipStream_t)consumer_stream;
-    if (ld->sync) return loader_next_threaded(ld, cs, out);
-    if (ld->prev_slot >= 0) {   // the consumer is done with the previous batch once its queued work has run
-        if (traced("record released", [&] { return hipEventRecord(ld->released[ld->prev_slot], cs); }) != hipSuccess) return fail(GVL_ERR_HIP, "%s", "gvl_loader_next: hipEventRecord failed");
-        ld->prev_slot = -1;
-    }
-    while (ld->submitted < ld->n_batches && ld->submitted - ld->consumed < ld->cfg.in_flight) {
-        const int rc = loader_submit(ld, ld->submitted);
-        if (rc) return rc;
-        ++ld->submitted;
-    }
+    LoaderSync *sy = ld->sync;
+    int rc = loader_release_prev(ld, cs);      // (`consumed` only changes on this thread)
+    if (rc) return rc;
     memset(out, 0, sizeof(*out));
     if (ld->consumed >= ld->n_batches) { out->slot = -1; return GVL_OK; }
-    const int slot = (int)(ld->consumed % ld->cfg.n_slots);
-    if (traced("wait done", [&] { return hipStreamWaitEvent(cs, ld->done[slot], 0); }) != hipSuccess) return fail(GVL_ERR_HIP, "%s", "gvl_loader_next: hipStreamWaitEvent failed");
-    loader_parts(ld, slot, ld->consumed, out);
-    ld->prev_slot = slot;
-    ++ld->consumed;
+    const i64 j = ld->consumed, g = j / ld->G;
+    if (sy) {
+        std::unique_lock<std::mutex> lk(sy->mu);
+        sy->cv_producer.notify_one();          // a release may have opened the window
+        sy->cv_consumer.wait(lk, [&] { return sy->err != GVL_OK || ld->submitted > g; });
+        if (sy->err != GVL_OK && ld->submitted <= g) {
+            snprintf(g_err, sizeof(g_err), "%s", sy->msg);
+            return sy->err;
+        }
+    } else {
+        while (loader_may_submit(ld)) {
+            rc = loader_submit(ld, ld->submitted);
+            if (rc) return rc;
+            ++ld->submitted;
+        }
+    }
+    if (j % ld->G == 0 &&
+        traced("wait done", [&] { return hipStreamWaitEvent(cs, ld->done[g % ld->n_sets], 0); }) != hipSuccess)
+        return fail(GVL_ERR_HIP, "%s", "gvl_loader_next: hipStreamWaitEvent failed");
+    loader_parts(ld, j, out);
+    if (sy) {
+        {
+            std::lock_guard<std::mutex> lk(sy->mu);
+            ld->consumed = j + 1;              // the window moves: the producer may submit one more group
+        }
+        sy->cv_producer.notify_one();
+    } else {
+        ld->consumed = j + 1;
+    }
     return GVL_OK;
 }
 

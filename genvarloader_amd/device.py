@@ -97,7 +97,8 @@ class ReconOutput:
 
 class HapsDevice:
     def __init__(self, *, ref, ref_offsets, v_starts, ilens, alt_alleles, alt_offsets,
-                 geno_offsets, geno_v_idxs, pad_char=ord("N"), device="cuda", inline_genotypes=None):
+                 geno_offsets, geno_v_idxs, pad_char=ord("N"), device="cuda", inline_genotypes=None,
+                 slot_records=None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.GvlError("genvarloader_amd needs a HIP device (no CPU fallback)")
@@ -131,7 +132,7 @@ class HapsDevice:
             n_variants=n_var, alt_len=self.alt_alleles.numel(), vrec=self.vrec.data_ptr(),
             geno_o_starts=self.geno_offsets[0].data_ptr(), geno_o_stops=self.geno_offsets[1].data_ptr(),
             n_geno_offsets=n_go, geno_v_idxs=self.geno_v_idxs.data_ptr(),
-            n_geno=self.geno_v_idxs.numel(), pad_char=self.pad_char, geno_rec=None,
+            n_geno=self.geno_v_idxs.numel(), pad_char=self.pad_char, geno_rec=None, slot_rec=None,
         )
         # Derived layout: the variant's fields next to each genotype CSR entry (gvl_grec, 16 B per
         # entry) removes one of the dependent gathers in the kernel head.  Default: build it
@@ -145,6 +146,18 @@ class HapsDevice:
                 self.geno_rec = torch.empty((n_geno, 4), dtype=torch.int32, device=d)
                 _lib.check(self.lib.gvl_pack_genotypes(C.byref(self.c), _ptr(self.geno_rec), _stream_ptr()))
             self.c.geno_rec = self.geno_rec.data_ptr()
+        # Slot-major records (gvl_srec, 128 B per genotype slot): a row reaches its variants with one
+        # read after geno_offset_idx instead of geno_o_starts/stops -> records -> alt_offsets.  Same
+        # default: build when it costs less than a quarter of the free HBM (and ALT bytes fit u32).
+        self.slot_rec = None
+        if slot_records is None:
+            slot_records = (n_go > 0 and n_var > 0 and int(self.alt_alleles.numel()) < (1 << 32)
+                            and 128 * n_go <= torch.cuda.mem_get_info(d)[0] // 4)
+        if slot_records and n_go > 0 and n_var > 0:
+            with torch.cuda.device(d):
+                self.slot_rec = torch.empty((n_go * 8, 4), dtype=torch.int32, device=d)
+                _lib.check(self.lib.gvl_pack_slots(C.byref(self.c), _ptr(self.slot_rec), _stream_ptr()))
+            self.c.slot_rec = self.slot_rec.data_ptr()
 
     # ------------------------------------------------------------------ batches
     def prepare_batch(self, regions, shifts, geno_offset_idx, output_length, keep=None,
@@ -261,6 +274,18 @@ class HapsDevice:
     def launch(self, bt: DeviceBatch, out_c: GvlOut, stream=None) -> None:
         """One pass of the hot path over one batch: a single kernel launch."""
         _lib.check(self.lib.gvl_reconstruct(C.byref(self.c), C.byref(bt.c), C.byref(out_c), _stream_ptr(stream)))
+
+    def pack_many(self, bts, out_cs):
+        """C arrays for :meth:`launch_many` (build once, launch many times)."""
+        n = len(bts)
+        if n != len(out_cs) or n == 0:
+            raise ValueError("need as many outputs as batches")
+        return (GvlBatch * n)(*[b.c for b in bts]), (GvlOut * n)(*out_cs), n
+
+    def launch_many(self, packed, stream=None) -> None:
+        """``gvl_reconstruct_many``: several batches, one launch (up to ``GVL_MANY_MAX`` per launch)."""
+        b, o, n = packed
+        _lib.check(self.lib.gvl_reconstruct_many(C.byref(self.c), b, o, C.c_int32(n), _stream_ptr(stream)))
 
     def reconstruct(self, regions, shifts, geno_offset_idx, output_length, keep=None, keep_offsets=None,
                     to_rc=None, *, out_offsets=None, haps=True, onehot=False, layout="lc",

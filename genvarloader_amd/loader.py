@@ -88,7 +88,15 @@ class DeviceHapsDataset:
         self.jitter, self.rc_neg, self.deterministic = int(jitter), bool(rc_neg), bool(deterministic)
         self.onehot, self.haps, self.layout = bool(onehot), bool(haps), layout
         self.seed = (0 if seed is None else int(seed)) & 0xFFFFFFFFFFFFFFFF
-        self._counter = 0
+        self._counter = 0          # random draws are keyed by (seed, counter, dataset index): one tick per request
+        self._loaders = 0          # ... and every loader gets its own derived seed, so a new loader does not replay
+
+    def _loader_seed(self) -> int:
+        """A seed per loader (splitmix64 of seed and the loaders created so far)."""
+        from .sharding import splitmix64
+
+        self._loaders += 1
+        return splitmix64((self.seed + self._loaders) & 0xFFFFFFFFFFFFFFFF)
 
     @property
     def shape(self):
@@ -182,15 +190,16 @@ class DeviceHapsDataset:
         return batch
 
     def to_dataloader(self, batch_size: int = 1, shuffle: bool = False, sampler=None, drop_last: bool = False,
-                      generator: torch.Generator | None = None, in_flight: int = 3, rank: int = 0,
-                      world_size: int = 1, seed: int = 0, threaded: bool = False) -> "DeviceLoader":
+                      generator: torch.Generator | None = None, in_flight: int = 2, rank: int = 0,
+                      world_size: int = 1, seed: int = 0, threaded: bool = False, group: int = 4) -> "DeviceLoader":
         """``Dataset.to_dataloader`` (``_impl.py:1963-2072``) for device consumers.  With
         ``world_size > 1`` the epoch is sharded across ranks like ``DistributedSampler``
         (:func:`genvarloader_amd.sharding.epoch_order`): same permutation on every rank, disjoint
-        strided shares, no collective.  ``threaded=True``: a producer thread inside the library
-        submits the batches (launches overlap the consumer's own host work per batch)."""
+        strided shares, no collective.  ``group`` batches share one launch and ``in_flight`` such
+        groups are submitted ahead.  ``threaded=True``: a producer thread inside the library
+        submits them (launches overlap the consumer's own host work per batch)."""
         return DeviceLoader(self, batch_size, shuffle, sampler, drop_last, generator, in_flight, rank, world_size,
-                            seed, threaded)
+                            seed, threaded, group)
 
 
 @dataclass
@@ -211,12 +220,16 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
     Batches own their memory (random access / custom samplers / ``DeviceLoader``'s Python loop)."""
 
     def __init__(self, dev, regions, n_samples, ploidy, *, tracks: dict, strategy_id: int = 0, param: float = 0.0,
-                 base_seed: int = 0, **kw):
+                 base_seed: int | None = None, **kw):
         super().__init__(dev, regions, n_samples, ploidy, **kw)
         from . import device as _device
 
         d = dev.device
-        self.strategy_id, self.param, self.base_seed = int(strategy_id), float(param), int(base_seed)
+        # base_seed of the seed-dependent fills (FlankSample): None = per batch like the reference
+        # (_reconstruct.py:215-222: xor-reduce of the batch's dataset indices when deterministic, a
+        # fresh draw otherwise); an int pins it.
+        self.strategy_id, self.param = int(strategy_id), float(param)
+        self.base_seed = None if base_seed is None else int(base_seed) & 0xFFFFFFFFFFFFFFFF
         self.track_names = list(tracks)
         self._itv = []
         n_lists = self.n_regions * self.n_samples
@@ -242,6 +255,17 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
         from . import device as _device
         from .device import _ptr, _stream_ptr
 
+        if self.base_seed is not None:
+            seed = self.base_seed
+        elif self.deterministic:
+            if isinstance(idx, torch.Tensor) and idx.is_cuda:      # (one host read; host indices avoid it)
+                seed = int(np.bitwise_xor.reduce(idx.detach().cpu().numpy().astype(np.uint64).reshape(-1)))
+            else:
+                seed = int(np.bitwise_xor.reduce(np.asarray(idx).astype(np.uint64).reshape(-1))) if np.size(idx) else 0
+        else:
+            from .sharding import splitmix64
+
+            seed = splitmix64(self.seed ^ splitmix64(self._counter + 1))
         base = super().__getitem__(idx)
         dev, d = self.dev, self.dev.device
         b, P, L = int(base.idx.numel()), self.ploidy, self.output_length
@@ -271,22 +295,24 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
                     _stream_ptr()))
                 _lib.check(dev.lib.gvl_realign_tracks(
                     C.byref(dev.c), C.byref(bt.c), _ptr(scratch), _ptr(track_offsets), par, C.c_int64(self.strategy_id),
-                    C.c_uint64(self.base_seed & 0xFFFFFFFFFFFFFFFF), _ptr(tracks[t]), _stream_ptr()))
+                    C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), _ptr(tracks[t]), _stream_ptr()))
         out = TrackBatch(base.onehot, base.haps, base.idx, base.regions, base.shifts, base.geno_offset_idx, base.to_rc,
                          tracks.view(len(self._itv), b, P, L).permute(1, 0, 2, 3))
         out._arena = base._arena
+        out.base_seed = seed
         out._keep = (bt, scratch, out_offsets, track_offsets, qs)
         return out
 
     def to_dataloader(self, batch_size: int = 1, shuffle: bool = False, sampler=None, drop_last: bool = False,
-                      generator=None, in_flight: int = 2, **kw) -> "DeviceLoader":
-        """Tracks go through the Python submit loop (each batch owns its memory)."""
-        if sampler is None:
-            n = len(self)
-            order = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
-            sampler = [order[s:s + batch_size] for s in range(0, n, batch_size)
-                       if not (drop_last and s + batch_size > n)]
-        return DeviceLoader(self, batch_size, False, sampler, drop_last, None, in_flight)
+                      generator=None, in_flight: int = 2, rank: int = 0, world_size: int = 1, seed: int = 0,
+                      **unsupported) -> "DeviceLoader":
+        """Tracks go through the Python submit loop (each batch owns its memory); the epoch order is
+        drawn per epoch like the native loop's (``epoch_order``: reshuffled every epoch, sharded
+        across ranks)."""
+        if unsupported:
+            raise TypeError(f"DeviceHapsTracksDataset.to_dataloader: unsupported arguments {sorted(unsupported)}")
+        return DeviceLoader(self, batch_size, shuffle, sampler, drop_last, generator, in_flight, rank, world_size,
+                            seed, False, 1, python_loop=True)
 
 
 class DeviceLoader:
@@ -303,8 +329,11 @@ class DeviceLoader:
     its memory."""
 
     def __init__(self, ds: DeviceHapsDataset, batch_size=1, shuffle=False, sampler=None, drop_last=False,
-                 generator=None, in_flight=3, rank=0, world_size=1, seed=0, threaded=False):
+                 generator=None, in_flight=2, rank=0, world_size=1, seed=0, threaded=False, group=4,
+                 python_loop=False):
         self.threaded = bool(threaded)
+        self.group = max(1, min(8, int(group)))
+        self.python_loop = bool(python_loop)
         self.ds, self.batch_size, self.shuffle, self.drop_last = ds, int(batch_size), shuffle, drop_last
         self.sampler, self.generator = sampler, generator
         self.rank, self.world_size, self.seed, self.epoch = int(rank), int(world_size), int(seed), 0
@@ -325,13 +354,13 @@ class DeviceLoader:
 
         ds, d = self.ds, self.ds.dev.device
         lib = ds.dev.lib
-        n_slots = self.in_flight + 2
+        n_slots = (self.in_flight + 1) * self.group
         cfg = GvlLoaderConfig(
             full_regions=ds.full_regions.data_ptr(), n_regions=ds.n_regions, n_samples=ds.n_samples, ploidy=ds.ploidy,
             batch_size=self.batch_size, output_length=ds.output_length, jitter=ds.jitter, rc_neg=int(ds.rc_neg),
-            deterministic=int(ds.deterministic), seed=ds.seed, want_haps=int(ds.haps), want_onehot=int(ds.onehot),
+            deterministic=int(ds.deterministic), seed=ds._loader_seed(), want_haps=int(ds.haps), want_onehot=int(ds.onehot),
             onehot_layout=_lib.GVL_ONEHOT_LC if ds.layout == "lc" else _lib.GVL_ONEHOT_CL, in_flight=self.in_flight,
-            n_slots=n_slots, slot_arenas=None, threaded=int(self.threaded))
+            n_slots=n_slots, slot_arenas=None, threaded=int(self.threaded), group=self.group)
         parts = (C.c_int64 * 7)()
         nbytes = int(lib.gvl_loader_slot_bytes(C.byref(cfg), parts))
         if nbytes <= 0:
@@ -361,10 +390,33 @@ class DeviceLoader:
 
         oh = view(0, torch.uint8, (b, P, L, 4) if ds.layout == "lc" else (b, P, 4, L)) if ds.onehot else None
         hp = view(1, torch.uint8, (b, P, L)) if ds.haps else None
-        v = Batch(oh, hp, None, view(2, torch.int32, (b, 4)), view(4, torch.int32, (b, P)),
-                  view(3, torch.int64, (b, P)), view(5, torch.uint8, (K,)) if ds.rc_neg else None)
+        v = (oh, hp)        # the request arrays of a batch are rows of the epoch table (see _epoch_table)
         nat["views"][key] = v
         return v
+
+    def _epoch_table(self, n: int):
+        """The epoch's request arrays (filled by gvl_loader_start_epoch): one grow-only device buffer,
+        typed views of its four parts, split into per-batch views once per epoch."""
+        import ctypes as C
+
+        nat, ds, d = self._native, self.ds, self.ds.dev.device
+        lib = ds.dev.lib
+        po = (C.c_int64 * 4)()
+        nbytes = int(lib.gvl_loader_table_bytes(C.byref(nat["cfg"]), C.c_int64(n), po))
+        tab = nat.get("table")
+        if tab is None or tab.numel() < nbytes:
+            tab = nat["table"] = torch.empty(nbytes + nbytes // 4, dtype=torch.uint8, device=d)
+        P, bs = ds.ploidy, self.batch_size
+
+        def part(i, dtype, shape):
+            nb = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+            return tab[int(po[i]):int(po[i]) + nb].view(dtype).view(shape)
+
+        reg, goi = part(0, torch.int32, (n, 4)), part(1, torch.int64, (n, P))
+        sh, rc = part(2, torch.int32, (n, P)), part(3, torch.uint8, (n * P,))
+        if n == 0:
+            return tab, (), (), (), ()
+        return tab, reg.split(bs), goi.split(bs), sh.split(bs), (rc.split(bs * P) if ds.rc_neg else None)
 
     def _iter_native(self):
         import ctypes as C
@@ -392,8 +444,10 @@ class DeviceLoader:
                                     device=d, generator=g)
             self.epoch += 1
             n = int(order.numel())
+            tab, reg_v, goi_v, sh_v, rc_v = self._epoch_table(n)
             _lib.check(lib.gvl_loader_start_epoch(handle, C.c_void_p(order.data_ptr()), C.c_int64(n),
-                                                  C.c_int32(int(self.drop_last)), C.c_void_p(cur.cuda_stream)))
+                                                  C.c_int32(int(self.drop_last)), C.c_void_p(tab.data_ptr()),
+                                                  C.c_void_p(cur.cuda_stream)))
             nat["order"] = order                       # keep the epoch order alive
             nxt, ref_out, bs = lib.gvl_loader_next, C.byref(out), self.batch_size
             idx_views = order.split(bs) if n else ()          # one C++ loop instead of a slice per batch
@@ -405,8 +459,8 @@ class DeviceLoader:
                     _lib.check(rc)
                 if out.slot < 0:
                     return
-                batch = views(out.slot, out.batch)
-                batch.idx = idx_views[i]
+                oh, hp = views(out.slot, out.batch)
+                batch = Batch(oh, hp, idx_views[i], reg_v[i], sh_v[i], goi_v[i], None if rc_v is None else rc_v[i])
                 i += 1
                 yield batch
 
@@ -421,10 +475,27 @@ class DeviceLoader:
 
     # ---- Python loop (custom samplers) ---------------------------------------------------
     def _index_batches(self):
-        for b in self.sampler:                      # a BatchSampler-like iterable of index lists
-            yield np.asarray(b, dtype=np.int64).reshape(-1)
+        if self.sampler is not None:
+            for b in self.sampler:                  # a BatchSampler-like iterable of index lists
+                yield np.asarray(b, dtype=np.int64).reshape(-1)
+            return
+        # no sampler: this rank's share of a fresh permutation, every epoch (seed + epoch)
+        order = epoch_order(len(self.ds), shuffle=self.shuffle, seed=self.seed, epoch=self.epoch, rank=self.rank,
+                            world=self.world_size, drop_last=self.drop_last and self.world_size > 1,
+                            device="cpu", generator=self.generator).numpy()       # host indices: no sync per batch
+        self.epoch += 1
+        bs, n = self.batch_size, int(order.numel())
+        for s in range(0, n, bs):
+            if self.drop_last and s + bs > n:
+                break
+            yield order[s:s + bs]
 
     def __len__(self):
+        if self.sampler is not None:
+            try:
+                return len(self.sampler)
+            except TypeError:
+                pass
         n = len(self.ds)
         if self.world_size > 1:                     # DistributedSampler: equal shares
             n = n // self.world_size if self.drop_last else -(-n // self.world_size)
@@ -435,7 +506,7 @@ class DeviceLoader:
         self.epoch = int(epoch)
 
     def __iter__(self):
-        if self.sampler is None:
+        if self.sampler is None and not self.python_loop:
             yield from self._iter_native()
             return
         if self.streams is None:
@@ -450,6 +521,8 @@ class DeviceLoader:
                 idx = next(it)
             except StopIteration:
                 return False
+            if isinstance(idx, np.ndarray):
+                idx = torch.from_numpy(idx)
             st = self.streams[k % self.in_flight]
             k += 1
             st.wait_stream(torch.cuda.current_stream(self.ds.dev.device))

@@ -18,6 +18,14 @@ from __future__ import annotations
 import numpy as np
 
 
+def splitmix64(x: int) -> int:
+    """One step of splitmix64 (seed derivation: per loader, per non-deterministic batch)."""
+    z = (int(x) + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
 def shard_bounds(n_queries: int, world: int, rank: int) -> tuple[int, int]:
     """Contiguous block of queries for `rank`: sizes differ by at most one."""
     if not (0 <= rank < world):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GVL_ABI_VERSION 2
+#define GVL_ABI_VERSION 3
 
 enum {
     GVL_OK = 0,
@@ -67,6 +67,24 @@ typedef struct gvl_grec {
     int32_t v_idx;     /* geno_v_idxs[i], clamped to [0, n_variants)               */
 } gvl_grec;
 
+/* Slot-major records ("one cache line per haplotype"): GVL_SLOT_RECS 16-byte records per genotype
+ * slot, slot o at slot_rec[o * GVL_SLOT_RECS ..], built once per dataset by gvl_pack_slots().  A row
+ * then reaches its variants with ONE dependent read after geno_offset_idx (the CSR needs
+ * geno_offset_idx -> geno_o_starts/stops -> records -> alt_offsets: three more levels, each an HBM +
+ * TLB miss at genome scale), and insertions find their ALT bytes without going through alt_offsets.
+ * Unused entries have alen_inl == GVL_SREC_EMPTY; a slot with more than GVL_SLOT_RECS variants has
+ * GVL_SREC_OVERFLOW in entry 0 and is read through the CSR instead.  Optional: 128 B x n_geno_offsets
+ * of HBM (sized for 288 GB parts); not used by the annotated entry (it needs v_idx). */
+#define GVL_SLOT_RECS 8
+#define GVL_SREC_EMPTY 0xFFFFFFFFu
+#define GVL_SREC_OVERFLOW 0xFFFFFFFEu
+typedef struct gvl_srec {
+    int32_t pos;       /* v_starts[v]                                              */
+    int32_t ilen;      /* ilens[v]                                                 */
+    uint32_t alen_inl; /* (min(alen, 2^24 - 1) << 8) | first ALT byte              */
+    uint32_t a0;       /* alt_offsets[v] (the table is only built when alt_len < 2^32) */
+} gvl_srec;
+
 /* Per-dataset, device-resident arrays.  Mirrors `_HapsFfiStatic`
  * (_haps.py:233-247) + `Reference` (_reference.py:31-50) + the sparse genotype
  * CSR (`genotypes/offsets.npy`, `variant_idxs.npy`). */
@@ -89,6 +107,7 @@ typedef struct gvl_static {
     int64_t n_geno;
     uint8_t pad_char;
     const gvl_grec *geno_rec;    /* nullable: n_geno, from gvl_pack_genotypes() */
+    const gvl_srec *slot_rec;    /* nullable: GVL_SLOT_RECS * n_geno_offsets, from gvl_pack_slots() */
 } gvl_static;
 
 /* Per-batch arrays.  Mirrors `ReconstructionRequest` (_haps.py:58-93) as
@@ -143,6 +162,11 @@ int gvl_pack_variants(const int32_t *v_starts, const int32_t *ilens,
  * Needs st->vrec, st->geno_v_idxs, st->n_geno, st->n_variants. */
 int gvl_pack_genotypes(const gvl_static *st, gvl_grec *grec_out, void *stream);
 
+/* Build the slot-major records (once per dataset; optional, see gvl_srec).
+ * Needs st->vrec, alt_offsets, geno_o_starts/stops, geno_v_idxs, n_geno_offsets, n_variants;
+ * GVL_ERR_UNSUPPORTED when alt_len >= 2^32. */
+int gvl_pack_slots(const gvl_static *st, gvl_srec *srec_out, void *stream);
+
 /* Haplotype reconstruction (+RC, +one-hot, +annotations) for a batch.
  * Replaces: reconstruct_haplotypes_fused (src/ffi/mod.rs:722-860) steps 3-4b,
  *   reconstruct_haplotypes_from_sparse (src/ffi/mod.rs:632-700; in place when
@@ -153,6 +177,16 @@ int gvl_pack_genotypes(const gvl_static *st, gvl_grec *grec_out, void *stream);
  *   seqpro one-hot (docs/source/index.md:109-119). */
 int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *out,
                     void *stream);
+
+/* The same for `n` batches (arrays of n structs) in as few launches as possible: batches that need
+ * the same kernel instance (same set of outputs) share a launch, GVL_MANY_MAX at most.  Batches are
+ * independent, so inside one launch the latency-bound head of a batch (parameter and record
+ * gathers, plan) runs under the store-bound tail of the previous one -- what a prefetching loader
+ * otherwise gets from keeping several batches in flight on separate streams.  Equivalent to n
+ * calls of gvl_reconstruct on `stream`; outputs of different batches must not overlap. */
+#define GVL_MANY_MAX 8
+int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_out *outs,
+                         int32_t n, void *stream);
 
 /* Per-row length deltas.  Replaces get_diffs_sparse (src/ffi/mod.rs:143-185 ->
  * src/genotypes/mod.rs:15-125).  Query mode iff q_starts, q_ends and st->v_starts
@@ -301,6 +335,9 @@ typedef struct gvl_loader_config {
     void *const *slot_arenas;    /* HOST array of n_slots device pointers */
     int32_t threaded;            /* != 0: a producer thread of the library submits the batches, so that the
                                     launches overlap the caller's own per-batch host work */
+    int32_t group;               /* batches per launch (gvl_reconstruct_many): 0 / 1 .. GVL_MANY_MAX;
+                                    in_flight then counts GROUPS, n_slots must be a multiple of group
+                                    and >= (in_flight + 1) * group */
 } gvl_loader_config;
 
 typedef struct gvl_loader_batch {
@@ -309,11 +346,11 @@ typedef struct gvl_loader_batch {
     const int64_t *idx;          /* device: this batch's dataset indices (into the epoch order) */
     uint8_t *onehot;             /* device pointers into the slot (NULL when not requested) */
     uint8_t *haps;
-    int32_t *regions;            /* (batch, 4) */
-    int64_t *geno_offset_idx;    /* (batch, ploidy) */
-    int32_t *shifts;             /* (batch, ploidy) */
-    uint8_t *to_rc;              /* (batch * ploidy) */
-    int64_t *out_offsets;        /* (batch * ploidy + 1) */
+    int32_t *regions;            /* (batch, 4)              \                                      */
+    int64_t *geno_offset_idx;    /* (batch, ploidy)          | rows of the loader's epoch table:      */
+    int32_t *shifts;             /* (batch, ploidy)          | valid until the epoch ends             */
+    uint8_t *to_rc;              /* (batch * ploidy)        /                                        */
+    int64_t *out_offsets;        /* (batch * ploidy + 1), in the slot */
 } gvl_loader_batch;
 
 /* Bytes of one slot and the offsets of its parts (7 values: onehot, haps, regions,
@@ -322,9 +359,17 @@ int64_t gvl_loader_slot_bytes(const gvl_loader_config *cfg, int64_t *part_offset
 /* `st` is copied; the device arrays it points to must outlive the loader. */
 int gvl_loader_create(const gvl_static *st, const gvl_loader_config *cfg, gvl_loader **out);
 /* Begin an epoch over `order` (device i64[n] dataset indices, already shuffled by the caller;
- * must stay alive until the epoch ends).  `stream` is the stream `order` was produced on. */
+ * must stay alive until the epoch ends).  `stream` is the stream `order` was produced on.  The
+ * request arrays of the WHOLE epoch are prepared here, with one launch of the prep kernel
+ * (gvl_prepare_request over all n indices) into `table`; random draws are keyed by
+ * (cfg.seed, epochs started so far, dataset index). */
 int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int32_t drop_last,
-                           void *stream);
+                           void *table, void *stream);
+/* Bytes of the epoch table for n queries and the offsets of its 4 parts (regions i32 (n, 4),
+ * geno_offset_idx i64 (n, ploidy), shifts i32 (n, ploidy), to_rc u8 (n * ploidy)).  The table is the
+ * caller's device memory (256-byte aligned) and must stay alive until the epoch ends; batch j's
+ * request arrays are rows [j * batch_size, ...) of its parts. */
+int64_t gvl_loader_table_bytes(const gvl_loader_config *cfg, int64_t n, int64_t *part_offsets);
 /* Release the previously returned batch, top the pipeline up, and make `consumer_stream` wait
  * for the next batch.  Never blocks the host.  out->slot == -1 when the epoch is over. */
 int gvl_loader_next(gvl_loader *ld, void *consumer_stream, gvl_loader_batch *out);

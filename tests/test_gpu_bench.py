@@ -1,0 +1,86 @@
+"""bench.py end to end on the GPU box: the JSON contract at N = 1, and the N > 1 code path
+(two ranks sharing GPU 0 over gloo -- the driver's real multi-GPU run uses RCCL, covered by
+the nccl test below when the box has two devices)."""
+
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = Path(__file__).resolve().parent.parent
+SMALL = ["--scale", "small", "--queries", "16384", "--rotate", "8", "--min-region-ms", "2", "--cpu-budget", "1.5"]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _last_json(stdout: str) -> dict:
+    lines = [l for l in stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _run(cmd, env=None, timeout=600):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, env=e, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return _last_json(r.stdout)
+
+
+def test_bench_contract_single_gpu():
+    d = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", *SMALL])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "timing"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["dtype"] == "u8" and d["scaling"] == "weak"
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert 0 < r["pipelined_frac"] < 1 and r["frac_of_copy_ceiling"] > r["frac"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and "1" in c["threads_sweep"] and c["cores"] >= 1
+    assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+@pytest.mark.parametrize("extra", [["--gather"], ["--strong", "--gather"]], ids=["weak+gather", "strong+gather"])
+def test_bench_two_ranks_sharing_one_gpu_gloo(extra):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "10", "--warmup", "2",
+           "--no-cpu-baseline", *SMALL, *extra]
+    d = _run(cmd, env={"GVL_BENCH_DEVICE": "0", "GVL_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["gather_ms"] > 0
+    strong = "--strong" in extra
+    assert d["scaling"] == ("strong" if strong else "weak")
+    per_step = 4096 if strong else 8192
+    assert abs(d["value"] - per_step / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["config"]["windows_per_step_per_rank"] == (2048 if strong else 4096)
+    assert "world_size 2" in d["config"]["parallelism"]
+
+
+def test_bench_two_gpus_rccl():
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two HIP devices (the driver's SCALE run covers RCCL)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--no-cpu-baseline", "--gather", *SMALL]
+    d = _run(cmd)
+    assert d["n_gpus"] == 2 and d["gather_ms"] > 0 and d["scaling"] == "weak"
+
+
+def test_bench_refuses_world_size_mismatch():
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5", *SMALL], capture_output=True, text=True,
+                       cwd=REPO, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

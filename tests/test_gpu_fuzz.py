@@ -44,9 +44,19 @@ def test_fuzz_haplotypes_per_wave_scans_only():
     _run("fuzz.py", 300, 107, dbg=512)
 
 
+def test_fuzz_haplotypes_without_slot_records():
+    """GVL_DBG=64: ignore gvl_static.slot_rec: rows find their records through the CSR + geno_rec."""
+    _run("fuzz.py", 300, 108, dbg=64)
+
+
 def test_fuzz_haplotypes_without_genotype_records():
-    """GVL_DBG=16: ignore gvl_static.geno_rec, i.e. the geno_v_idxs -> vrec gather."""
-    _run("fuzz.py", 300, 105, dbg=16)
+    """GVL_DBG=80: ignore slot_rec and geno_rec, i.e. the geno_v_idxs -> vrec gather."""
+    _run("fuzz.py", 300, 105, dbg=80)
+
+
+def test_fuzz_haplotypes_without_speculative_reads():
+    """GVL_DBG=128: reference bytes are requested after the plan only."""
+    _run("fuzz.py", 200, 109, dbg=128)
 
 
 def test_fuzz_tracks_planned_walk():

@@ -40,7 +40,8 @@ def gpu():
 # reference's parity suite runs every schedule against the same goldens
 # (tests/parity/test_rayon_equivalence.py:31-62); here every reference vector goes down every
 # kernel path: gvl_set_debug_flags removes one way at a time.
-KERNEL_PATHS = {0: "default", 8: "scalar-walk", 16: "no-inline-records", 32: "no-scan-free-plan", 512: "per-wave-scans"}
+KERNEL_PATHS = {0: "default", 8: "scalar-walk", 64: "csr-inline-records", 80: "csr-vrec-gather", 32: "no-scan-free-plan",
+                128: "no-speculative-reads", 512: "per-wave-scans"}
 
 
 @pytest.fixture(params=sorted(KERNEL_PATHS), ids=[KERNEL_PATHS[k] for k in sorted(KERNEL_PATHS)])
@@ -561,3 +562,77 @@ def test_coordinates_beyond_2_30_fall_back_to_the_scalar_walk(gpu, oracle):
         np.testing.assert_array_equal(out.annot_ref_pos.cpu().numpy(), ap)
     del dev
     gpu.torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------ genome-scale generator (bench.py's dataset)
+@pytest.mark.parametrize("scale_kw", [dict(contigs=(3_000_000, 1_000_000, 500_000), n_queries=20_000),
+                                      dict(contigs=(700_000,) * 300, n_queries=30_000)],
+                         ids=["3-contigs", "300-contigs-no-lds-table"])
+def test_genome_dataset_batches(gpu, oracle, kpath, scale_kw):
+    """bench.py's device-generated dataset: batches drawn across the whole (multi-contig) genome,
+    genotype slots scattered over a large CSR; HIP vs oracle on the compacted host copy."""
+    from genvarloader_amd import HapsDevice, synth
+
+    ds = synth.GenomeDataset(device="cuda", seed=11, **scale_kw)
+    dev = HapsDevice(**ds.static_kwargs())
+    assert dev.slot_rec is not None
+    hs = ds.host_static()
+    for q in ds.draw_batches(2, 512, seed=5):
+        r = ds.request(q)
+        out = dev.reconstruct(r["regions"], r["shifts"], r["geno_offset_idx"], ds.length, to_rc=r["to_rc"],
+                              haps=True, onehot=True)
+        hb = ds.host_batch(q)
+        exp, exp_off, exp_oh = oracle.reconstruct_haplotypes_fused(
+            hb.regions, hb.shifts, hb.geno_offset_idx, hb.geno_offsets, hb.geno_v_idxs, hs.v_starts, hs.ilens,
+            hs.alt_alleles, hs.alt_offsets, hs.ref, hs.ref_offsets, hs.pad_char, ds.length, None, None, hb.to_rc, True,
+            onehot=True, n_threads=8)
+        np.testing.assert_array_equal(out.haps.cpu().numpy(), exp)
+        np.testing.assert_array_equal(out.onehot.cpu().numpy(), exp_oh)
+
+
+def test_slot_records_layout(gpu):
+    """gvl_pack_slots: 8 records per slot, EMPTY padding, OVERFLOW for slots with more than 8 variants."""
+    st, bt = _synth(41, (60_000,), 300, 600, indel_frac=0.3, density=1 / 60)
+    dev = make_dev(gpu, st, bt)
+    sr = dev.slot_rec.cpu().numpy().view(np.uint32).reshape(-1, 8, 4)
+    go = bt.geno_offsets
+    n = go[1] - go[0]
+    assert (n > 8).any() and (n <= 8).any()
+    for o in range(go.shape[1]):
+        if n[o] > 8:
+            assert sr[o, 0, 2] == 0xFFFFFFFE and (sr[o, 1:, 2] == 0xFFFFFFFF).all()
+            continue
+        v = bt.geno_v_idxs[go[0, o]:go[1, o]]
+        assert (sr[o, :n[o], 0].view(np.int32) == st.v_starts[v]).all()
+        assert (sr[o, :n[o], 1].view(np.int32) == st.ilens[v]).all()
+        alen = np.diff(st.alt_offsets)[v]
+        assert (sr[o, :n[o], 2] == ((alen.astype(np.uint32) << 8) | st.alt_alleles[st.alt_offsets[v]])).all()
+        assert (sr[o, :n[o], 3] == st.alt_offsets[v]).all()
+        assert (sr[o, n[o]:, 2] == 0xFFFFFFFF).all()
+
+
+# ------------------------------------------------------------------ a8 at realistic sizes
+@pytest.mark.parametrize("dtype", ["float32", "int32"])
+def test_reverse_flat_rows_4_ragged(gpu, dtype):
+    """reverse_flat_rows_inplace<T> (reverse.rs:25-38): ragged rows of odd / even / zero / one
+    length, masked rows untouched, f32 (tracks) and i32 (annotations), against numpy."""
+    rng = np.random.default_rng(77)
+    lens = np.concatenate([[0, 1, 2, 3, 4, 5, 255, 256, 257, 2047, 2048, 2049, 131072, 131071],
+                           rng.integers(0, 5000, 300)]).astype(np.int64)
+    rng.shuffle(lens)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    mask = rng.random(len(lens)) < 0.6
+    if dtype == "float32":
+        data = rng.standard_normal(int(offs[-1])).astype(np.float32)
+        data[::97] = np.nan                                     # bit patterns must survive
+    else:
+        data = rng.integers(-2**31, 2**31 - 1, int(offs[-1])).astype(np.int32)
+    exp = data.copy()
+    for i, m in enumerate(mask):
+        if m:
+            exp[offs[i]:offs[i + 1]] = exp[offs[i]:offs[i + 1]][::-1]
+    t = gpu.torch.from_numpy(data.copy()).cuda()
+    gpu.device.reverse_flat_rows_inplace(t, offs, mask)
+    np.testing.assert_array_equal(t.cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    gpu.device.reverse_flat_rows_inplace(t, offs, mask)         # involution
+    np.testing.assert_array_equal(t.cpu().numpy().view(np.uint32), data.view(np.uint32))

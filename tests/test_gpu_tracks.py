@@ -22,7 +22,7 @@ def ffi():
 
 # the realignment walk has two implementations (wave-scan planner / scalar replay) and the
 # variant records two sources: every reference vector goes down each of them
-TRACK_PATHS = {0: "default", 8: "scalar-walk", 16: "no-inline-records"}
+TRACK_PATHS = {0: "default", 8: "scalar-walk", 80: "csr-vrec-gather"}
 
 
 @pytest.fixture(params=sorted(TRACK_PATHS), ids=[TRACK_PATHS[k] for k in sorted(TRACK_PATHS)])

@@ -291,7 +291,7 @@ def test_threaded_loader_matches_inline_loader_and_survives_abandoned_epochs(ora
                            deterministic=False, seed=4)
 
     def run(threaded, epochs):
-        ds._counter = 0
+        ds._counter = ds._loaders = 0          # same derived loader seed for both runs
         dl = ds.to_dataloader(batch_size=4, shuffle=True, seed=9, in_flight=2, threaded=threaded)
         res = []
         lag = torch.zeros(1 << 20, device="cuda")
@@ -345,9 +345,9 @@ def test_haps_tracks_dataset_matches_oracle(oracle):
     dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
                      alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
                      pad_char=st.pad_char)
-    for strategy, param in ((0, 0.0), (4, 3.0)):
+    for strategy, param, pinned in ((0, 0.0, 11), (4, 3.0, 11), (3, 6.0, None), (3, 6.0, 5)):
         ds = DeviceHapsTracksDataset(dev, full_regions, S, P, tracks=tracks, strategy_id=strategy, param=param,
-                                     base_seed=11, output_length=L, onehot=False, haps=True)
+                                     base_seed=pinned, output_length=L, onehot=False, haps=True)
         seen = 0
         for batch in ds.to_dataloader(batch_size=7, shuffle=True, generator=torch.Generator().manual_seed(1)):
             idx = batch.idx.cpu().numpy()
@@ -370,7 +370,9 @@ def test_haps_tracks_dataset_matches_oracle(oracle):
                 exp = np.zeros(len(idx) * P * L, np.float32)
                 oracle.intervals_and_realign_track_fused(
                     exp, out_offsets, regions, shifts, goi, gv, go, st.v_starts, st.ilens, idx.astype(np.int64), a, e, v, io,
-                    track_offsets, np.array([param]), strategy, 11, None, None, to_rc)
+                    track_offsets, np.array([param]), strategy,
+                    # the reference's per-batch seed: xor-reduce of the dataset indices (_reconstruct.py:215-218)
+                    pinned if pinned is not None else int(np.bitwise_xor.reduce(idx.astype(np.uint64))), None, None, to_rc)
                 got = batch.tracks[:, t].contiguous().cpu().numpy().ravel()
                 np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32), err_msg=f"{name} strategy {strategy}")
             seen += len(idx)
