@@ -21,11 +21,13 @@ SYMBOLS = (
     "gvl_abi_version",
     "gvl_set_debug_flags",
     "gvl_last_error",
+    "gvl_async_error",
     "gvl_pack_variants",
     "gvl_pack_genotypes",
     "gvl_pack_slots",
     "gvl_reconstruct",
     "gvl_reconstruct_many",
+    "gvl_prefetch",
     "gvl_get_diffs_sparse",
     "gvl_hap_offsets",
     "gvl_get_reference",
@@ -35,8 +37,12 @@ SYMBOLS = (
     "gvl_reverse_rows_4",
     "gvl_onehot",
     "gvl_intervals_prefix_max",
+    "gvl_intervals_bucket_counts",
+    "gvl_intervals_bucket_fill",
     "gvl_intervals_to_tracks",
     "gvl_realign_tracks",
+    "gvl_tracks_scratch_bytes",
+    "gvl_tracks_batch",
     "gvl_prepare_request",
     "gvl_loader_slot_bytes",
     "gvl_loader_table_bytes",
@@ -77,6 +83,14 @@ class GvlOut(C.Structure):
     _fields_ = [
         ("haps", _vp), ("onehot", _vp), ("onehot_layout", C.c_int32),
         ("annot_v_idxs", _vp), ("annot_ref_pos", _vp), ("out_offsets", _vp),
+    ]
+
+
+class GvlTrackSet(C.Structure):
+    _fields_ = [
+        ("itv_starts", _vp), ("itv_ends", _vp), ("itv_values", _vp), ("itv_offsets", _vp),
+        ("n_intervals", _i64), ("itv_pmax_ends", _vp),
+        ("bkt_offsets", _vp), ("bkt_base", _vp), ("bkt_lo", _vp), ("bkt_hi", _vp),
     ]
 
 
@@ -139,10 +153,11 @@ def load() -> C.CDLL:
         fn = getattr(lib, name, None)
         if fn is None:
             raise GvlError(f"{p} does not export {name}")
-        if name not in ("gvl_last_error", "gvl_loader_slot_bytes", "gvl_loader_table_bytes"):
+        if name not in ("gvl_last_error", "gvl_loader_slot_bytes", "gvl_loader_table_bytes", "gvl_tracks_scratch_bytes"):
             fn.restype = C.c_int
     lib.gvl_loader_slot_bytes.restype = C.c_int64
     lib.gvl_loader_table_bytes.restype = C.c_int64
+    lib.gvl_tracks_scratch_bytes.restype = C.c_int64
     _LIB = lib
     return lib
 
@@ -154,3 +169,9 @@ def check(rc: int) -> None:
     if rc == 1:
         raise ValueError(msg)
     raise GvlError(msg)
+
+
+def check_async(clear: bool = True) -> None:
+    """After a synchronisation point: raise if a launch reported an error only the device could see
+    (a row longer than its batch's ``max_row_len`` hint)."""
+    check(load().gvl_async_error(C.c_int(1 if clear else 0)))

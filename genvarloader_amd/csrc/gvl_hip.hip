@@ -162,6 +162,7 @@ struct ReconArgs {
     // out
     u8 *haps; u8 *onehot; int *av; int *ap; i64 *out_offsets_w;
     u64 *stamps;        // diagnostic builds (-DGVL_DIAG): per-workgroup phase time stamps
+    int *async_err;     // host-mapped word: set when the launch finds a row longer than the max_row_len hint
 };
 
 // Per-wave mirror of the segment table + staging, used only by "general" trips.
@@ -1035,6 +1036,8 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         const bool shift_ok = !(ri.shift < 0 || ri.shift >= (1 << 30));
         if (!shift_ok || !planned_ok) fl |= 2;
         if (use_srec && shift_ok && !(A.dbg & 1)) fl |= 16;
+        // a row longer than the caller's max_row_len hint would be left partly unwritten: report it
+        if (row_lane && chunk == 0 && A.async_err && (i64)ri.L > (i64)gridDim.y * (i64)A.chunk_len) *A.async_err = 1;
         if (!row_lane || lo_clip >= ri.L) fl = 1;
         if (row_lane && A.out_offsets_w && chunk == 0) {
             A.out_offsets_w[k] = ri.row_base;
@@ -1057,6 +1060,14 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             i32x4 rec = *reinterpret_cast<const i32x4 *>(A.srec + ((want ? o_r : 0) * GVL_SLOT_RECS + (lane & 7)));
             if (!want) { rec.x = 0; rec.y = 0; rec.z = (int)GVL_SREC_EMPTY; rec.w = 0; }
             lrec[lane] = rec;
+            // a slot with more than 8 variants: that row goes through the CSR (third level; rare)
+            const u64 ovf = __builtin_amdgcn_ballot_w64(want && (lane & 7) == 0 && (u32)rec.z == GVL_SREC_OVERFLOW);
+            if (ovf && tid < WG_WAVES && ((ovf >> (8 * tid)) & 1ull)) {
+                fl &= ~16;
+                ri.o_s = A.go_starts[o_idx];
+                const i64 nv = A.go_stops[o_idx] - ri.o_s;
+                ri.n_var = nv < 0 ? 0 : (nv > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)nv);
+            }
         }
         if (fl != 1) {
             ri.c_s = l_cs;
@@ -1159,6 +1170,12 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         if ((spmask >> u) & 1u) wq[u] = load_u32_unaligned(sp_base + u * TRIP);
     }
 
+    // Who plans a row: see below (SNP-only rows plan themselves, the first wave that holds a row with
+    // an indel plans all such rows of the workgroup).  Measured and dropped in round 2: wave 0 planning
+    // EVERY packable row lane-parallel right after P1 while the other waves only keep their reference
+    // reads in flight -- a third of the issue slots, but the packed plan is a 3.6 us chain of dependent
+    // instructions when one wave runs it alone, and every row then waits for it (cfg3 14.5 vs 12.8 us,
+    // cfg2 14.0 vs 12.0 us per launch on the same box).
     int f_pos = 0, f_inl = 0, f_vi = 0;
     bool f_valid = false, is_fast = false;
     if (packable) {
@@ -2148,6 +2165,27 @@ __global__ __launch_bounds__(1024) void offsets_scan_kernel(i64 *offs, i64 n, i6
     }
 }
 
+// Scratch-track lengths of a haps + tracks batch (_reconstruct.py:191): per query,
+// len - min over haplotypes of min(diff, 0) with diff = the haplotype's length delta inside the
+// window (query mode of get_diffs_sparse); written at lengths[q + 1] for the scan.  Also the
+// (batch * ploidy + 1) fixed-length output offsets k * L that the realign kernel reads.
+__global__ __launch_bounds__(256) void track_lengths_kernel(const DiffArgs A, const int *regions, i64 regions_stride, i64 batch,
+                                                             i64 out_len, i64 *lengths, i64 *out_offsets) {
+    const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 K = batch * A.ploidy;
+    for (i64 k = q; k <= K; k += (i64)gridDim.x * blockDim.x) out_offsets[k] = k * out_len;
+    if (q >= batch) return;
+    const int *reg = regions + q * regions_stride;
+    const i64 qs = reg[1], qe = reg[2];
+    i64 mn = 0;
+    for (int p = 0; p < A.ploidy; ++p) {
+        const i64 d = (i64)(int)row_diff_core(A, A.geno_offset_idx[q * A.ploidy + p], false, 0, true, qs, qe);
+        mn = d < mn ? d : mn;
+    }
+    lengths[q + 1] = (qe - qs) - mn;
+    if (q == 0) lengths[0] = 0;
+}
+
 // ---------------------------------------------------------------------------
 // choose_exonic_variants (src/genotypes/mod.rs:127-176): keep[v] = the variant lies entirely
 // inside its query's [start, end).  Offsets first (counts -> the scan above), then the mask.
@@ -2758,11 +2796,17 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_kernel(
 constexpr int PAINT_TILE = 256;
 constexpr int PAINT_CHUNK = 2048;
 struct PaintTile { u32 idx[PAINT_CHUNK]; float cv[PAINT_TILE]; };
+// Coarse per-list index (gvl_intervals_bucket_*): bucket b of list i covers positions
+// [base[i] + 2048 b, base[i] + 2048 (b + 1)); lo[] = first interval whose running max of ends passes
+// the bucket's start, hi[] = first interval that starts at or after the bucket's end (both relative
+// to the list's first interval).  One lookup per chunk gives a SUPERSET of the chunk's candidates
+// (intervals outside the chunk clip to nothing), instead of two dependent 64-ary searches.
+struct PaintIndex { const i64 *offsets; const int *base; const int *lo; const int *hi; };
 
 __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
     const i64 *offset_idxs, const int *starts, i64 starts_stride, i64 n_queries, const int *itv_starts,
     const int *itv_ends, const float *itv_values, const i64 *itv_offsets, const int *pmax, float *out,
-    const i64 *out_offsets, int chunk_len, int n_chunks, u8 *chunk_todo) {
+    const i64 *out_offsets, int chunk_len, int n_chunks, u8 *chunk_todo, const PaintIndex X) {
     __shared__ PaintTile tiles[4];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = rfl((int)(threadIdx.x >> 6));
@@ -2777,7 +2821,7 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
     const i64 qs = rfl(starts[q * starts_stride]);
     // the first round of both searches probes the same 64 strided entries of the query's list for
     // every chunk: wave 0 fetches them once for the block's 4 chunks
-    if (wave == 0 && e0 > s0) {
+    if (!X.offsets && wave == 0 && e0 > s0) {
         const i64 st = (e0 - s0 + WAVE - 1) / WAVE;
         i64 pp = s0 + (i64)(lane + 1) * st - 1;
         if (pp > e0 - 1) pp = e0 - 1;
@@ -2791,11 +2835,26 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
     const i64 j1 = (length - j0 > chunk_len) ? j0 + chunk_len : length;
     // first start - qs >= j1 and first pmax - qs > j0: both searches advance together so that
     // their probe loads overlap (2 dependent rounds for lists of thousands instead of 4)
-    i64 hi_c, lo_c;
-    {
+    i64 hi_c = 0, lo_c = 0;
+    bool indexed = false;
+    if (X.offsets) {
+        const i64 b0 = rfl64(X.offsets[idx]);
+        const i64 nb = rfl64(X.offsets[idx + 1]) - b0;
+        if (nb > 0) {
+            const i64 base = rfl(X.base[idx]);
+            i64 ba = (qs + j0 - base) >> 11, bb = (qs + j1 - 1 - base) >> 11;
+            ba = ba < 0 ? 0 : (ba > nb - 1 ? nb - 1 : ba);
+            bb = bb < 0 ? 0 : (bb > nb - 1 ? nb - 1 : bb);
+            lo_c = s0 + rfl(X.lo[b0 + ba]);
+            hi_c = s0 + rfl(X.hi[b0 + bb]);
+            if (lo_c > hi_c) lo_c = hi_c;
+            indexed = hi_c - lo_c <= PAINT_TILE;
+        }
+    }
+    if (!indexed) {
         i64 a1 = s0, b1 = e0, a2 = s0, b2 = e0;
         bool d1 = false, d2 = false;
-        bool first = true;
+        bool first = X.offsets == nullptr;      // (the shared first-round probes are only fetched without an index)
         while (!(d1 && d2)) {
             i64 p1 = 0, p2 = 0, st1 = 1, st2 = 1;
             int k1 = 0, k2 = 0;
@@ -2892,6 +2951,44 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
     }
 }
 
+// bucket counts of every list (written at counts[i + 1] for the scan) and the list's base position
+__global__ __launch_bounds__(256) void bucket_counts_kernel(const int *itv_starts, const i64 *itv_offsets, i64 n_lists,
+                                                             i64 *counts, int *base) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) counts[0] = 0;
+    if (i >= n_lists) return;
+    const i64 s0 = itv_offsets[i], e0 = itv_offsets[i + 1];
+    i64 n = 0;
+    int b = 0;
+    if (e0 > s0) {
+        b = itv_starts[s0];
+        n = ((i64)itv_starts[e0 - 1] - (i64)b) / PAINT_CHUNK + 1;
+    }
+    counts[i + 1] = n;
+    base[i] = b;
+}
+
+__global__ __launch_bounds__(256) void bucket_fill_kernel(const int *itv_starts, const int *pmax, const i64 *itv_offsets,
+                                                           i64 n_lists, const i64 *bkt_offsets, const int *base, int *lo_out,
+                                                           int *hi_out) {
+    const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= bkt_offsets[n_lists]) return;
+    i64 a = 0, b = n_lists;                      // list i with bkt_offsets[i] <= g < bkt_offsets[i + 1]
+    while (b - a > 1) {
+        const i64 m = (a + b) >> 1;
+        if (bkt_offsets[m] <= g) a = m; else b = m;
+    }
+    const i64 i = a;
+    const i64 s0 = itv_offsets[i], e0 = itv_offsets[i + 1];
+    const i64 x0 = (i64)base[i] + (g - bkt_offsets[i]) * PAINT_CHUNK, x1 = x0 + PAINT_CHUNK;
+    i64 l = s0, h = e0;                          // first c with pmax[c] > x0
+    while (l < h) { const i64 m = (l + h) >> 1; if ((i64)pmax[m] > x0) h = m; else l = m + 1; }
+    lo_out[g] = (int)(l - s0);
+    l = s0; h = e0;                              // first c with start >= x1
+    while (l < h) { const i64 m = (l + h) >> 1; if ((i64)itv_starts[m] >= x1) h = m; else l = m + 1; }
+    hi_out[g] = (int)(l - s0);
+}
+
 // pmax[c] = max(ends[s .. c]) within each queried list: one wave per list, 64 entries per trip
 __global__ __launch_bounds__(256) void intervals_prefix_max_kernel(const i64 *list_idxs, i64 n_lists,
                                                                     const int *itv_ends, const i64 *itv_offsets,
@@ -2918,6 +3015,42 @@ __global__ __launch_bounds__(256) void intervals_prefix_max_kernel(const i64 *li
 // ---------------------------------------------------------------------------------
 // Device-side request prep: one thread per query (see gvl_prepare_request in gvl_hip.h).
 // ---------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// Input prefetch for a batch that will be reconstructed soon (a loader knows its next batches): touch
+// the lines the reconstruct kernel will gather -- the rows' request entries, their slot-major record
+// line, their reference window -- so that they sit in L2 / Infinity Cache when it runs.  Pure
+// latency work on a side stream; 32 lanes per row, one 128-byte line each per pass.
+// ---------------------------------------------------------------------------
+struct PrefetchArgs {
+    const u8 *ref; i64 ref_len; const i64 *ref_offsets; int n_contigs;
+    const gvl_srec *srec; i64 n_geno_offsets;
+    const int *regions; i64 regions_stride; const int *shifts; const i64 *geno_offset_idx;
+    i64 n_rows; int ploidy; i64 span;      // bytes of reference a row may read from its start
+    u32 *sink;
+};
+
+__global__ __launch_bounds__(256) void prefetch_kernel(const PrefetchArgs A) {
+    const i64 k = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int t = threadIdx.x & 31;
+    if (k >= A.n_rows) return;
+    const i64 q = k / A.ploidy;
+    const int *reg = A.regions + q * A.regions_stride;
+    const int c = reg[0];
+    const i64 start = reg[1];
+    const i64 shift = A.shifts ? (i64)A.shifts[k] : 0;
+    const i64 slot = A.geno_offset_idx ? A.geno_offset_idx[k] : 0;
+    u32 acc = 0;
+    if (c >= 0 && c < A.n_contigs) {
+        const i64 c_s = A.ref_offsets[c], c_e = A.ref_offsets[c + 1];
+        i64 lo = c_s + (start < 0 ? 0 : start) + (shift < 0 ? 0 : shift);
+        lo &= ~127ll;
+        const i64 hi = imin(imin(lo + A.span + 256, c_e), A.ref_len);
+        for (i64 a = lo + 128ll * t; a + 4 <= hi; a += 128ll * 32) acc ^= *reinterpret_cast<const u32 *>(A.ref + a);
+    }
+    if (t == 0 && A.srec && slot >= 0 && slot < A.n_geno_offsets) acc ^= *reinterpret_cast<const u32 *>(A.srec + slot * GVL_SLOT_RECS);
+    if (acc == 0x9E3779B9u && A.sink) *A.sink = acc;      // (keeps the loads; practically never taken)
+}
+
 struct PrepArgs {
     DiffArgs D;               // CSR + ilens / v_starts for the shift bound
     const i64 *idx; i64 batch; const int *full_regions; i64 n_regions; i64 n_samples; int ploidy;
@@ -2985,6 +3118,24 @@ int check_launch(const char *what) {
     return GVL_OK;
 }
 
+// Errors a kernel finds out about (asynchronous, like a sticky HIP error): one host-mapped word the
+// device writes and gvl_async_error() reads.
+int *g_async_err = nullptr;
+int *async_err_word() {
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void *p = nullptr;
+        if (hipHostMalloc(&p, sizeof(int), hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && p) {
+            *(volatile int *)p = 0;
+            g_async_err = (int *)p;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    return g_async_err;
+}
+
 int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
     // one wave owns `chunk_len` bases of a row (blockIdx.y = chunk, so <= 65535 chunks);
     // rows up to 2048 bp are one chunk (= CHUNK_TRIPS trips, what the planned path handles)
@@ -3011,6 +3162,7 @@ int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
 //    16  ignore gvl_static.geno_rec (records come from geno_v_idxs -> vrec)
 //    64  ignore gvl_static.slot_rec (rows find their records through the CSR)
 //   128  no speculative reference reads in front of the plan
+//  1024  painter ignores the per-list bucket index (exact 64-ary searches per chunk)
 // and 1 / 2 / 4 = timing ablations (no variants / no stores / no loads).
 int g_debug_override = -1;
 int debug_flags() {
@@ -3061,6 +3213,15 @@ int gvl_set_debug_flags(int flags) { g_debug_override = flags; return GVL_OK; }
 void gvl_diag_set_stamps(void *buf) { g_stamps = (u64 *)buf; }
 #endif
 const char *gvl_last_error(void) { return g_err; }
+
+int gvl_async_error(int clear) {
+    int *w = g_async_err;
+    if (!w) return GVL_OK;
+    const int e = *(volatile int *)w;
+    if (clear) *(volatile int *)w = 0;
+    if (e == 1) return fail(GVL_ERR_INVALID, "%s", "a launch found a row longer than its batch's max_row_len hint: that row was left partly unwritten");
+    return e ? fail(GVL_ERR_INVALID, "%s", "asynchronous device-side error") : GVL_OK;
+}
 
 int gvl_pack_variants(const int32_t *v_starts, const int32_t *ilens, const int64_t *alt_offsets,
                       const uint8_t *alt_alleles, int64_t n_variants, gvl_vrec *vrec_out,
@@ -3152,6 +3313,7 @@ static int fill_recon_args(const gvl_static *st, const gvl_batch *bt, const gvl_
     A.haps = out->haps; A.onehot = out->onehot;
     A.av = out->annot_v_idxs; A.ap = out->annot_ref_pos; A.out_offsets_w = (i64 *)out->out_offsets;
     A.stamps = g_stamps;
+    A.async_err = async_err_word();
     const bool annot = out->annot_v_idxs || out->annot_ref_pos;
     const int oh = !out->onehot ? OH_NONE : (out->onehot_layout == GVL_ONEHOT_CL ? OH_CL : OH_LC);
     *variant = oh | ((out->haps != nullptr) ? 4 : 0) | (annot ? 8 : 0);
@@ -3193,6 +3355,29 @@ int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_o
         if (rc) return rc;
     }
     return GVL_OK;
+}
+
+int gvl_prefetch(const gvl_static *st, const gvl_batch *bt, void *stream) {
+    if (!st || !bt) return fail(GVL_ERR_INVALID, "%s", "gvl_prefetch: NULL struct");
+    if (bt->batch <= 0 || bt->ploidy <= 0) return GVL_OK;
+    if (!st->ref || !st->ref_offsets || !bt->regions || bt->regions_stride < 3) return fail(GVL_ERR_INVALID, "%s", "gvl_prefetch: NULL array");
+    PrefetchArgs P;
+    memset(&P, 0, sizeof(P));
+    P.ref = st->ref; P.ref_len = st->ref_len; P.ref_offsets = (const i64 *)st->ref_offsets;
+    P.n_contigs = (int)(st->n_contigs > 0x7FFFFFFFll ? 0x7FFFFFFF : st->n_contigs);
+    P.srec = st->slot_rec; P.n_geno_offsets = st->n_geno_offsets;
+    P.regions = bt->regions; P.regions_stride = bt->regions_stride; P.shifts = bt->shifts;
+    P.geno_offset_idx = (const i64 *)bt->geno_offset_idx;
+    P.n_rows = bt->batch * bt->ploidy; P.ploidy = (int)bt->ploidy;
+    i64 span = bt->output_length >= 0 ? bt->output_length : bt->max_row_len;
+    if (span < 0) span = 0;
+    if (span > (1 << 20)) span = 1 << 20;             // very long rows: the head of the row is what the latency is about
+    P.span = span + 64;
+    P.sink = (u32 *)async_err_word();
+    const i64 grid = (P.n_rows * 32 + 255) / 256;
+    if (grid > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_prefetch: batch too large");
+    prefetch_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(P);
+    return check_launch("gvl_prefetch");
 }
 
 int gvl_get_reference(const gvl_static *st, const int32_t *regions, int64_t regions_stride,
@@ -3354,6 +3539,63 @@ int gvl_intervals_prefix_max(const int32_t *itv_ends, const int64_t *itv_offsets
     return check_launch("gvl_intervals_prefix_max");
 }
 
+int gvl_intervals_bucket_counts(const int32_t *itv_starts, const int64_t *itv_offsets, int64_t n_lists,
+                                int64_t *bkt_offsets, int32_t *bkt_base, int64_t *total, void *stream) {
+    if (n_lists < 0) return fail(GVL_ERR_INVALID, "%s", "gvl_intervals_bucket_counts: negative size");
+    if (!itv_offsets || !bkt_offsets || !bkt_base || (n_lists > 0 && !itv_starts && false))
+        return fail(GVL_ERR_INVALID, "%s", "gvl_intervals_bucket_counts: NULL array");
+    hipStream_t s = (hipStream_t)stream;
+    const i64 grid = (n_lists + 1 + 255) / 256;
+    bucket_counts_kernel<<<dim3((unsigned)grid), dim3(256), 0, s>>>(itv_starts, (const i64 *)itv_offsets, (i64)n_lists,
+                                                                   (i64 *)bkt_offsets, bkt_base);
+    int rc = check_launch("gvl_intervals_bucket_counts");
+    if (rc) return rc;
+    offsets_scan_kernel<<<dim3(1), dim3(1024), 0, s>>>((i64 *)bkt_offsets, (i64)n_lists, (i64 *)total);
+    return check_launch("gvl_intervals_bucket_counts(scan)");
+}
+
+int gvl_intervals_bucket_fill(const int32_t *itv_starts, const int32_t *itv_pmax_ends, const int64_t *itv_offsets,
+                              int64_t n_lists, const int64_t *bkt_offsets, const int32_t *bkt_base, int64_t n_buckets,
+                              int32_t *bkt_lo, int32_t *bkt_hi, void *stream) {
+    if (n_lists < 0 || n_buckets < 0) return fail(GVL_ERR_INVALID, "%s", "gvl_intervals_bucket_fill: negative size");
+    if (n_buckets == 0) return GVL_OK;
+    if (!itv_starts || !itv_pmax_ends || !itv_offsets || !bkt_offsets || !bkt_base || !bkt_lo || !bkt_hi)
+        return fail(GVL_ERR_INVALID, "%s", "gvl_intervals_bucket_fill: NULL array");
+    const i64 grid = (n_buckets + 255) / 256;
+    if (grid > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_intervals_bucket_fill: too many buckets");
+    bucket_fill_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(
+        itv_starts, itv_pmax_ends, (const i64 *)itv_offsets, (i64)n_lists, (const i64 *)bkt_offsets, bkt_base, bkt_lo, bkt_hi);
+    return check_launch("gvl_intervals_bucket_fill");
+}
+
+// paint launches; `todo` (n_queries * n_chunks bytes, nullable) selects the tiled kernel + the per-value
+// kernel for the chunks it leaves, NULL the per-value kernel alone
+static int paint_launch(const int64_t *offset_idxs, const int32_t *starts, int64_t starts_stride, int64_t n_queries,
+                        const int32_t *itv_starts, const int32_t *itv_ends, const float *itv_values,
+                        const int64_t *itv_offsets, const int32_t *itv_pmax_ends, float *out, const int64_t *out_offsets,
+                        int64_t max_row_len, u8 *todo, hipStream_t s, const PaintIndex X = PaintIndex{nullptr, nullptr, nullptr, nullptr}) {
+    const int chunk_len = 2048;
+    const i64 n_chunks = (max_row_len + chunk_len - 1) / chunk_len;
+    if (todo) {
+        intervals_to_tracks_tiled_kernel<<<dim3((unsigned)((n_chunks + 3) / 4), (unsigned)n_queries), dim3(256), 0, s>>>(
+            (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
+            (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, (int)n_chunks, todo, X);
+        intervals_to_tracks_kernel<<<dim3((unsigned)n_chunks, (unsigned)n_queries), dim3(256), 0, s>>>(
+            (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
+            (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, todo);
+    } else {
+        i64 gx = (max_row_len + 255) / 256;
+        if (gx > 1024) gx = 1024;
+        intervals_to_tracks_kernel<<<dim3((unsigned)gx, (unsigned)n_queries), dim3(256), 0, s>>>(
+            (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
+            (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, nullptr);
+    }
+    return check_launch("gvl_intervals_to_tracks");
+}
+static bool paint_can_tile(const int32_t *pmax, int64_t max_row_len) {
+    return pmax && max_row_len < 0x7FFFFF00ll && (max_row_len + 2047) / 2048 <= 0x7FFFFFFFll / 4;
+}
+
 int gvl_intervals_to_tracks(const int64_t *offset_idxs, const int32_t *starts, int64_t starts_stride,
                             int64_t n_queries, const int32_t *itv_starts, const int32_t *itv_ends,
                             const float *itv_values, const int64_t *itv_offsets, int64_t n_intervals,
@@ -3382,29 +3624,15 @@ int gvl_intervals_to_tracks(const int64_t *offset_idxs, const int32_t *starts, i
     // tiled pass (rows shorter than 2^31, every list has its prefix maxima), then the per-value
     // kernel for the chunks it left (more than PAINT_TILE candidate intervals) -- or for everything
     // when the flag scratch cannot be had
-    const int chunk_len = 2048;
-    const i64 n_chunks = (max_row_len + chunk_len - 1) / chunk_len;
+    const i64 n_chunks = (max_row_len + 2047) / 2048;
     u8 *todo = nullptr;
-    if (itv_pmax_ends && max_row_len < 0x7FFFFF00ll && n_chunks <= 0x7FFFFFFFll / 4 &&
+    if (paint_can_tile(itv_pmax_ends, max_row_len) &&
         hipMallocAsync((void **)&todo, (size_t)(n_queries * n_chunks), s) != hipSuccess) {
         (void)hipGetLastError();
         todo = nullptr;
     }
-    if (todo) {
-        intervals_to_tracks_tiled_kernel<<<dim3((unsigned)((n_chunks + 3) / 4), (unsigned)n_queries), dim3(256), 0, s>>>(
-            (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
-            (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, (int)n_chunks, todo);
-        intervals_to_tracks_kernel<<<dim3((unsigned)n_chunks, (unsigned)n_queries), dim3(256), 0, s>>>(
-            (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
-            (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, todo);
-    } else {
-        i64 gx = (max_row_len + 255) / 256;
-        if (gx > 1024) gx = 1024;
-        intervals_to_tracks_kernel<<<dim3((unsigned)gx, (unsigned)n_queries), dim3(256), 0, s>>>(
-            (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
-            (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, nullptr);
-    }
-    const int rc = check_launch("gvl_intervals_to_tracks");
+    const int rc = paint_launch(offset_idxs, starts, starts_stride, n_queries, itv_starts, itv_ends, itv_values, itv_offsets,
+                                itv_pmax_ends, out, out_offsets, max_row_len, todo, s);
     if (todo) (void)hipFreeAsync(todo, s);
     if (scratch) (void)hipFreeAsync(scratch, s);
     return rc;
@@ -3443,6 +3671,84 @@ int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *t
     return check_launch("gvl_realign_tracks");
 }
 
+
+// scratch layout of gvl_tracks_batch: track_offsets i64 (batch + 1) | out_offsets i64 (batch * ploidy + 1) |
+// chunk flags u8 (batch * chunks) | scratch tracks f32 (batch * stride)
+static void tracks_scratch_parts(i64 batch, i64 ploidy, i64 stride, i64 part[5]) {
+    const i64 n_chunks = (stride + 2047) / 2048;
+    const i64 sz[4] = {8 * (batch + 1), 8 * (batch * ploidy + 1), batch * n_chunks, 4 * batch * stride};
+    i64 off = 0;
+    for (int i = 0; i < 4; ++i) { part[i] = off; off += (sz[i] + 255) & ~255ll; }
+    part[4] = off;
+}
+
+int64_t gvl_tracks_scratch_bytes(int64_t batch, int64_t ploidy, int64_t scratch_stride) {
+    if (batch < 0 || ploidy <= 0 || scratch_stride < 0) return -1;
+    i64 part[5];
+    tracks_scratch_parts(batch, ploidy, scratch_stride, part);
+    return part[4] > 0 ? part[4] : 256;
+}
+
+int gvl_tracks_batch(const gvl_static *st, const gvl_batch *bt, const int64_t *offset_idxs, const gvl_track_set *tracks,
+                     int32_t n_tracks, const double *params, int64_t strategy_id, uint64_t base_seed, float *out,
+                     int64_t out_track_stride, void *scratch, int64_t scratch_stride, void *stream) {
+    if (!st || !bt || n_tracks < 0) return fail(GVL_ERR_INVALID, "%s", "gvl_tracks_batch: bad arguments");
+    if (bt->batch < 0 || bt->ploidy <= 0 || bt->output_length < 0)
+        return fail(GVL_ERR_INVALID, "%s", "gvl_tracks_batch: needs batch >= 0, ploidy > 0 and a fixed output_length");
+    if (bt->batch == 0 || n_tracks == 0) return GVL_OK;
+    if (bt->batch > 65535) return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_tracks_batch: more than 65535 queries per call");
+    if (!bt->regions || !bt->shifts || !bt->geno_offset_idx || bt->regions_stride < 3 || !offset_idxs || !tracks || !params ||
+        !out || !scratch || ((uintptr_t)scratch & 255) || scratch_stride <= 0 || scratch_stride > 0x7FFFFF00ll)
+        return fail(GVL_ERR_INVALID, "%s", "gvl_tracks_batch: NULL/invalid array (scratch: gvl_tracks_scratch_bytes(), 256-byte aligned)");
+    const i64 B = bt->batch, P = bt->ploidy, L = bt->output_length;
+    if (out_track_stride < B * P * L) return fail(GVL_ERR_INVALID, "%s", "gvl_tracks_batch: out_track_stride < batch * ploidy * output_length");
+    hipStream_t s = (hipStream_t)stream;
+    i64 part[5];
+    tracks_scratch_parts(B, P, scratch_stride, part);
+    u8 *base = (u8 *)scratch;
+    i64 *track_offsets = (i64 *)(base + part[0]);
+    i64 *out_offsets = (i64 *)(base + part[1]);
+    u8 *todo = base + part[2];
+    float *scr = (float *)(base + part[3]);
+    // 1. scratch-track lengths -> offsets (the reference sizes the scratch track per query, _reconstruct.py:191)
+    DiffArgs D;
+    int rc = fill_diff_args(D, st, bt, "gvl_tracks_batch");
+    if (rc) return rc;
+    D.keep = nullptr; D.keep_offsets = nullptr;
+    {
+        i64 n = B > B * P + 1 ? B : B * P + 1;
+        i64 grid = (n + 255) / 256;
+        if (grid > 4096) grid = 4096;
+        if (grid < (B + 255) / 256) grid = (B + 255) / 256;
+        track_lengths_kernel<<<dim3((unsigned)grid), dim3(256), 0, s>>>(D, bt->regions, (i64)bt->regions_stride, B, L, track_offsets, out_offsets);
+        rc = check_launch("gvl_tracks_batch(lengths)");
+        if (rc) return rc;
+        offsets_scan_kernel<<<dim3(1), dim3(1024), 0, s>>>(track_offsets, B, (i64 *)nullptr);
+        rc = check_launch("gvl_tracks_batch(scan)");
+        if (rc) return rc;
+    }
+    // 2. per track: paint the query's intervals into its scratch track, realign it to every haplotype
+    gvl_batch rb = *bt;
+    rb.out_offsets = (const int64_t *)out_offsets;
+    rb.max_row_len = L;
+    rb.output_length = -1;
+    for (int t = 0; t < n_tracks; ++t) {
+        const gvl_track_set &T = tracks[t];
+        if (!T.itv_offsets || (T.n_intervals > 0 && (!T.itv_starts || !T.itv_ends || !T.itv_values)))
+            return fail(GVL_ERR_INVALID, "%s", "gvl_tracks_batch: NULL interval array");
+        PaintIndex X{nullptr, nullptr, nullptr, nullptr};
+        if (T.bkt_offsets && T.bkt_base && T.bkt_lo && T.bkt_hi && !(debug_flags() & 1024))
+            X = PaintIndex{(const i64 *)T.bkt_offsets, T.bkt_base, T.bkt_lo, T.bkt_hi};
+        rc = paint_launch(offset_idxs, bt->regions + 1, bt->regions_stride, B, T.itv_starts, T.itv_ends, T.itv_values, T.itv_offsets,
+                          T.itv_pmax_ends, scr, (const int64_t *)track_offsets, scratch_stride,
+                          paint_can_tile(T.itv_pmax_ends, scratch_stride) ? todo : nullptr, s, X);
+        if (rc) return rc;
+        rc = gvl_realign_tracks(st, &rb, scr, (const int64_t *)track_offsets, params, strategy_id, base_seed,
+                                out + (i64)t * out_track_stride, stream);
+        if (rc) return rc;
+    }
+    return GVL_OK;
+}
 
 int gvl_prepare_request(const gvl_static *st, const int64_t *idx, int64_t batch,
                         const int32_t *full_regions, int64_t n_regions, int64_t n_samples,

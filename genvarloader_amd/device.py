@@ -275,6 +275,10 @@ class HapsDevice:
         """One pass of the hot path over one batch: a single kernel launch."""
         _lib.check(self.lib.gvl_reconstruct(C.byref(self.c), C.byref(bt.c), C.byref(out_c), _stream_ptr(stream)))
 
+    def prefetch(self, bt: DeviceBatch, stream=None) -> None:
+        """``gvl_prefetch``: pull a coming batch's inputs into L2 / Infinity Cache (side stream)."""
+        _lib.check(self.lib.gvl_prefetch(C.byref(self.c), C.byref(bt.c), _stream_ptr(stream)))
+
     def pack_many(self, bts, out_cs):
         """C arrays for :meth:`launch_many` (build once, launch many times)."""
         n = len(bts)
@@ -384,6 +388,27 @@ def intervals_prefix_max(itv_ends, itv_offsets, device="cuda") -> torch.Tensor:
     with torch.cuda.device(d):
         _lib.check(lib.gvl_intervals_prefix_max(_ptr(b), _ptr(io), C.c_int64(int(io.numel()) - 1), _ptr(pm), _stream_ptr()))
     return pm
+
+
+def intervals_bucket_index(itv_starts, itv_pmax_ends, itv_offsets, device="cuda"):
+    """Coarse per-list index for the painter (``gvl_intervals_bucket_counts`` / ``_fill``; once per
+    interval set, one host read of the bucket total) -> (bkt_offsets, bkt_base, bkt_lo, bkt_hi)."""
+    lib = _lib.load()
+    d = torch.device(device)
+    a, pm, io = _dev(itv_starts, torch.int32, d), _dev(itv_pmax_ends, torch.int32, d), _dev(itv_offsets, torch.int64, d)
+    n_lists = int(io.numel()) - 1
+    bo = torch.empty(n_lists + 1, dtype=torch.int64, device=d)
+    base = torch.empty(max(n_lists, 1), dtype=torch.int32, device=d)
+    tot = torch.zeros(2, dtype=torch.int64, device=d)
+    with torch.cuda.device(d):
+        _lib.check(lib.gvl_intervals_bucket_counts(_ptr(a), _ptr(io), C.c_int64(n_lists), _ptr(bo), _ptr(base), _ptr(tot),
+                                                   _stream_ptr()))
+        n_b = int(tot[0].item())
+        lo = torch.empty(max(n_b, 1), dtype=torch.int32, device=d)
+        hi = torch.empty(max(n_b, 1), dtype=torch.int32, device=d)
+        _lib.check(lib.gvl_intervals_bucket_fill(_ptr(a), _ptr(pm), _ptr(io), C.c_int64(n_lists), _ptr(bo), _ptr(base),
+                                                 C.c_int64(n_b), _ptr(lo), _ptr(hi), _stream_ptr()))
+    return bo, base, lo, hi
 
 
 def intervals_to_tracks(offset_idxs, starts, itv_starts, itv_ends, itv_values, itv_offsets, out_offsets,

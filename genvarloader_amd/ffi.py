@@ -38,6 +38,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
+from . import _lib
 from . import device as _device
 from .device import HapsDevice, _starts_stops
 
@@ -46,8 +47,25 @@ _STATIC_CACHE_MAX = 4
 
 
 def _key(a):
+    """Cache key of a per-dataset host array: address, shape, dtype AND a content fingerprint, so
+    that an in-place edit of a cached array is a miss (re-upload) and not silently ignored.  The
+    fingerprint is exact below 1 MiB and a strided sample of 4096 elements (plus both ends) above --
+    the arrays are per-dataset constants by contract (``_HapsFfiStatic``, _haps.py:233-247), this
+    only guards against accidents; ``clear_static_cache()`` forces a re-upload."""
+    import zlib
+
     a = np.asarray(a)
-    return (a.__array_interface__["data"][0], a.shape, a.dtype.str)
+    flat = a.reshape(-1)
+    if flat.size == 0:
+        fp = 0
+    elif a.nbytes <= (1 << 20):
+        fp = zlib.adler32(np.ascontiguousarray(flat).view(np.uint8))
+    else:
+        step = max(1, flat.size // 4096)
+        fp = zlib.adler32(np.ascontiguousarray(flat[::step]).view(np.uint8))
+        fp = zlib.adler32(np.ascontiguousarray(flat[:64]).view(np.uint8), fp)
+        fp = zlib.adler32(np.ascontiguousarray(flat[-64:]).view(np.uint8), fp)
+    return (a.__array_interface__["data"][0], a.shape, a.dtype.str, fp)
 
 
 def _req(a, dt, name, ndim=None):
@@ -97,6 +115,13 @@ def _np(t):
     pinned block is one DMA at PCIe speed."""
     if t is None:
         return None
+    try:
+        return _np_copy(t)
+    finally:
+        _lib.check_async()       # (the copy synchronised: anything a launch reported is visible now)
+
+
+def _np_copy(t):
     if t.is_cuda and t.numel() * t.element_size() >= (1 << 20):
         host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
         host.copy_(t, non_blocking=True)
@@ -187,7 +212,7 @@ def get_diffs_sparse(geno_offset_idx, geno_v_idxs, geno_offsets, ilens, keep=Non
     ilens = _req(ilens, np.int32, "ilens", 1)
     n_var = len(ilens)
     has_query = q_starts is not None and q_ends is not None and v_starts is not None
-    vs = _req(v_starts, np.int32, "v_starts", 1) if has_query else np.zeros(n_var, np.int32)
+    vs = _req(v_starts, np.int32, "v_starts", 1) if has_query else None
     # diffs only read the CSR + ilens/v_starts: a stub reference/allele table is enough
     dev = _diffs_static(geno_offsets, geno_v_idxs, vs, ilens)
     d = dev.get_diffs_sparse(geno_offset_idx, keep, keep_offsets,
@@ -222,16 +247,18 @@ def rc_alleles(byte_data, seq_offsets, var_offsets, to_rc_row):
 
 
 def _diffs_static(geno_offsets, geno_v_idxs, v_starts, ilens) -> HapsDevice:
-    arrs = tuple(np.asarray(a) for a in (geno_offsets, geno_v_idxs, v_starts, ilens))
-    geno_offsets, geno_v_idxs, v_starts, ilens = arrs
-    key = tuple(_key(a) for a in arrs)
+    """``v_starts`` None (plain / keep mode): positions are not read, and not part of the key."""
+    arrs = tuple(np.asarray(a) for a in (geno_offsets, geno_v_idxs, ilens) + (() if v_starts is None else (v_starts,)))
+    geno_offsets, geno_v_idxs, ilens = arrs[:3]
+    key = tuple(_key(a) for a in arrs) + (v_starts is None,)
     dev = _DIFF_CACHE.get(key)
     if dev is None:
         n = len(ilens)
         dev = HapsDevice(ref=np.zeros(1, np.uint8), ref_offsets=np.array([0, 1], np.int64),
-                         v_starts=v_starts, ilens=ilens, alt_alleles=np.zeros(1, np.uint8),
+                         v_starts=np.zeros(n, np.int32) if v_starts is None else arrs[3], ilens=ilens,
+                         alt_alleles=np.zeros(1, np.uint8),
                          alt_offsets=np.zeros(n + 1, np.int64), geno_offsets=_starts_stops(geno_offsets),
-                         geno_v_idxs=_req(geno_v_idxs, np.int32, "geno_v_idxs", 1))
+                         geno_v_idxs=_req(geno_v_idxs, np.int32, "geno_v_idxs", 1), slot_records=False)
         dev._host_refs = arrs
         _DIFF_CACHE[key] = dev
         while len(_DIFF_CACHE) > _STATIC_CACHE_MAX:
@@ -282,7 +309,7 @@ def _track_static(geno_offsets, geno_v_idxs, v_starts, ilens) -> HapsDevice:
                          v_starts=_req(v_starts, np.int32, "v_starts", 1), ilens=_req(ilens, np.int32, "ilens", 1),
                          alt_alleles=np.zeros(1, np.uint8), alt_offsets=np.zeros(n + 1, np.int64),
                          geno_offsets=_starts_stops(geno_offsets),
-                         geno_v_idxs=_req(geno_v_idxs, np.int32, "geno_v_idxs", 1))
+                         geno_v_idxs=_req(geno_v_idxs, np.int32, "geno_v_idxs", 1), slot_records=False)
         dev._host_refs = arrs
         _TRACK_CACHE[key] = dev
         while len(_TRACK_CACHE) > _STATIC_CACHE_MAX:

@@ -231,7 +231,7 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
         self.strategy_id, self.param = int(strategy_id), float(param)
         self.base_seed = None if base_seed is None else int(base_seed) & 0xFFFFFFFFFFFFFFFF
         self.track_names = list(tracks)
-        self._itv = []
+        self._itv, self._bkt = [], []
         n_lists = self.n_regions * self.n_samples
         for name in self.track_names:
             a, b, v, io = tracks[name]
@@ -243,6 +243,15 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
                 raise ValueError(f"track {name!r}: itv_offsets must have regions x samples + 1 entries")
             pm = _device.intervals_prefix_max(b, io, d) if int(b.numel()) else None
             self._itv.append((a, b, v, io, pm))
+            self._bkt.append(_device.intervals_bucket_index(a, pm, io, d) if pm is not None else None)
+        from ._lib import GvlTrackSet
+
+        self._track_sets = (GvlTrackSet * max(len(self._itv), 1))(*[
+            GvlTrackSet(itv_starts=a.data_ptr(), itv_ends=b.data_ptr(), itv_values=v.data_ptr(), itv_offsets=io.data_ptr(),
+                        n_intervals=int(a.numel()), itv_pmax_ends=None if pm is None else pm.data_ptr(),
+                        bkt_offsets=None if bk is None else bk[0].data_ptr(), bkt_base=None if bk is None else bk[1].data_ptr(),
+                        bkt_lo=None if bk is None else bk[2].data_ptr(), bkt_hi=None if bk is None else bk[3].data_ptr())
+            for (a, b, v, io, pm), bk in zip(self._itv, self._bkt)])
         reg = self.full_regions
         max_len = int((reg[:, 2] - reg[:, 1]).max().item()) if self.n_regions else 0
         # scratch track per query: len - min(diff, 0) <= 2 * len (a window cannot lose more than itself)
@@ -252,8 +261,7 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
         import ctypes as C
 
         from . import _lib
-        from . import device as _device
-        from .device import _ptr, _stream_ptr
+        from ._lib import GvlBatch
 
         if self.base_seed is not None:
             seed = self.base_seed
@@ -272,35 +280,30 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
         if b == 0 or not self._itv:
             return TrackBatch(base.onehot, base.haps, base.idx, base.regions, base.shifts, base.geno_offset_idx,
                               base.to_rc, None)
-        K = b * P
-        out_offsets = torch.arange(K + 1, dtype=torch.int64, device=d) * L
-        qs = base.regions[:, 1].contiguous()
-        qe = base.regions[:, 2].contiguous()
-        # the reference's scratch track length per query (_reconstruct.py:191): len - min_p(min(diff, 0))
-        diffs = dev.get_diffs_sparse(base.geno_offset_idx, q_starts=qs, q_ends=qe)
-        tlen = (qe - qs).to(torch.int64) - diffs.min(dim=1).values.clamp(max=0).to(torch.int64)
-        track_offsets = torch.zeros(b + 1, dtype=torch.int64, device=d)
-        torch.cumsum(tlen, 0, out=track_offsets[1:])
-        offset_idxs = base.idx                                   # list index = region * S + sample = dataset index
-        bt = dev.prepare_batch(base.regions, base.shifts, base.geno_offset_idx, -1, None, None, base.to_rc,
-                               out_offsets, max_row_len=L)
+        K, T = b * P, len(self._itv)
+        # ONE native call for the track half (gvl_tracks_batch): scratch-track lengths, then paint +
+        # realign per track; output and scratch share one arena, no torch op per batch
+        lib = dev.lib
+        n_scr = int(lib.gvl_tracks_scratch_bytes(C.c_int64(b), C.c_int64(P), C.c_int64(self._stride)))
+        out_bytes = (4 * T * K * L + 255) & ~255
+        arena = torch.empty(out_bytes + n_scr, dtype=torch.uint8, device=d)
+        bt = GvlBatch(regions=base.regions.data_ptr(), regions_stride=4, shifts=base.shifts.data_ptr(),
+                      geno_offset_idx=base.geno_offset_idx.data_ptr(), batch=b, ploidy=P, keep=None, keep_offsets=None,
+                      to_rc=None if base.to_rc is None else base.to_rc.data_ptr(), output_length=L, out_offsets=None,
+                      max_row_len=L)
         par = (C.c_double * 1)(self.param)
-        tracks = torch.empty((len(self._itv), K * L), dtype=torch.float32, device=d)
-        scratch = torch.empty(b * self._stride, dtype=torch.float32, device=d)
         with torch.cuda.device(d):
-            for t, (a, e, v, io, pm) in enumerate(self._itv):
-                _lib.check(dev.lib.gvl_intervals_to_tracks(
-                    _ptr(offset_idxs), _ptr(qs), C.c_int64(1), C.c_int64(b), _ptr(a), _ptr(e), _ptr(v), _ptr(io),
-                    C.c_int64(int(a.numel())), _ptr(pm), _ptr(scratch), _ptr(track_offsets), C.c_int64(self._stride),
-                    _stream_ptr()))
-                _lib.check(dev.lib.gvl_realign_tracks(
-                    C.byref(dev.c), C.byref(bt.c), _ptr(scratch), _ptr(track_offsets), par, C.c_int64(self.strategy_id),
-                    C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), _ptr(tracks[t]), _stream_ptr()))
+            _lib.check(lib.gvl_tracks_batch(
+                C.byref(dev.c), C.byref(bt), C.c_void_p(base.idx.data_ptr()), self._track_sets, C.c_int32(T), par,
+                C.c_int64(self.strategy_id), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_void_p(arena.data_ptr()),
+                C.c_int64(K * L), C.c_void_p(arena.data_ptr() + out_bytes), C.c_int64(self._stride),
+                C.c_void_p(torch.cuda.current_stream(d).cuda_stream)))
+        tracks = arena[:4 * T * K * L].view(torch.float32).view(T, b, P, L).permute(1, 0, 2, 3)
         out = TrackBatch(base.onehot, base.haps, base.idx, base.regions, base.shifts, base.geno_offset_idx, base.to_rc,
-                         tracks.view(len(self._itv), b, P, L).permute(1, 0, 2, 3))
+                         tracks)
         out._arena = base._arena
         out.base_seed = seed
-        out._keep = (bt, scratch, out_offsets, track_offsets, qs)
+        out._keep = (arena,)
         return out
 
     def to_dataloader(self, batch_size: int = 1, shuffle: bool = False, sampler=None, drop_last: bool = False,
@@ -450,17 +453,24 @@ class DeviceLoader:
                                                   C.c_void_p(cur.cuda_stream)))
             nat["order"] = order                       # keep the epoch order alive
             nxt, ref_out, bs = lib.gvl_loader_next, C.byref(out), self.batch_size
+            nxt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]          # plain ints in, no wrapper objects per call
             idx_views = order.split(bs) if n else ()          # one C++ loop instead of a slice per batch
-            cur_stream, views, vp = torch.cuda.current_stream, self._slot_views, C.c_void_p
+            # the consumer's CURRENT stream, read every iteration (it may change), through the raw getter
+            raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+            dev_i = d.index if d.index is not None else torch.cuda.current_device()
+            if raw_stream is None:
+                raw_stream = lambda i_: torch.cuda.current_stream(i_).cuda_stream
+            views, h = self._slot_views, handle.value
+            none_rc = rc_v is None
             i = 0
             while True:
-                rc = nxt(handle, vp(cur_stream(d).cuda_stream), ref_out)
+                rc = nxt(h, raw_stream(dev_i), ref_out)
                 if rc:
                     _lib.check(rc)
                 if out.slot < 0:
                     return
                 oh, hp = views(out.slot, out.batch)
-                batch = Batch(oh, hp, idx_views[i], reg_v[i], sh_v[i], goi_v[i], None if rc_v is None else rc_v[i])
+                batch = Batch(oh, hp, idx_views[i], reg_v[i], sh_v[i], goi_v[i], None if none_rc else rc_v[i])
                 i += 1
                 yield batch
 
@@ -484,7 +494,7 @@ class DeviceLoader:
                             world=self.world_size, drop_last=self.drop_last and self.world_size > 1,
                             device="cpu", generator=self.generator).numpy()       # host indices: no sync per batch
         self.epoch += 1
-        bs, n = self.batch_size, int(order.numel())
+        bs, n = self.batch_size, int(order.size)
         for s in range(0, n, bs):
             if self.drop_last and s + bs > n:
                 break
@@ -521,8 +531,6 @@ class DeviceLoader:
                 idx = next(it)
             except StopIteration:
                 return False
-            if isinstance(idx, np.ndarray):
-                idx = torch.from_numpy(idx)
             st = self.streams[k % self.in_flight]
             k += 1
             st.wait_stream(torch.cuda.current_stream(self.ds.dev.device))

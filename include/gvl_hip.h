@@ -150,6 +150,12 @@ int gvl_abi_version(void);
  * debug_flags() in gvl_hip.hip); flags < 0 returns to the environment's value. */
 int gvl_set_debug_flags(int flags);
 const char *gvl_last_error(void);
+/* Errors only the device can find are reported asynchronously, like a sticky HIP error: after the
+ * stream has been synchronised, gvl_async_error() returns GVL_ERR_INVALID (message in
+ * gvl_last_error()) if any launch since the last clear met a row longer than its batch's
+ * `max_row_len` hint (such a row is left partly unwritten; the reference writes every byte,
+ * src/ffi/mod.rs:17-35, so this must not pass silently).  clear != 0 resets the flag. */
+int gvl_async_error(int clear);
 
 /* Build the packed variant records (once per dataset).
  * Replaces nothing in the reference; it is the HBM layout this path reads
@@ -187,6 +193,11 @@ int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *ou
 #define GVL_MANY_MAX 8
 int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_out *outs,
                          int32_t n, void *stream);
+
+/* Touch the inputs a later gvl_reconstruct of `bt` will gather (request entries, slot-major record
+ * lines, reference windows) so that they are in L2 / Infinity Cache by then.  For a prefetching
+ * loader, which knows its next batches; asynchronous on `stream` (use a side stream), reads only. */
+int gvl_prefetch(const gvl_static *st, const gvl_batch *bt, void *stream);
 
 /* Per-row length deltas.  Replaces get_diffs_sparse (src/ffi/mod.rs:143-185 ->
  * src/genotypes/mod.rs:15-125).  Query mode iff q_starts, q_ends and st->v_starts
@@ -285,6 +296,51 @@ int gvl_intervals_to_tracks(const int64_t *offset_idxs, const int32_t *starts, i
 int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *tracks,
                        const int64_t *track_offsets, const double *params, int64_t strategy_id,
                        uint64_t base_seed, float *out, void *stream);
+
+/* One track's interval store (per dataset; the reference's RaggedIntervals, _dataset/_tracks.py):
+ * list i = intervals [itv_offsets[i], itv_offsets[i + 1]), sorted by start. */
+typedef struct gvl_track_set {
+    const int32_t *itv_starts;
+    const int32_t *itv_ends;
+    const float *itv_values;
+    const int64_t *itv_offsets;
+    int64_t n_intervals;
+    const int32_t *itv_pmax_ends; /* from gvl_intervals_prefix_max(); NULL = per-value painting only */
+    /* optional coarse index (gvl_intervals_bucket_counts / _fill); all four or none */
+    const int64_t *bkt_offsets;   /* n_lists + 1 */
+    const int32_t *bkt_base;      /* n_lists     */
+    const int32_t *bkt_lo;        /* n_buckets   */
+    const int32_t *bkt_hi;        /* n_buckets   */
+} gvl_track_set;
+
+/* Coarse per-list index for the painter (once per interval set, next to gvl_intervals_prefix_max):
+ * buckets of 2048 positions from each list's first start; per bucket the first interval whose running
+ * maximum of ends passes the bucket's start and the first interval starting at or after its end.
+ * Step 1 writes bkt_offsets (n_lists + 1, exclusive scan of the lists' bucket counts), bkt_base
+ * (n_lists) and total[0] = number of buckets (device i64[2]); the caller sizes bkt_lo / bkt_hi from
+ * it; step 2 fills them.  A painter with the index does one lookup per (query, 2048-value chunk)
+ * instead of two dependent 64-ary searches over the query's list. */
+int gvl_intervals_bucket_counts(const int32_t *itv_starts, const int64_t *itv_offsets, int64_t n_lists,
+                                int64_t *bkt_offsets, int32_t *bkt_base, int64_t *total, void *stream);
+int gvl_intervals_bucket_fill(const int32_t *itv_starts, const int32_t *itv_pmax_ends, const int64_t *itv_offsets,
+                              int64_t n_lists, const int64_t *bkt_offsets, const int32_t *bkt_base,
+                              int64_t n_buckets, int32_t *bkt_lo, int32_t *bkt_hi, void *stream);
+
+/* The track half of a haplotypes + tracks batch in ONE call (what Haps/Tracks reconstruction does per
+ * batch and track, _reconstruct.py:183-307 -> intervals_and_realign_track_fused, src/ffi/mod.rs:2551-2672):
+ * scratch-track length per query = len - min_p(min(diff, 0)) (diff = get_diffs_sparse in query mode),
+ * then per track: paint the query's intervals (list offset_idxs[q]) into its scratch track, realign it
+ * to every haplotype (fill strategy / params / base_seed as gvl_realign_tracks), reverse negative-strand
+ * rows.  bt: regions, shifts, geno_offset_idx, to_rc, batch, ploidy, output_length (fixed, >= 0).
+ * out: f32, track t at out + t * out_track_stride, rows (batch * ploidy, output_length).
+ * scratch: gvl_tracks_scratch_bytes(batch, ploidy, scratch_stride) bytes of the caller's device memory,
+ * 256-byte aligned; scratch_stride = values reserved per query's scratch track (>= 2 * the longest
+ * region is always enough).  No allocation, no host synchronisation. */
+int64_t gvl_tracks_scratch_bytes(int64_t batch, int64_t ploidy, int64_t scratch_stride);
+int gvl_tracks_batch(const gvl_static *st, const gvl_batch *bt, const int64_t *offset_idxs,
+                     const gvl_track_set *tracks, int32_t n_tracks, const double *params,
+                     int64_t strategy_id, uint64_t base_seed, float *out, int64_t out_track_stride,
+                     void *scratch, int64_t scratch_stride, void *stream);
 
 /* ---- device-side request prep -------------------------------------- */
 

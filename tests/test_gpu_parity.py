@@ -636,3 +636,42 @@ def test_reverse_flat_rows_4_ragged(gpu, dtype):
     np.testing.assert_array_equal(t.cpu().numpy().view(np.uint32), exp.view(np.uint32))
     gpu.device.reverse_flat_rows_inplace(t, offs, mask)         # involution
     np.testing.assert_array_equal(t.cpu().numpy().view(np.uint32), data.view(np.uint32))
+
+
+# ------------------------------------------------------------------ host hints and caches
+def test_wrong_max_row_len_hint_is_reported(gpu, oracle):
+    """A max_row_len hint smaller than a row would leave that row partly unwritten; the reference
+    writes every byte (src/ffi/mod.rs:17-35), so the launch reports it (gvl_async_error)."""
+    from genvarloader_amd import _lib
+
+    st, bt = _synth(51, (60_000,), 20, 3000, indel_frac=0.3, output_length=-1)
+    dev = make_dev(gpu, st, bt)
+    _, exp_off, _ = oracle_fused(oracle, st, bt, onehot=True)
+    lens = np.diff(exp_off)
+    assert lens.max() > 2048
+    _lib.check_async()                                              # clean slate
+    good = dev.prepare_batch(bt.regions, bt.shifts, bt.geno_offset_idx, -1, out_offsets=exp_off, max_row_len=int(lens.max()))
+    out, oc = dev.alloc_output(good, int(exp_off[-1]), haps=True, onehot=False)
+    dev.launch(good, oc)
+    gpu.torch.cuda.synchronize()
+    _lib.check_async()                                              # a correct hint: nothing to report
+    bad = dev.prepare_batch(bt.regions, bt.shifts, bt.geno_offset_idx, -1, out_offsets=exp_off, max_row_len=2048)
+    dev.launch(bad, oc)
+    gpu.torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="max_row_len"):
+        _lib.check_async()
+    _lib.check_async()                                              # cleared by the check
+
+
+def test_ffi_cache_sees_in_place_edits(gpu, oracle):
+    """The numpy drop-in layer caches the per-dataset arrays in HBM keyed by the host buffers; an
+    in-place edit of a cached array must be a miss, not a stale result."""
+    st, bt = _synth(52, (40_000,), 30, 500, indel_frac=0.2)
+    args = lambda: (bt.regions, bt.shifts, bt.geno_offset_idx, bt.geno_offsets, bt.geno_v_idxs, st.v_starts, st.ilens,
+                    st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, bt.output_length)
+    a, _ = gpu.ffi.reconstruct_haplotypes_fused(*args())
+    st.ref[:] = np.where(st.ref == ord("A"), ord("C"), st.ref)      # same buffer, new content
+    b, _ = gpu.ffi.reconstruct_haplotypes_fused(*args())
+    exp, _ = oracle.reconstruct_haplotypes_fused(*args(), None, None, None, False)
+    np.testing.assert_array_equal(b, exp)
+    assert not np.array_equal(a, b)

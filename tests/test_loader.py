@@ -322,7 +322,8 @@ def test_threaded_loader_matches_inline_loader_and_survives_abandoned_epochs(ora
 
 
 @pytest.mark.gpu
-def test_haps_tracks_dataset_matches_oracle(oracle):
+@pytest.mark.parametrize("dbg", [0, 1024, 8], ids=["default", "painter-without-bucket-index", "scalar-walk"])
+def test_haps_tracks_dataset_matches_oracle(oracle, dbg):
     """cfg4's dataset shape at a small size: haplotypes + two realigned tracks per batch from dataset
     indices, against the oracle's fused paint + realign for the same request."""
     from genvarloader_amd import HapsDevice
@@ -345,6 +346,9 @@ def test_haps_tracks_dataset_matches_oracle(oracle):
     dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
                      alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
                      pad_char=st.pad_char)
+    from genvarloader_amd import _lib
+
+    _lib.load().gvl_set_debug_flags(dbg)
     for strategy, param, pinned in ((0, 0.0, 11), (4, 3.0, 11), (3, 6.0, None), (3, 6.0, 5)):
         ds = DeviceHapsTracksDataset(dev, full_regions, S, P, tracks=tracks, strategy_id=strategy, param=param,
                                      base_seed=pinned, output_length=L, onehot=False, haps=True)
@@ -377,3 +381,53 @@ def test_haps_tracks_dataset_matches_oracle(oracle):
                 np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32), err_msg=f"{name} strategy {strategy}")
             seen += len(idx)
         assert seen == R * S
+    _lib.load().gvl_set_debug_flags(-1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dbg", [0, 1024], ids=["bucket-index", "exact-searches"])
+def test_tracks_batch_long_rows_jitter_and_dense_lists(oracle, dbg):
+    """gvl_tracks_batch on rows of many 2048-value chunks whose starts are not bucket aligned (jitter),
+    with sparse, ordinary and very dense interval lists (a dense list overflows the painter's tile:
+    per-value kernel; two buckets of candidates beyond the tile: exact searches)."""
+    from genvarloader_amd import HapsDevice, _lib
+    from genvarloader_amd.loader import DeviceHapsTracksDataset
+
+    R, S, P, L = 3, 4, 2, 9000
+    st, full_regions, go, gv = _grid_dataset(77, R, S, P, L, contig=400_000, indel_frac=0.4, slack=50)
+    rng = np.random.default_rng(9)
+    starts, ends, vals, offs = [], [], [], [0]
+    for r in range(R):
+        for s_ in range(S):
+            mean_w = (3, 25, 400)[(r * S + s_) % 3]
+            pos = int(full_regions[r, 1]) - int(rng.integers(0, 300))
+            while pos < int(full_regions[r, 2]) + 300:
+                w, gap = int(rng.geometric(1 / mean_w)), int(rng.integers(0, 4)) if mean_w < 100 else int(rng.integers(0, 3000))
+                starts.append(pos + gap); ends.append(pos + gap + w); vals.append(float(rng.random() * 5)); pos += gap + w
+            offs.append(len(starts))
+    tracks = {"t": (np.array(starts, np.int32), np.array(ends, np.int32), np.array(vals, np.float32), np.array(offs, np.int64))}
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+    _lib.load().gvl_set_debug_flags(dbg)
+    try:
+        ds = DeviceHapsTracksDataset(dev, full_regions, S, P, tracks=tracks, strategy_id=0, output_length=L, jitter=37,
+                                     onehot=False, haps=True, seed=3)
+        for batch in ds.to_dataloader(batch_size=5, shuffle=True, seed=2):
+            idx = batch.idx.cpu().numpy()
+            regions, shifts = batch.regions.cpu().numpy(), batch.shifts.cpu().numpy()
+            goi = batch.geno_offset_idx.cpu().numpy()
+            to_rc = batch.to_rc.cpu().numpy().astype(bool)
+            diffs = oracle.get_diffs_sparse(goi, gv, go, st.ilens, None, None, regions[:, 1], regions[:, 2], st.v_starts)
+            tlen = (regions[:, 2] - regions[:, 1]).astype(np.int64) - np.minimum(diffs.min(axis=1), 0)
+            track_offsets = np.concatenate([[0], np.cumsum(tlen)]).astype(np.int64)
+            out_offsets = np.arange(len(idx) * P + 1, dtype=np.int64) * L
+            a, e, v, io = tracks["t"]
+            exp = np.zeros(len(idx) * P * L, np.float32)
+            oracle.intervals_and_realign_track_fused(exp, out_offsets, regions, shifts, goi, gv, go, st.v_starts, st.ilens,
+                                                     idx.astype(np.int64), a, e, v, io, track_offsets, np.array([0.0]), 0,
+                                                     0, None, None, to_rc)
+            got = batch.tracks[:, 0].contiguous().cpu().numpy().ravel()
+            np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32))
+    finally:
+        _lib.load().gvl_set_debug_flags(-1)

@@ -19,9 +19,14 @@ dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, i
                  alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv, pad_char=st.pad_char)
 for det in (True, False):
     ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, jitter=0 if det else 16, deterministic=det, seed=1)
-    for in_flight, gen, thr in ((1, None, False), (3, None, False), (3, None, True), (3, torch.Generator().manual_seed(0), False)):
-        dl = ds.to_dataloader(batch_size=bs, shuffle=True, generator=gen, in_flight=in_flight, threaded=thr)
-        for rep in range(3):                        # first pass warms up
+    combos = ((1, 1, None, False), (3, 1, None, False), (4, 1, None, False), (2, 4, None, False), (3, 4, None, False),
+              (4, 4, None, False), (4, 2, None, False), (4, 4, None, True), (3, 4, None, True),
+              (3, 4, torch.Generator().manual_seed(0), False))
+    if os.environ.get("QUICK"):
+        combos = ((4, 4, None, False),)
+    for in_flight, group, gen, thr in combos:
+        dl = ds.to_dataloader(batch_size=bs, shuffle=True, generator=gen, in_flight=in_flight, threaded=thr, group=group)
+        for rep in range(int(os.environ.get("REPS", 4))):                        # first pass warms up
             torch.cuda.synchronize(); t0 = time.perf_counter(); n = 0; t_first = None
             for batch in dl:
                 if t_first is None:
@@ -30,6 +35,6 @@ for det in (True, False):
             t_issue = time.perf_counter()
             torch.cuda.synchronize(); t1 = time.perf_counter()
         dt = t1 - t0
-        print(f"deterministic={det} in_flight={in_flight} {'cpu-shuffle' if gen is not None else 'dev-shuffle'}{' threaded' if thr else ''}: {n} windows in {dt*1e3:.1f} ms -> {n/dt/1e6:.1f} M windows/s; "
-              f"first batch after {1e3*(t_first-t0):.1f} ms, loop {1e6*(t_issue-t_first)/max(1,len(dl)-1):.1f} us/batch host, "
-              f"steady {1e6*(t1-t_first)/max(1,len(dl)-1):.1f} us per {bs*P}-window batch")
+        print(f"deterministic={det} in_flight={in_flight} group={group} {'cpu-shuffle' if gen is not None else 'dev-shuffle'}{' threaded' if thr else ''}: {n} windows in {dt*1e3:.2f} ms -> {n/dt/1e6:.1f} M windows/s; "
+              f"first batch after {1e3*(t_first-t0):.2f} ms, loop {1e6*(t_issue-t_first)/max(1,len(dl)-1):.1f} us/batch host, "
+              f"steady {1e6*(t1-t_first)/max(1,len(dl)-1):.1f} us per {bs*P}-window batch", flush=True)
