@@ -216,8 +216,6 @@ def main() -> None:
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the launches of the timed region rotate over")
-    ap.add_argument("--prefetch", type=int, default=0,
-                    help="timed region: also launch gvl_prefetch for the batch this many steps ahead (side stream)")
     ap.add_argument("--many", type=int, default=1,
                     help="batches per launch in the timed region (gvl_reconstruct_many; a step is still ONE batch)")
     ap.add_argument("--min-region-ms", type=float, default=20.0)
@@ -295,7 +293,6 @@ def main() -> None:
                                    - dev.geno_offsets[0][b.geno_offset_idx.reshape(-1)]).double().mean())
                             for b in batches[: min(8, n_rot)]]))
     counter = [0]
-    pf_stream = torch.cuda.Stream()
 
     def step_pipelined(i: int) -> None:
         # a batch is independent of the previous one: the loader keeps `--streams` batches in
@@ -303,8 +300,6 @@ def main() -> None:
         # and variant gathers, scans) overlaps the store-bound tail of another
         j = counter[0]
         counter[0] += 1
-        if args.prefetch > 0:
-            dev.prefetch(batches[(j + args.prefetch) % n_rot], pf_stream)
         dev.launch(batches[j % n_rot], slots[j % n_slots][1], streams[i % len(streams)])
 
     class ManyStepper:
@@ -443,7 +438,7 @@ def main() -> None:
                           else ("rotating" if n_rot > 1 else "cache-hot (one batch re-launched)"),
                 "parallelism": f"world_size {world}: " + ("one batch split into contiguous query blocks" if args.strong
                                                           else "rows sharded over the ranks, one full batch per rank per step"),
-                "streams": len(streams), "batches_per_launch": G, "prefetch_distance": args.prefetch, "batches_in_flight": len(streams) * G,
+                "streams": len(streams), "batches_per_launch": G, "batches_in_flight": len(streams) * G,
                 "dataset_build_s": round(t_gen, 2),
             },
             "timing": {

@@ -27,7 +27,6 @@ SYMBOLS = (
     "gvl_pack_slots",
     "gvl_reconstruct",
     "gvl_reconstruct_many",
-    "gvl_prefetch",
     "gvl_get_diffs_sparse",
     "gvl_hap_offsets",
     "gvl_get_reference",

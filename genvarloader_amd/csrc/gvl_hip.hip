@@ -2092,6 +2092,75 @@ __device__ __forceinline__ i64 row_diff_core(const DiffArgs &A, const i64 o_idx,
     return acc;
 }
 
+// The same, one WAVE per haplotype, 64 variants per trip (one coalesced read of the records).  The
+// walk is sequential only through "skip a variant that starts inside what an applied variant already
+// covers" (mod.rs:70): variant i is applied iff NOT (q_start <= pos_i < max(q_start, v_end of every
+// applied variant before it)) -- an exclusive prefix-max over the applied set, iterated to its fixed
+// point (unique: membership of i depends on the applied set in front of i only; each round settles at
+// least one more lane).  The break at the first pos >= q_end is a filter because positions are sorted.
+__device__ __forceinline__ i64 wave_excl_prefix_max64(i64 x, const int lane) {
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const i64 y = __shfl_up(x, o, WAVE);
+        if (lane >= o) x = imax(x, y);
+    }
+    const i64 p = __shfl_up(x, 1, WAVE);
+    return lane == 0 ? (i64)(-0x7FFFFFFFFFFFFFFFll - 1) : p;
+}
+__device__ __forceinline__ i64 row_diff_wave(const DiffArgs &A, const i64 o_idx, const bool has_keep, const i64 ks,
+                                              const bool has_query, const i64 q_start, const i64 q_end, const int lane) {
+    const i64 o_s = rfl64(A.go_starts[o_idx]), o_e = rfl64(A.go_stops[o_idx]);
+    i64 acc = 0, carry = q_start;
+    for (i64 b = o_s; b < o_e; b += WAVE) {
+        const i64 v = b + lane;
+        i64 vs = 0, il = 0;
+        bool valid = v < o_e;
+        if (valid) {
+            if (A.grec) {
+                const int2 r = *reinterpret_cast<const int2 *>(A.grec + v);
+                vs = r.x; il = r.y;
+            } else {
+                const i64 vi = A.geno_v_idxs[v];
+                il = A.ilens[vi];
+                if (has_query) vs = A.v_starts[vi];
+            }
+            if (has_keep) valid = A.keep[ks + (v - o_s)] != 0;
+        }
+        i64 x = 0;
+        if (!has_query) {                                          // mod.rs:86-103: a (masked) sum
+            x = valid ? il : 0;
+        } else {                                                   // mod.rs:48-85
+            const i64 v_end = vs - imin(il, 0) + 1;
+            const bool cand = valid && v_end > q_start && vs < q_end;
+            bool inB = cand;
+            u64 mB = __builtin_amdgcn_ballot_w64(inB);
+            for (int it = 0; it < WAVE + 1; ++it) {
+                i64 pm = wave_excl_prefix_max64(inB ? v_end : (i64)(-0x7FFFFFFFFFFFFFFFll - 1), lane);
+                pm = imax(pm, carry);
+                inB = cand && !(vs >= q_start && vs < pm);
+                const u64 m2 = __builtin_amdgcn_ballot_w64(inB);
+                if (m2 == mB) break;
+                mB = m2;
+            }
+            if (inB) {
+                i64 d = il;
+                if (d < 0) d += imax(q_start - vs - 1, 0);
+                d += imax(v_end - q_end, 0);
+                x = d;
+            }
+            i64 mx = inB ? v_end : carry;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = imax(mx, __shfl_xor(mx, o, WAVE));
+            carry = imax(carry, mx);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, WAVE);
+        acc += x;
+        if (has_query && __builtin_amdgcn_ballot_w64(v < o_e && vs >= q_end) != 0) break;   // sorted: nothing further counts
+    }
+    return acc;
+}
+
 __device__ __forceinline__ i64 row_diff(const DiffArgs &A, i64 k) {
     const i64 query = k / A.ploidy;
     const bool has_query = A.q_starts && A.q_ends && A.v_starts;   // mod.rs:35
@@ -2114,6 +2183,32 @@ __global__ __launch_bounds__(256) void diffs_kernel(const DiffArgs A, const int 
             len = A.output_length;
         } else {
             const int *reg = regions + (k / A.ploidy) * regions_stride;
+            len = imax((i64)(reg[2] - reg[1]) + d, 0);
+        }
+        A.lengths[k + 1] = len;
+        if (k == 0) A.lengths[0] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void diffs_wave_kernel(const DiffArgs A, const int *regions, i64 regions_stride) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const i64 k = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (k >= A.n_rows) return;
+    const i64 query = k / A.ploidy;
+    const bool has_query = A.q_starts && A.q_ends && A.v_starts;
+    const bool has_keep = A.keep && A.keep_offsets;
+    const i64 ks = has_keep ? rfl64(A.keep_offsets[k]) : 0;
+    const i64 q_start = has_query ? (i64)rfl(A.q_starts[query * A.q_stride]) : 0;
+    const i64 q_end = has_query ? (i64)rfl(A.q_ends[query * A.q_stride]) : 0;
+    const int d = (int)row_diff_wave(A, rfl64(A.geno_offset_idx[k]), has_keep, ks, has_query, q_start, q_end, lane);
+    if (lane != 0) return;
+    if (A.diffs) A.diffs[k] = d;
+    if (A.lengths) {
+        i64 len;
+        if (A.output_length >= 0) {
+            len = A.output_length;
+        } else {
+            const int *reg = regions + query * regions_stride;
             len = imax((i64)(reg[2] - reg[1]) + d, 0);
         }
         A.lengths[k + 1] = len;
@@ -2171,19 +2266,23 @@ __global__ __launch_bounds__(1024) void offsets_scan_kernel(i64 *offs, i64 n, i6
 // (batch * ploidy + 1) fixed-length output offsets k * L that the realign kernel reads.
 __global__ __launch_bounds__(256) void track_lengths_kernel(const DiffArgs A, const int *regions, i64 regions_stride, i64 batch,
                                                              i64 out_len, i64 *lengths, i64 *out_offsets) {
-    const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const i64 K = batch * A.ploidy;
-    for (i64 k = q; k <= K; k += (i64)gridDim.x * blockDim.x) out_offsets[k] = k * out_len;
+    for (i64 k = t; k <= K; k += (i64)gridDim.x * blockDim.x) out_offsets[k] = k * out_len;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const i64 q = t >> 6;                                    // one wave per query
     if (q >= batch) return;
     const int *reg = regions + q * regions_stride;
-    const i64 qs = reg[1], qe = reg[2];
+    const i64 qs = rfl(reg[1]), qe = rfl(reg[2]);
     i64 mn = 0;
     for (int p = 0; p < A.ploidy; ++p) {
-        const i64 d = (i64)(int)row_diff_core(A, A.geno_offset_idx[q * A.ploidy + p], false, 0, true, qs, qe);
+        const i64 d = (i64)(int)row_diff_wave(A, rfl64(A.geno_offset_idx[q * A.ploidy + p]), false, 0, true, qs, qe, lane);
         mn = d < mn ? d : mn;
     }
-    lengths[q + 1] = (qe - qs) - mn;
-    if (q == 0) lengths[0] = 0;
+    if (lane == 0) {
+        lengths[q + 1] = (qe - qs) - mn;
+        if (q == 0) lengths[0] = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -3015,42 +3114,6 @@ __global__ __launch_bounds__(256) void intervals_prefix_max_kernel(const i64 *li
 // ---------------------------------------------------------------------------------
 // Device-side request prep: one thread per query (see gvl_prepare_request in gvl_hip.h).
 // ---------------------------------------------------------------------------------
-// ---------------------------------------------------------------------------
-// Input prefetch for a batch that will be reconstructed soon (a loader knows its next batches): touch
-// the lines the reconstruct kernel will gather -- the rows' request entries, their slot-major record
-// line, their reference window -- so that they sit in L2 / Infinity Cache when it runs.  Pure
-// latency work on a side stream; 32 lanes per row, one 128-byte line each per pass.
-// ---------------------------------------------------------------------------
-struct PrefetchArgs {
-    const u8 *ref; i64 ref_len; const i64 *ref_offsets; int n_contigs;
-    const gvl_srec *srec; i64 n_geno_offsets;
-    const int *regions; i64 regions_stride; const int *shifts; const i64 *geno_offset_idx;
-    i64 n_rows; int ploidy; i64 span;      // bytes of reference a row may read from its start
-    u32 *sink;
-};
-
-__global__ __launch_bounds__(256) void prefetch_kernel(const PrefetchArgs A) {
-    const i64 k = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    const int t = threadIdx.x & 31;
-    if (k >= A.n_rows) return;
-    const i64 q = k / A.ploidy;
-    const int *reg = A.regions + q * A.regions_stride;
-    const int c = reg[0];
-    const i64 start = reg[1];
-    const i64 shift = A.shifts ? (i64)A.shifts[k] : 0;
-    const i64 slot = A.geno_offset_idx ? A.geno_offset_idx[k] : 0;
-    u32 acc = 0;
-    if (c >= 0 && c < A.n_contigs) {
-        const i64 c_s = A.ref_offsets[c], c_e = A.ref_offsets[c + 1];
-        i64 lo = c_s + (start < 0 ? 0 : start) + (shift < 0 ? 0 : shift);
-        lo &= ~127ll;
-        const i64 hi = imin(imin(lo + A.span + 256, c_e), A.ref_len);
-        for (i64 a = lo + 128ll * t; a + 4 <= hi; a += 128ll * 32) acc ^= *reinterpret_cast<const u32 *>(A.ref + a);
-    }
-    if (t == 0 && A.srec && slot >= 0 && slot < A.n_geno_offsets) acc ^= *reinterpret_cast<const u32 *>(A.srec + slot * GVL_SLOT_RECS);
-    if (acc == 0x9E3779B9u && A.sink) *A.sink = acc;      // (keeps the loads; practically never taken)
-}
-
 struct PrepArgs {
     DiffArgs D;               // CSR + ilens / v_starts for the shift bound
     const i64 *idx; i64 batch; const int *full_regions; i64 n_regions; i64 n_samples; int ploidy;
@@ -3163,6 +3226,7 @@ int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
 //    64  ignore gvl_static.slot_rec (rows find their records through the CSR)
 //   128  no speculative reference reads in front of the plan
 //  1024  painter ignores the per-list bucket index (exact 64-ary searches per chunk)
+//  2048  length deltas (get_diffs_sparse, ragged sizing) always one wave per row
 // and 1 / 2 / 4 = timing ablations (no variants / no stores / no loads).
 int g_debug_override = -1;
 int debug_flags() {
@@ -3357,29 +3421,6 @@ int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_o
     return GVL_OK;
 }
 
-int gvl_prefetch(const gvl_static *st, const gvl_batch *bt, void *stream) {
-    if (!st || !bt) return fail(GVL_ERR_INVALID, "%s", "gvl_prefetch: NULL struct");
-    if (bt->batch <= 0 || bt->ploidy <= 0) return GVL_OK;
-    if (!st->ref || !st->ref_offsets || !bt->regions || bt->regions_stride < 3) return fail(GVL_ERR_INVALID, "%s", "gvl_prefetch: NULL array");
-    PrefetchArgs P;
-    memset(&P, 0, sizeof(P));
-    P.ref = st->ref; P.ref_len = st->ref_len; P.ref_offsets = (const i64 *)st->ref_offsets;
-    P.n_contigs = (int)(st->n_contigs > 0x7FFFFFFFll ? 0x7FFFFFFF : st->n_contigs);
-    P.srec = st->slot_rec; P.n_geno_offsets = st->n_geno_offsets;
-    P.regions = bt->regions; P.regions_stride = bt->regions_stride; P.shifts = bt->shifts;
-    P.geno_offset_idx = (const i64 *)bt->geno_offset_idx;
-    P.n_rows = bt->batch * bt->ploidy; P.ploidy = (int)bt->ploidy;
-    i64 span = bt->output_length >= 0 ? bt->output_length : bt->max_row_len;
-    if (span < 0) span = 0;
-    if (span > (1 << 20)) span = 1 << 20;             // very long rows: the head of the row is what the latency is about
-    P.span = span + 64;
-    P.sink = (u32 *)async_err_word();
-    const i64 grid = (P.n_rows * 32 + 255) / 256;
-    if (grid > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_prefetch: batch too large");
-    prefetch_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(P);
-    return check_launch("gvl_prefetch");
-}
-
 int gvl_get_reference(const gvl_static *st, const int32_t *regions, int64_t regions_stride,
                       int64_t n_rows, const int64_t *out_offsets, int64_t max_row_len,
                       const uint8_t *to_rc, uint8_t *out, uint8_t *onehot, void *stream) {
@@ -3408,6 +3449,12 @@ int gvl_get_reference(const gvl_static *st, const int32_t *regions, int64_t regi
     return check_launch("gvl_get_reference");
 }
 
+// rows with many variants (mean > 16 per genotype slot, or GVL_DBG=2048): one wave per row instead of one lane
+static bool diffs_long_rows(const gvl_static *st) {
+    if (debug_flags() & 2048) return true;
+    return st->n_geno_offsets > 0 && st->n_geno / st->n_geno_offsets > 16;
+}
+
 static int fill_diff_args(DiffArgs &D, const gvl_static *st, const gvl_batch *bt, const char *who) {
     if (!st || !bt) return fail(GVL_ERR_INVALID, "%s: NULL struct", who);
     if (bt->batch < 0 || bt->ploidy <= 0) return fail(GVL_ERR_INVALID, "%s: bad batch/ploidy", who);
@@ -3432,8 +3479,14 @@ int gvl_get_diffs_sparse(const gvl_static *st, const gvl_batch *bt, const int32_
     if (!diffs) return fail(GVL_ERR_INVALID, "%s", "gvl_get_diffs_sparse: NULL diffs");
     D.q_starts = q_starts; D.q_ends = q_ends; D.q_stride = q_stride > 0 ? q_stride : 1;
     D.diffs = diffs; D.output_length = 0; D.lengths = nullptr;
-    const unsigned grid = (unsigned)((D.n_rows + 255) / 256);
-    hipLaunchKernelGGL(diffs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, D, (const int *)nullptr, (i64)0);
+    if (diffs_long_rows(st)) {
+        const i64 grid = (D.n_rows * WAVE + 255) / 256;
+        if (grid > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_get_diffs_sparse: batch too large");
+        hipLaunchKernelGGL(diffs_wave_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, D, (const int *)nullptr, (i64)0);
+    } else {
+        const unsigned grid = (unsigned)((D.n_rows + 255) / 256);
+        hipLaunchKernelGGL(diffs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, D, (const int *)nullptr, (i64)0);
+    }
     return check_launch("gvl_get_diffs_sparse");
 }
 
@@ -3453,8 +3506,14 @@ int gvl_hap_offsets(const gvl_static *st, const gvl_batch *bt, int32_t *diffs, i
     if (!bt->regions || bt->regions_stride < 3) return fail(GVL_ERR_INVALID, "%s", "gvl_hap_offsets: NULL regions");
     D.q_starts = bt->regions + 1; D.q_ends = bt->regions + 2; D.q_stride = bt->regions_stride;
     D.diffs = diffs; D.output_length = bt->output_length; D.lengths = (i64 *)out_offsets;
-    const unsigned grid = (unsigned)((D.n_rows + 255) / 256);
-    hipLaunchKernelGGL(diffs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, D, bt->regions, (i64)bt->regions_stride);
+    if (diffs_long_rows(st)) {
+        const i64 grid = (D.n_rows * WAVE + 255) / 256;
+        if (grid > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_hap_offsets: batch too large");
+        hipLaunchKernelGGL(diffs_wave_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, D, bt->regions, (i64)bt->regions_stride);
+    } else {
+        const unsigned grid = (unsigned)((D.n_rows + 255) / 256);
+        hipLaunchKernelGGL(diffs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, D, bt->regions, (i64)bt->regions_stride);
+    }
     rc = check_launch("gvl_hap_offsets(diffs)");
     if (rc) return rc;
     hipLaunchKernelGGL(offsets_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (i64 *)out_offsets, D.n_rows, (i64 *)total_and_max);
@@ -3716,10 +3775,7 @@ int gvl_tracks_batch(const gvl_static *st, const gvl_batch *bt, const int64_t *o
     if (rc) return rc;
     D.keep = nullptr; D.keep_offsets = nullptr;
     {
-        i64 n = B > B * P + 1 ? B : B * P + 1;
-        i64 grid = (n + 255) / 256;
-        if (grid > 4096) grid = 4096;
-        if (grid < (B + 255) / 256) grid = (B + 255) / 256;
+        const i64 grid = (B * WAVE + 255) / 256;            // one wave per query (covers the K + 1 offsets too)
         track_lengths_kernel<<<dim3((unsigned)grid), dim3(256), 0, s>>>(D, bt->regions, (i64)bt->regions_stride, B, L, track_offsets, out_offsets);
         rc = check_launch("gvl_tracks_batch(lengths)");
         if (rc) return rc;

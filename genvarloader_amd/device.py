@@ -275,10 +275,6 @@ class HapsDevice:
         """One pass of the hot path over one batch: a single kernel launch."""
         _lib.check(self.lib.gvl_reconstruct(C.byref(self.c), C.byref(bt.c), C.byref(out_c), _stream_ptr(stream)))
 
-    def prefetch(self, bt: DeviceBatch, stream=None) -> None:
-        """``gvl_prefetch``: pull a coming batch's inputs into L2 / Infinity Cache (side stream)."""
-        _lib.check(self.lib.gvl_prefetch(C.byref(self.c), C.byref(bt.c), _stream_ptr(stream)))
-
     def pack_many(self, bts, out_cs):
         """C arrays for :meth:`launch_many` (build once, launch many times)."""
         n = len(bts)

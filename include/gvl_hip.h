@@ -184,20 +184,16 @@ int gvl_pack_slots(const gvl_static *st, gvl_srec *srec_out, void *stream);
 int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *out,
                     void *stream);
 
-/* The same for `n` batches (arrays of n structs) in as few launches as possible: batches that need
- * the same kernel instance (same set of outputs) share a launch, GVL_MANY_MAX at most.  Batches are
- * independent, so inside one launch the latency-bound head of a batch (parameter and record
- * gathers, plan) runs under the store-bound tail of the previous one -- what a prefetching loader
- * otherwise gets from keeping several batches in flight on separate streams.  Equivalent to n
- * calls of gvl_reconstruct on `stream`; outputs of different batches must not overlap. */
+/* The same for `n` <= GVL_MANY_MAX batches (arrays of n structs) in ONE host call: every batch is
+ * validated before the first launch, then the launches go back to back on `stream` -- what the
+ * native loader issues per group of batches (one event pair per group instead of per batch).
+ * Equivalent to n calls of gvl_reconstruct; outputs of different batches must not overlap.
+ * (One launch for all n batches, blockIdx.z = batch, was built and measured: the per-batch
+ * arguments then sit behind an index in the kernarg segment, which cost 1.2-1.8 us per batch, and
+ * the batches overlapped no better than launches on separate streams -- DESIGN.md 4.1.) */
 #define GVL_MANY_MAX 8
 int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_out *outs,
                          int32_t n, void *stream);
-
-/* Touch the inputs a later gvl_reconstruct of `bt` will gather (request entries, slot-major record
- * lines, reference windows) so that they are in L2 / Infinity Cache by then.  For a prefetching
- * loader, which knows its next batches; asynchronous on `stream` (use a side stream), reads only. */
-int gvl_prefetch(const gvl_static *st, const gvl_batch *bt, void *stream);
 
 /* Per-row length deltas.  Replaces get_diffs_sparse (src/ffi/mod.rs:143-185 ->
  * src/genotypes/mod.rs:15-125).  Query mode iff q_starts, q_ends and st->v_starts

@@ -41,7 +41,7 @@ def gpu():
 # (tests/parity/test_rayon_equivalence.py:31-62); here every reference vector goes down every
 # kernel path: gvl_set_debug_flags removes one way at a time.
 KERNEL_PATHS = {0: "default", 8: "scalar-walk", 64: "csr-inline-records", 80: "csr-vrec-gather", 32: "no-scan-free-plan",
-                128: "no-speculative-reads", 512: "per-wave-scans"}
+                128: "no-speculative-reads", 512: "per-wave-scans", 2048: "wave-per-row-diffs"}
 
 
 @pytest.fixture(params=sorted(KERNEL_PATHS), ids=[KERNEL_PATHS[k] for k in sorted(KERNEL_PATHS)])
@@ -316,7 +316,7 @@ def test_keep_mask(gpu, oracle):
 
 
 @pytest.mark.parametrize("seed", [21, 22])
-def test_ragged_mode(gpu, oracle, seed):
+def test_ragged_mode(gpu, oracle, seed, kpath):
     st, bt = _synth(seed, (60_000, 40_000), 100, 700, indel_frac=0.4, density=1 / 25, rc_frac=0.5,
                     edge_frac=0.1, output_length=-1)
     dev = make_dev(gpu, st, bt)

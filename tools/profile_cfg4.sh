@@ -1,9 +1,14 @@
 #!/bin/bash
-# rocprofv3 kernel stats for cfg4 (haplotypes + one realigned track) -> gpurun_out/<tag>_cfg4/
-TAG=${1:-r01}
-cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_cfg4
-mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/track_bench.py 0 > $OUT/run.log 2>&1
-tail -3 $OUT/run.log
-find $OUT -name "*kernel_stats.csv" | head -1 | xargs cat | head -8
+# rocprofv3 kernel stats of the cfg4 step (bench.py --workload cfg4) -> gpurun_out/<tag>/cfg4_prof
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/${1:-r02_cfg4}
+mkdir -p $O
+export TMPDIR=/tmp; cd /tmp
+for dbg in 0 1024; do
+GVL_DBG=$dbg rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg4_prof_d$dbg -- python3 $R/bench.py --workload cfg4 --steps 20 --warmup 3 > $O/cfg4_prof_d$dbg.log 2>&1
+echo "== GVL_DBG=$dbg"; python3 - $(find $O/cfg4_prof_d$dbg -name "*kernel_stats.csv" | head -1) <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if int(r["Calls"]) >= 20: print(r["Name"][:90].ljust(90), r["Calls"].rjust(6), ("%.2f" % (float(r["AverageNs"]) / 1000)).rjust(9), "us")
+PY
+done
