@@ -33,6 +33,7 @@ SYMBOLS = (
     "gvl_keep_offsets",
     "gvl_choose_exonic_variants",
     "gvl_rc_rows",
+    "gvl_rc_bounded_rows",
     "gvl_reverse_rows_4",
     "gvl_onehot",
     "gvl_intervals_prefix_max",

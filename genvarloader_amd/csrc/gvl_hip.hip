@@ -2404,6 +2404,22 @@ __global__ __launch_bounds__(256) void rc_rows_kernel(u8 *data, const i64 *offse
     }
 }
 
+// reverse.rs:75-84: rows given as (start, end) pairs instead of consecutive offsets
+__global__ __launch_bounds__(256) void rc_bounded_rows_kernel(u8 *data, const i64 *bounds, const u8 *to_rc, i64 n_rows) {
+    const i64 r = blockIdx.x;
+    if (r >= n_rows || !to_rc[r]) return;
+    const i64 b0 = bounds[2 * r], b1 = bounds[2 * r + 1];
+    if (b1 <= b0) return;
+    u8 *row = data + b0;
+    const i64 n = b1 - b0;
+    for (i64 i = threadIdx.x; i < (n + 1) / 2; i += blockDim.x) {
+        const i64 j = n - 1 - i;
+        const u32 a = row[i], b = row[j];
+        row[i] = (u8)comp_byte(b);
+        row[j] = (u8)comp_byte(a);
+    }
+}
+
 __global__ __launch_bounds__(256) void reverse_rows4_kernel(u32 *data, const i64 *offsets,
                                                              const u8 *to_rc, i64 n_rows) {
     const i64 r = blockIdx.x;
@@ -3563,6 +3579,15 @@ int gvl_rc_rows(uint8_t *data, const int64_t *offsets, const uint8_t *to_rc, int
     if (n_rows > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_rc_rows: too many rows");
     hipLaunchKernelGGL(rc_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, data, (const i64 *)offsets, to_rc, (i64)n_rows);
     return check_launch("gvl_rc_rows");
+}
+
+int gvl_rc_bounded_rows(uint8_t *data, const int64_t *bounds, const uint8_t *to_rc, int64_t n_rows, void *stream) {
+    if (n_rows < 0) return fail(GVL_ERR_INVALID, "%s", "gvl_rc_bounded_rows: n_rows < 0");
+    if (n_rows == 0) return GVL_OK;
+    if (!data || !bounds || !to_rc) return fail(GVL_ERR_INVALID, "%s", "gvl_rc_bounded_rows: NULL array");
+    if (n_rows > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_rc_bounded_rows: too many rows");
+    hipLaunchKernelGGL(rc_bounded_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, data, (const i64 *)bounds, to_rc, (i64)n_rows);
+    return check_launch("gvl_rc_bounded_rows");
 }
 
 int gvl_reverse_rows_4(void *data, const int64_t *offsets, const uint8_t *to_rc, int64_t n_rows, void *stream) {

@@ -351,6 +351,18 @@ def rc_flat_rows_inplace(data: torch.Tensor, offsets, to_rc) -> None:
         _lib.check(lib.gvl_rc_rows(_ptr(data), _ptr(oo), _ptr(rc), C.c_int64(rc.numel()), _stream_ptr()))
 
 
+def rc_bounded_rows_inplace(data: torch.Tensor, bounds, to_rc) -> None:
+    """rc_bounded_rows_inplace (reverse.rs:75-84): rows as (start, end) pairs, i64 (n, 2)."""
+    lib = _lib.load()
+    d = data.device
+    bd, rc = _dev(bounds, torch.int64, d), _dev(to_rc, torch.uint8, d)
+    assert data.dtype == torch.uint8 and data.is_contiguous() and bd.dim() == 2 and bd.shape[1] == 2
+    if data.numel() == 0 or rc.numel() == 0:
+        return
+    with torch.cuda.device(d):
+        _lib.check(lib.gvl_rc_bounded_rows(_ptr(data), _ptr(bd), _ptr(rc), C.c_int64(rc.numel()), _stream_ptr()))
+
+
 def reverse_flat_rows_inplace(data: torch.Tensor, offsets, to_rc) -> None:
     """reverse_flat_rows_inplace<T> (reverse.rs:25-38) for 4-byte elements."""
     lib = _lib.load()

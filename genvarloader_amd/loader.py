@@ -62,17 +62,28 @@ class Batch:
     shifts: torch.Tensor
     geno_offset_idx: torch.Tensor
     to_rc: torch.Tensor | None
+    out_offsets: torch.Tensor | None = None      # ragged mode: (b * P + 1,) i64; haps / onehot are then flat
+    annot_v_idxs: torch.Tensor | None = None     # annotate=True: i32, same shape as haps
+    annot_ref_pos: torch.Tensor | None = None
 
 
 class DeviceHapsDataset:
-    """(regions x samples) grid over a :class:`HapsDevice`, fixed output length.
+    """(regions x samples) grid over a :class:`HapsDevice`.
+
+    ``output_length >= 1``: fixed-length rows (crop / pad), the native batch loop.  ``output_length
+    = -1``: RAGGED rows like the reference's default output (``_haps.py:794-811``: row length = region
+    length + the haplotype's length delta): batches carry flat ``haps`` / ``onehot`` plus
+    ``out_offsets`` and come from the Python submit loop (one host read of the batch's total size
+    per batch, which the exactly-sized allocation forces).  ``annotate=True`` adds the variant-index /
+    reference-position annotations (``reconstruct_annotated_haplotypes_fused``), also through the
+    Python loop.
 
     ``dev``'s genotype offsets must be laid out like the reference's sparse genotypes: slot
     ``ravel_multi_index((region, sample, ploid), (R, S, P))`` (``_haps.py:757-768``)."""
 
     def __init__(self, dev, regions, n_samples: int, ploidy: int, *, output_length: int, jitter: int = 0,
                  rc_neg: bool = True, deterministic: bool = True, seed: int | None = None, onehot: bool = True,
-                 haps: bool = False, layout: str = "lc"):
+                 haps: bool = False, layout: str = "lc", annotate: bool = False):
         self.dev = dev
         d = dev.device
         reg = torch.as_tensor(np.ascontiguousarray(regions, np.int32)).to(d)
@@ -83,10 +94,15 @@ class DeviceHapsDataset:
         if int(dev.geno_offsets.shape[1]) < self.n_regions * self.n_samples * self.ploidy:
             raise ValueError("genotype offsets do not cover regions x samples x ploidy")
         self.output_length = int(output_length)
-        if self.output_length < 1:
-            raise ValueError("output_length must be >= 1 (fixed-length output)")
+        if self.output_length < 1 and self.output_length != -1:
+            raise ValueError("output_length must be >= 1 (fixed-length output) or -1 (ragged)")
+        self.ragged, self.annotate = self.output_length == -1, bool(annotate)
         self.jitter, self.rc_neg, self.deterministic = int(jitter), bool(rc_neg), bool(deterministic)
-        self.onehot, self.haps, self.layout = bool(onehot), bool(haps), layout
+        if self.ragged and not self.deterministic:
+            raise ValueError("random shifts crop a fixed-length window: ragged output is deterministic")
+        self.onehot, self.haps, self.layout = bool(onehot), bool(haps) or self.annotate, layout
+        if self.ragged and layout != "lc":
+            raise ValueError("channel-major one-hot needs fixed-length rows")
         self.seed = (0 if seed is None else int(seed)) & 0xFFFFFFFFFFFFFFFF
         self._counter = 0          # random draws are keyed by (seed, counter, dataset index): one tick per request
         self._loaders = 0          # ... and every loader gets its own derived seed, so a new loader does not replay
@@ -127,7 +143,7 @@ class DeviceHapsDataset:
             _lib.check(self.dev.lib.gvl_prepare_request(
                 C.byref(self.dev.c), _ptr(idx), C.c_int64(b), _ptr(self.full_regions), C.c_int64(self.n_regions),
                 C.c_int64(self.n_samples), C.c_int64(P), C.c_int64(self.jitter), C.c_int32(int(self.rc_neg)),
-                C.c_int32(int(self.deterministic)), C.c_int64(self.output_length), C.c_uint64(self.seed),
+                C.c_int32(int(self.deterministic)), C.c_int64(max(self.output_length, 0)), C.c_uint64(self.seed),
                 C.c_uint64(self._counter), _ptr(regions), _ptr(goi), _ptr(to_rc), _ptr(shifts), _stream_ptr()))
         return idx, regions, shifts, goi, (to_rc if self.rc_neg else None)
 
@@ -141,6 +157,25 @@ class DeviceHapsDataset:
         from ._lib import GvlBatch, GvlOut
 
         d = self.dev.device
+        if self.ragged or self.annotate:
+            # the general path: request prep, then HapsDevice.reconstruct (ragged: sizes on the device,
+            # one host read of {total, longest row} to allocate)
+            idx_d, regions, shifts, goi, to_rc = self.request(idx)
+            out = self.dev.reconstruct(regions, shifts, goi, self.output_length, to_rc=to_rc, haps=self.haps,
+                                       onehot=self.onehot, layout=self.layout, annotate=self.annotate)
+            b, P = int(idx_d.numel()), self.ploidy
+            hp, oh, av, ap = out.haps, out.onehot, out.annot_v_idxs, out.annot_ref_pos
+            if not self.ragged:
+                L = self.output_length
+                hp = None if hp is None else hp.view(b, P, L)
+                av = None if av is None else av.view(b, P, L)
+                ap = None if ap is None else ap.view(b, P, L)
+                if oh is not None:
+                    oh = oh.view(b, P, L, 4) if self.layout == "lc" else oh.view(b, P, 4, L)
+            batch = Batch(oh, hp, idx_d, regions, shifts, goi, to_rc, out.out_offsets, av, ap)
+            batch._arena = out.haps if out.haps is not None else out.onehot      # (record_stream target)
+            batch._keep = out
+            return batch
         idx = torch.as_tensor(np.asarray(idx) if not isinstance(idx, torch.Tensor) else idx)
         idx = idx.to(device=d, dtype=torch.int64).reshape(-1).contiguous()
         b, P, L = int(idx.numel()), self.ploidy, self.output_length
@@ -199,7 +234,7 @@ class DeviceHapsDataset:
         groups are submitted ahead.  ``threaded=True``: a producer thread inside the library
         submits them (launches overlap the consumer's own host work per batch)."""
         return DeviceLoader(self, batch_size, shuffle, sampler, drop_last, generator, in_flight, rank, world_size,
-                            seed, threaded, group)
+                            seed, threaded, group, python_loop=self.ragged or self.annotate)
 
 
 @dataclass
@@ -222,6 +257,8 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
     def __init__(self, dev, regions, n_samples, ploidy, *, tracks: dict, strategy_id: int = 0, param: float = 0.0,
                  base_seed: int | None = None, **kw):
         super().__init__(dev, regions, n_samples, ploidy, **kw)
+        if self.ragged or self.annotate:
+            raise ValueError("DeviceHapsTracksDataset: fixed-length rows, no annotations")
         from . import device as _device
 
         d = dev.device

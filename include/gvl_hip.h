@@ -240,6 +240,11 @@ int gvl_choose_exonic_variants(const gvl_static *st, const int32_t *starts, cons
 int gvl_rc_rows(uint8_t *data, const int64_t *offsets, const uint8_t *to_rc,
                 int64_t n_rows, void *stream);
 
+/* The same for rows given as (start, end) pairs, bounds i64 (n_rows, 2) -- rows need not be
+ * adjacent.  Replaces rc_bounded_rows_inplace (src/reverse.rs:75-84). */
+int gvl_rc_bounded_rows(uint8_t *data, const int64_t *bounds, const uint8_t *to_rc,
+                        int64_t n_rows, void *stream);
+
 /* In-place reversal (no complement) of masked rows of 4-byte elements (f32
  * tracks / i32 annotations).  Replaces reverse_flat_rows_inplace<T>
  * (src/reverse.rs:25-38). */

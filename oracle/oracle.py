@@ -284,6 +284,13 @@ def rc_flat_rows_inplace(data, offsets, to_rc):
     lib().gvlo_rc_rows(_p(data), _p(oo), _p(rc), C.c_int64(len(rc)))
 
 
+def rc_bounded_rows_inplace(data, bounds, to_rc):
+    """reverse.rs:75-84: rows as (start, end) pairs."""
+    assert data.dtype == np.uint8 and data.flags.c_contiguous
+    bd, rc = _c(bounds, np.int64), _c(to_rc, np.bool_)
+    lib().gvlo_rc_bounded_rows(_p(data), _p(bd), _p(rc), C.c_int64(len(rc)))
+
+
 def reverse_flat_rows_inplace(data, offsets, to_rc):
     """reverse.rs:25-38 for 4-byte elements (f32 / i32)."""
     assert data.dtype.itemsize == 4 and data.flags.c_contiguous

@@ -675,3 +675,24 @@ def test_ffi_cache_sees_in_place_edits(gpu, oracle):
     exp, _ = oracle.reconstruct_haplotypes_fused(*args(), None, None, None, False)
     np.testing.assert_array_equal(b, exp)
     assert not np.array_equal(a, b)
+
+
+def test_rc_bounded_rows(gpu, oracle):
+    """rc_bounded_rows_inplace (reverse.rs:75-84): rows as (start, end) pairs with gaps between them,
+    empty rows and masked rows; the Rust test's vector (reverse.rs:165-178) and a random case vs the oracle."""
+    t = gpu.torch.from_numpy(S("ACGT--AACC").copy()).cuda()           # the Rust test's vector
+    gpu.device.rc_bounded_rows_inplace(t, np.array([[6, 10], [0, 4]], np.int64), [True, False])
+    assert t.cpu().numpy().tobytes() == b"ACGT--GGTT"
+    rng = np.random.default_rng(3)
+    n = 400
+    lens = rng.integers(0, 700, n)
+    gaps = rng.integers(0, 9, n)
+    starts = np.cumsum(lens + gaps) - lens
+    bounds = np.stack([starts, starts + lens], 1).astype(np.int64)
+    data = np.frombuffer(b"ACGTNacgtRY", np.uint8)[rng.integers(0, 11, int(bounds[-1, 1]) + 5)].copy()
+    mask = rng.random(n) < 0.5
+    exp = data.copy()
+    oracle.rc_bounded_rows_inplace(exp, bounds, mask)
+    t = gpu.torch.from_numpy(data.copy()).cuda()
+    gpu.device.rc_bounded_rows_inplace(t, bounds, mask)
+    np.testing.assert_array_equal(t.cpu().numpy(), exp)

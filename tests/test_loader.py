@@ -431,3 +431,54 @@ def test_tracks_batch_long_rows_jitter_and_dense_lists(oracle, dbg):
             np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32))
     finally:
         _lib.load().gvl_set_debug_flags(-1)
+
+
+@pytest.mark.gpu
+def test_loader_ragged_and_annotated_modes(oracle):
+    """The reference loader's other haplotype outputs from dataset indices: ragged rows (its default,
+    _haps.py:794-811) and annotated haplotypes (ffi/mod.rs:2237-2397), through the Python submit loop;
+    sharded across two ranks like the native loop."""
+    from genvarloader_amd import HapsDevice
+    from genvarloader_amd.loader import DeviceHapsDataset
+
+    R, S, P, L = 5, 7, 2, 400
+    st, full_regions, go, gv = _grid_dataset(21, R, S, P, L, indel_frac=0.5)
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+
+    def request(idx):
+        r_idx, s_idx = np.unravel_index(idx, (R, S))
+        regions = full_regions[r_idx]
+        goi = np.ravel_multi_index((r_idx[:, None], s_idx[:, None], np.arange(P)), (R, S, P))
+        return regions, goi, np.repeat(regions[:, 3] == -1, P), np.zeros_like(goi, dtype=np.int32)
+
+    ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=-1, onehot=True, haps=True)
+    seen, lens = [], []
+    for rank in range(2):
+        for batch in ds.to_dataloader(batch_size=6, shuffle=True, seed=4, rank=rank, world_size=2, drop_last=False):
+            idx = batch.idx.cpu().numpy()
+            regions, goi, to_rc, shifts = request(idx)
+            exp, exp_off, exp_oh = oracle.reconstruct_haplotypes_fused(
+                regions, shifts, goi, go, gv, st.v_starts, st.ilens, st.alt_alleles, st.alt_offsets, st.ref,
+                st.ref_offsets, st.pad_char, -1, None, None, to_rc, False, onehot=True)
+            np.testing.assert_array_equal(batch.out_offsets.cpu().numpy(), exp_off)
+            np.testing.assert_array_equal(batch.haps.cpu().numpy(), exp)
+            np.testing.assert_array_equal(batch.onehot.cpu().numpy(), exp_oh)
+            seen.extend(idx.tolist()); lens.extend(np.diff(exp_off).tolist())
+    assert sorted(set(seen)) == list(range(R * S)) and len(set(lens)) > 5          # every index, genuinely ragged
+
+    ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, onehot=False, annotate=True)
+    n = 0
+    for batch in ds.to_dataloader(batch_size=9, shuffle=False):
+        idx = batch.idx.cpu().numpy()
+        regions, goi, to_rc, shifts = request(idx)
+        exp, av, ap, _ = oracle.reconstruct_annotated_haplotypes_fused(
+            regions, shifts, goi, go, gv, st.v_starts, st.ilens, st.alt_alleles, st.alt_offsets, st.ref,
+            st.ref_offsets, st.pad_char, L, None, None, to_rc, False)
+        assert batch.haps.shape == (len(idx), P, L)
+        np.testing.assert_array_equal(batch.haps.cpu().numpy().ravel(), exp)
+        np.testing.assert_array_equal(batch.annot_v_idxs.cpu().numpy().ravel(), av)
+        np.testing.assert_array_equal(batch.annot_ref_pos.cpu().numpy().ravel(), ap)
+        n += len(idx)
+    assert n == R * S
