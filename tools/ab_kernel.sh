@@ -1,6 +1,11 @@
 #!/bin/bash
+# tools/ab_kernel.sh <tag> [dbg sets, default "0 64 128 192"]: same-box A/B of the reconstruct kernel --
+#  the round-1 tree (exported once with `git archive <round-1 commit> | tar -x -C tools/ab_r01`, built in place)
+#  next to the current one: GPU suite, per-phase stamps (tools/stamps.py, needs tools/libgvl_hip_diag.so
+#  built with -DGVL_DIAG), and bench.py hot / cold under each GVL_DBG set, twice.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/${1:-r02g}
+O=$R/gpurun_out/${1:-ab}
+SETS=${2:-"0 64 128 192"}
 mkdir -p $O
 cd $R
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -5 $O/pytest.log
@@ -10,7 +15,7 @@ run() { local name=$1; local dbg=$2; shift 2
   GVL_DBG=$dbg timeout 600 python bench.py --no-cpu-baseline --no-hot "$@" > $O/bench_$name.json 2> $O/bench_$name.err || echo "bench $name failed"; }
 for rep in 1 2; do
 (cd tools/ab_r01 && timeout 300 python bench.py --steps 300 --streams 4 --no-cpu-baseline > $O/r01_bench_$rep.json 2> $O/r01_bench_$rep.err)
-for dbg in 0 64 128 192; do
+for dbg in $SETS; do
 run hot_d${dbg}_$rep $dbg --steps 200 --scale small --rotate 1
 run cold_d${dbg}_$rep $dbg --steps 200
 done; done
