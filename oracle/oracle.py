@@ -46,7 +46,7 @@ def build(march: str | None = None, force: bool = False) -> Path:
 def lib() -> C.CDLL:
     global _LIB
     if _LIB is None:
-        so = _HERE / "libgvl_oracle.so"
+        so = Path(os.environ["GVL_ORACLE_LIB"]) if os.environ.get("GVL_ORACLE_LIB") else _HERE / "libgvl_oracle.so"
         if not so.exists():
             build()
         _LIB = C.CDLL(str(so))
