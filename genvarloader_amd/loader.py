@@ -316,7 +316,7 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
         b, P, L = int(base.idx.numel()), self.ploidy, self.output_length
         if b == 0 or not self._itv:
             return TrackBatch(base.onehot, base.haps, base.idx, base.regions, base.shifts, base.geno_offset_idx,
-                              base.to_rc, None)
+                              base.to_rc, tracks=None)
         K, T = b * P, len(self._itv)
         # ONE native call for the track half (gvl_tracks_batch): scratch-track lengths, then paint +
         # realign per track; output and scratch share one arena, no torch op per batch
@@ -337,7 +337,7 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
                 C.c_void_p(torch.cuda.current_stream(d).cuda_stream)))
         tracks = arena[:4 * T * K * L].view(torch.float32).view(T, b, P, L).permute(1, 0, 2, 3)
         out = TrackBatch(base.onehot, base.haps, base.idx, base.regions, base.shifts, base.geno_offset_idx, base.to_rc,
-                         tracks)
+                         tracks=tracks)
         out._arena = base._arena
         out.base_seed = seed
         out._keep = (arena,)
