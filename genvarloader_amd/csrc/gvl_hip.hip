@@ -95,6 +95,9 @@ __device__ __forceinline__ void store_u32_unaligned(u8 *dst, u32 v) {
 }
 struct __attribute__((aligned(4))) i32x4_a4 { int x, y, z, w; };
 
+// workgroup barrier that orders LDS traffic only: global loads a wave has in flight stay in flight
+// (__syncthreads' fence waits for vmcnt(0) on gfx9)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ i64 rfl64(i64 x) {
     u32 lo = (u32)rfl((int)(u32)(u64)x);
@@ -1002,6 +1005,11 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     // needs a global read before its plan, so the reference bytes it requests next (below) stay in
     // flight behind nothing.
     const bool use_srec = A.srec != nullptr && !A.ref_only && planned_ok && !(A.dbg & 512) && !ANNOT;
+    // wave 0's carry from P1a to P1b (the slot-line read stays in flight across the first barrier)
+    i32x4 p1_rec = {0, 0, (int)GVL_SREC_EMPTY, 0};
+    i64 p1_oidx = 0;
+    int p1_fl = 1;
+    bool p1_want = false;
     if (tid < WAVE) {
         // Every load of a level is issued before anything waits (no branch in between: an absent
         // array is replaced by a pointer that is always readable, and a lane without a row reads
@@ -1043,8 +1051,9 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             A.out_offsets_w[k] = ri.row_base;
             if (k == A.n_rows - 1) A.out_offsets_w[k + 1] = ri.row_base + ri.L;
         }
-        // ---- level 2: contig bounds, CSR bounds (rows that do not use the slot-major records), and the
-        // rows' slot-major records, lane (r, j) = entry j of row r's slot
+        // ---- level 2: contig bounds (L2 resident), CSR bounds (rows that do not use the slot-major
+        // records), and LAST the rows' slot-major records, lane (r, j) = entry j of row r's slot: the
+        // first two are waited for here, the slot lines stay in flight across the first barrier (P1b)
         const i64 c_idx = (l_c >= 0 && l_c < A.n_contigs) ? (i64)l_c : 0;       // (out of contract otherwise: clamp)
         const bool csr = !A.ref_only && !(fl & 17);
         const i64 o_safe = (csr && o_idx >= 0 && o_idx < A.n_geno_offsets) ? o_idx : 0;
@@ -1056,25 +1065,15 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             const int fl_r = bperm(r, fl);
             const u32 o_lo = (u32)bperm(r, (int)(u32)(u64)o_idx), o_hi = (u32)bperm(r, (int)(u32)((u64)o_idx >> 32));
             const i64 o_r = (i64)(((u64)o_hi << 32) | o_lo);
-            const bool want = (fl_r & 17) == 16 && o_r >= 0 && o_r < A.n_geno_offsets;
-            i32x4 rec = *reinterpret_cast<const i32x4 *>(A.srec + ((want ? o_r : 0) * GVL_SLOT_RECS + (lane & 7)));
-            if (!want) { rec.x = 0; rec.y = 0; rec.z = (int)GVL_SREC_EMPTY; rec.w = 0; }
-            lrec[lane] = rec;
-            // a slot with more than 8 variants: that row goes through the CSR (third level; rare)
-            const u64 ovf = __builtin_amdgcn_ballot_w64(want && (lane & 7) == 0 && (u32)rec.z == GVL_SREC_OVERFLOW);
-            if (ovf && tid < WG_WAVES && ((ovf >> (8 * tid)) & 1ull)) {
-                fl &= ~16;
-                ri.o_s = A.go_starts[o_idx];
-                const i64 nv = A.go_stops[o_idx] - ri.o_s;
-                ri.n_var = nv < 0 ? 0 : (nv > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)nv);
-            }
+            p1_want = (fl_r & 17) == 16 && o_r >= 0 && o_r < A.n_geno_offsets;
+            p1_rec = *reinterpret_cast<const i32x4 *>(A.srec + ((p1_want ? o_r : 0) * GVL_SLOT_RECS + (lane & 7)));
         }
         if (fl != 1) {
             ri.c_s = l_cs;
             ri.R = l_ce - l_cs;
             if (fl & 16) {
                 // the variant count is known once the line is read (a slot with more than 8 falls
-                // back to the CSR)
+                // back to the CSR: P1b)
                 ri.o_s = o_idx;
                 ri.n_var = GVL_SLOT_RECS;
             } else if (csr) {
@@ -1086,6 +1085,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             if (!(fl & 2) && ri.n_var <= 8 && !(A.dbg & 512)) fl |= 8;           // packable: planned with the other rows
         }
         ri.flags = fl;
+        p1_fl = fl; p1_oidx = o_idx;
         if (tid < WG_WAVES) {
             rin[tid] = ri;
             RowMeta m0; m0.nseg = m0.npatch = m0.bad = m0.slow = m0.ready = m0.pad0_ = m0.pad1_ = m0.pad2_ = 0;
@@ -1093,7 +1093,12 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         }
     }
     GVL_STAMP(1);
-    __syncthreads();
+    lds_barrier();      // (not __syncthreads: its fence would wait for wave 0's slot-line read)
+    // Every wave "uses" the slot-line registers here: a no-op for waves 1..7 (they have nothing in flight),
+    // wave 0 needs the line next anyway.  Without it the compiler's wait-count model carries "a load into
+    // these registers may be pending" past the reference reads below and, as soon as a register is reused,
+    // waits for ALL of them (vmcnt(0) right after the second barrier).
+    asm volatile("" :: "v"(p1_rec.x), "v"(p1_rec.y), "v"(p1_rec.z), "v"(p1_rec.w));
 
     GVL_STAMP(2);
     const RowIn &ri = rin[wave];
@@ -1148,9 +1153,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     // slot-major records of this row: parked in LDS by wave 0 (no global read, no vmcnt wait).  Then the
     // speculative reference reads: on the slot-major path nothing between here and pass A waits for a
     // global load, so they stay in flight while the row is classified and planned.
-    const bool ell = (flags & 16) != 0 && packable;
-    i32x4 srec_v = {0, 0, 0, 0};
-    if (ell) srec_v = lrec[wave * GVL_SLOT_RECS + (lane & (GVL_SLOT_RECS - 1))];
+    bool ell = (flags & 16) != 0 && packable;        // (tentative until P1b has seen the slot line)
     const bool sp_on = g_ok && !(flags & 4) && !(A.dbg & (4 | 128)) && (ell || row_n_var == 0);
     // lane u decides for trip u (full trips only), one ballot; the loads then differ by an immediate
     // offset only.  (The scalar unit is shared by the waves of a CU: per-trip scalar arithmetic in the
@@ -1164,11 +1167,17 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         spmask = (u32)__builtin_amdgcn_ballot_w64(inside);
     }
     u32 wq[CHUNK_TRIPS];
+    auto issue_spec = [&]() {
 #pragma unroll
-    for (int u = 0; u < CHUNK_TRIPS; ++u) {
-        wq[u] = 0;
-        if ((spmask >> u) & 1u) wq[u] = load_u32_unaligned(sp_base + u * TRIP);
-    }
+        for (int u = 0; u < CHUNK_TRIPS; ++u) {
+            wq[u] = 0;
+            if ((spmask >> u) & 1u) wq[u] = load_u32_unaligned(sp_base + u * TRIP);
+        }
+    };
+    // waves 1..7 request their reference bytes NOW, under wave 0's slot-line read; wave 0 first parks the
+    // slot lines (its own reads would otherwise sit in front of them: loads return in order)
+    const bool spec_late = use_srec && wave == 0;
+    if (!spec_late) issue_spec();
 
     // Who plans a row: see below (SNP-only rows plan themselves, the first wave that holds a row with
     // an indel plans all such rows of the workgroup).  Measured and dropped in round 2: wave 0 planning
@@ -1176,6 +1185,33 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     // reads in flight -- a third of the issue slots, but the packed plan is a 3.6 us chain of dependent
     // instructions when one wave runs it alone, and every row then waits for it (cfg3 14.5 vs 12.8 us,
     // cfg2 14.0 vs 12.0 us per launch on the same box).
+    // ---- P1b (wave 0): the slot lines have arrived by now (they were requested before the reference
+    // reads above, and loads return in order): park them in LDS; a slot with more than 8 variants sends
+    // its row through the CSR (third level; rare).  Second LDS-only barrier.
+    if (use_srec && tid < WAVE) {
+        i32x4 rec = p1_rec;
+        if (!p1_want) { rec.x = 0; rec.y = 0; rec.z = (int)GVL_SREC_EMPTY; rec.w = 0; }
+        lrec[lane] = rec;
+        const u64 ovf = __builtin_amdgcn_ballot_w64(p1_want && (lane & 7) == 0 && (u32)rec.z == GVL_SREC_OVERFLOW);
+        if (ovf && tid < WG_WAVES && ((ovf >> (8 * tid)) & 1ull)) {
+            const i64 gs = A.go_starts[p1_oidx];
+            const i64 nv = A.go_stops[p1_oidx] - gs;
+            rin[tid].o_s = gs;
+            rin[tid].n_var = nv < 0 ? 0 : (nv > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)nv);
+            rin[tid].flags = p1_fl & ~(8 | 16);          // more than 8 variants: not packable, per-wave scans
+        }
+    }
+    if (use_srec) {
+        lds_barrier();
+        flags = rfl(ri.flags);
+        packable = (flags & 11) == 8;
+        row_n_var = rfl(ri.n_var);
+        row_o_s = rfl64(ri.o_s);
+        ell = (flags & 16) != 0 && packable;
+    }
+    if (spec_late) issue_spec();
+    i32x4 srec_v = {0, 0, 0, 0};
+    if (ell) srec_v = lrec[wave * GVL_SLOT_RECS + (lane & (GVL_SLOT_RECS - 1))];
     int f_pos = 0, f_inl = 0, f_vi = 0;
     bool f_valid = false, is_fast = false;
     if (packable) {
@@ -1183,15 +1219,6 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         bool rec_valid;
         if (ell) {
             const u32 e = (u32)srec_v.z;
-            if ((u32)rdl((int)e, 0) == GVL_SREC_OVERFLOW) {
-                // more than 8 variants: this row is read through the CSR by the per-wave scans
-                packable = false;
-                flags &= ~(8 | 16);
-                const i64 o_idx = row_o_s;
-                row_o_s = rfl64(A.go_starts[o_idx]);
-                const i64 nv = rfl64(A.go_stops[o_idx]) - row_o_s;
-                row_n_var = nv < 0 ? 0 : (nv > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)nv);
-            }
             rec_valid = lane < GVL_SLOT_RECS && e != GVL_SREC_EMPTY;
             f_pos = srec_v.x; d = srec_v.y; alen = (int)(e >> 8); f_inl = (int)(e & 0xFF); f_vi = 0;
         } else {
