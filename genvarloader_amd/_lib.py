@@ -22,6 +22,8 @@ SYMBOLS = (
     "gvl_set_debug_flags",
     "gvl_last_error",
     "gvl_async_error",
+    "gvl_static_upload",
+    "gvl_static_free",
     "gvl_pack_variants",
     "gvl_pack_genotypes",
     "gvl_pack_slots",

@@ -3355,6 +3355,69 @@ int gvl_pack_genotypes(const gvl_static *st, gvl_grec *grec_out, void *stream) {
     return check_launch("gvl_pack_genotypes");
 }
 
+// ---- per-dataset arrays for callers without a device allocator of their own -----------------------
+struct StaticOwner { gvl_static st; void *bufs[16]; int n; };
+
+static void *dev_copy(StaticOwner *o, const void *host, size_t bytes, hipStream_t s, bool *ok) {
+    void *d = nullptr;
+    if (!*ok) return nullptr;
+    if (hipMalloc(&d, bytes ? bytes : 16) != hipSuccess) { (void)hipGetLastError(); *ok = false; return nullptr; }
+    o->bufs[o->n++] = d;
+    if (bytes && host && hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s) != hipSuccess) { (void)hipGetLastError(); *ok = false; }
+    return d;
+}
+
+int gvl_static_upload(const gvl_static *host, int32_t with_layouts, gvl_static **out, void *stream) {
+    if (!host || !out) return fail(GVL_ERR_INVALID, "%s", "gvl_static_upload: NULL argument");
+    if (host->ref_len < 0 || host->n_contigs < 0 || host->n_variants < 0 || host->alt_len < 0 || host->n_geno_offsets < 0 || host->n_geno < 0)
+        return fail(GVL_ERR_INVALID, "%s", "gvl_static_upload: negative size");
+    if (!host->ref_offsets || !host->geno_o_starts || !host->geno_o_stops || (host->ref_len > 0 && !host->ref) ||
+        (host->n_variants > 0 && (!host->v_starts || !host->ilens || !host->alt_offsets)) || (host->n_geno > 0 && !host->geno_v_idxs))
+        return fail(GVL_ERR_INVALID, "%s", "gvl_static_upload: NULL host array");
+    StaticOwner *o = new (std::nothrow) StaticOwner;
+    if (!o) return fail(GVL_ERR_HIP, "%s", "gvl_static_upload: out of host memory");
+    memset(o, 0, sizeof(*o));
+    hipStream_t s = (hipStream_t)stream;
+    bool ok = true;
+    gvl_static &d = o->st;
+    d = *host;
+    const i64 nv = host->n_variants, ng = host->n_geno, no = host->n_geno_offsets;
+    d.ref = (const uint8_t *)dev_copy(o, host->ref, (size_t)host->ref_len, s, &ok);
+    d.ref_offsets = (const int64_t *)dev_copy(o, host->ref_offsets, (size_t)(host->n_contigs + 1) * 8, s, &ok);
+    d.v_starts = (const int32_t *)dev_copy(o, host->v_starts, (size_t)nv * 4, s, &ok);
+    d.ilens = (const int32_t *)dev_copy(o, host->ilens, (size_t)nv * 4, s, &ok);
+    d.alt_offsets = (const int64_t *)dev_copy(o, host->alt_offsets, (size_t)(nv + 1) * 8, s, &ok);
+    d.alt_alleles = (const uint8_t *)dev_copy(o, host->alt_alleles, (size_t)host->alt_len, s, &ok);
+    d.geno_o_starts = (const int64_t *)dev_copy(o, host->geno_o_starts, (size_t)no * 8, s, &ok);
+    d.geno_o_stops = (const int64_t *)dev_copy(o, host->geno_o_stops, (size_t)no * 8, s, &ok);
+    d.geno_v_idxs = (const int32_t *)dev_copy(o, host->geno_v_idxs, (size_t)ng * 4, s, &ok);
+    d.vrec = (const gvl_vrec *)dev_copy(o, nullptr, (size_t)(nv > 0 ? nv : 1) * sizeof(gvl_vrec), s, &ok);
+    d.geno_rec = nullptr; d.slot_rec = nullptr;
+    int rc = ok ? GVL_OK : fail(GVL_ERR_HIP, "%s", "gvl_static_upload: device allocation / copy failed");
+    if (!rc && nv > 0) rc = gvl_pack_variants(d.v_starts, d.ilens, d.alt_offsets, d.alt_alleles, nv, (gvl_vrec *)d.vrec, stream);
+    if (!rc && with_layouts && ng > 0 && nv > 0) {
+        gvl_grec *g = (gvl_grec *)dev_copy(o, nullptr, (size_t)ng * sizeof(gvl_grec), s, &ok);
+        if (ok) { rc = gvl_pack_genotypes(&d, g, stream); if (!rc) d.geno_rec = g; }
+    }
+    if (!rc && ok && with_layouts && no > 0 && nv > 0 && host->alt_len < (1ll << 32)) {
+        gvl_srec *sr = (gvl_srec *)dev_copy(o, nullptr, (size_t)no * GVL_SLOT_RECS * sizeof(gvl_srec), s, &ok);
+        if (ok) { rc = gvl_pack_slots(&d, sr, stream); if (!rc) d.slot_rec = sr; }
+    }
+    if (!rc && !ok) rc = fail(GVL_ERR_HIP, "%s", "gvl_static_upload: device allocation failed");
+    if (rc) { gvl_static_free(&o->st); return rc; }
+    *out = &o->st;
+    return GVL_OK;
+}
+
+int gvl_static_free(gvl_static *st) {
+    if (!st) return GVL_OK;
+    StaticOwner *o = reinterpret_cast<StaticOwner *>(st);       // `st` is the first member
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < o->n; ++i) (void)hipFree(o->bufs[i]);
+    delete o;
+    return GVL_OK;
+}
+
 int gvl_pack_slots(const gvl_static *st, gvl_srec *srec_out, void *stream) {
     if (!st || st->n_geno_offsets < 0 || st->n_variants < 0) return fail(GVL_ERR_INVALID, "%s", "gvl_pack_slots: bad arguments");
     if (st->n_geno_offsets == 0) return GVL_OK;

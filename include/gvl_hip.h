@@ -157,6 +157,15 @@ const char *gvl_last_error(void);
  * src/ffi/mod.rs:17-35, so this must not pass silently).  clear != 0 resets the flag. */
 int gvl_async_error(int clear);
 
+/* For callers without a device allocator of their own (a C / Rust host; torch callers keep their
+ * tensors and fill a gvl_static themselves): copy a dataset's arrays from HOST pointers into freshly
+ * hipMalloc'd memory, build vrec and -- with_layouts != 0 -- the optional geno_rec / slot_rec layouts,
+ * and return a gvl_static that points at the device copies ("gvl_static_upload/free").
+ * `host` uses the same struct with host pointers (vrec / geno_rec / slot_rec ignored).  The copies are
+ * asynchronous on `stream` from pageable or pinned memory.  gvl_static_free releases everything. */
+int gvl_static_upload(const gvl_static *host, int32_t with_layouts, gvl_static **out, void *stream);
+int gvl_static_free(gvl_static *st);
+
 /* Build the packed variant records (once per dataset).
  * Replaces nothing in the reference; it is the HBM layout this path reads
  * instead of the four gathers at src/reconstruct/mod.rs:296-305. */

@@ -696,3 +696,43 @@ def test_rc_bounded_rows(gpu, oracle):
     t = gpu.torch.from_numpy(data.copy()).cuda()
     gpu.device.rc_bounded_rows_inplace(t, bounds, mask)
     np.testing.assert_array_equal(t.cpu().numpy(), exp)
+
+
+def test_static_upload_for_hosts_without_an_allocator(gpu, oracle):
+    """gvl_static_upload / gvl_static_free: the per-dataset arrays go to HBM from HOST pointers inside the
+    library (what a C / Rust caller without torch uses); a reconstruct through that gvl_static == oracle."""
+    import ctypes as C
+
+    from genvarloader_amd import _lib
+    from genvarloader_amd._lib import GvlBatch, GvlOut, GvlStatic
+
+    lib = _lib.load()
+    st, bt = _synth(61, (90_000, 40_000), 300, 800, indel_frac=0.3, rc_frac=0.5, random_shifts=True)
+    go = np.ascontiguousarray(bt.geno_offsets)
+    keep = [np.ascontiguousarray(a) for a in (st.ref, st.ref_offsets, st.v_starts, st.ilens, st.alt_offsets, st.alt_alleles,
+                                              go[0], go[1], bt.geno_v_idxs)]
+    ptr = lambda a: a.ctypes.data
+    host = GvlStatic(ref=ptr(keep[0]), ref_len=keep[0].size, ref_offsets=ptr(keep[1]), n_contigs=keep[1].size - 1,
+                     v_starts=ptr(keep[2]), ilens=ptr(keep[3]), alt_offsets=ptr(keep[4]), alt_alleles=ptr(keep[5]),
+                     n_variants=keep[2].size, alt_len=keep[5].size, vrec=None, geno_o_starts=ptr(keep[6]),
+                     geno_o_stops=ptr(keep[7]), n_geno_offsets=keep[6].size, geno_v_idxs=ptr(keep[8]), n_geno=keep[8].size,
+                     pad_char=st.pad_char, geno_rec=None, slot_rec=None)
+    exp, _, exp_oh = oracle_fused(oracle, st, bt, onehot=True)
+    t = gpu.torch
+    for with_layouts in (1, 0):
+        dst = C.POINTER(GvlStatic)()
+        _lib.check(lib.gvl_static_upload(C.byref(host), C.c_int32(with_layouts), C.byref(dst), None))
+        assert bool(dst.contents.slot_rec) == bool(with_layouts) and bool(dst.contents.vrec)
+        reg, sh = t.from_numpy(bt.regions).cuda(), t.from_numpy(bt.shifts).cuda()
+        goi, rc = t.from_numpy(bt.geno_offset_idx).cuda(), t.from_numpy(bt.to_rc.astype(np.uint8)).cuda()
+        K, L = bt.n_windows, bt.output_length
+        haps = t.empty(K * L, dtype=t.uint8, device="cuda")
+        oh = t.empty((K * L, 4), dtype=t.uint8, device="cuda")
+        b = GvlBatch(regions=reg.data_ptr(), regions_stride=4, shifts=sh.data_ptr(), geno_offset_idx=goi.data_ptr(),
+                     batch=reg.shape[0], ploidy=2, to_rc=rc.data_ptr(), output_length=L, max_row_len=L)
+        o = GvlOut(haps=haps.data_ptr(), onehot=oh.data_ptr(), onehot_layout=0)
+        _lib.check(lib.gvl_reconstruct(dst, C.byref(b), C.byref(o), C.c_void_p(t.cuda.current_stream().cuda_stream)))
+        t.cuda.synchronize()
+        np.testing.assert_array_equal(haps.cpu().numpy(), exp)
+        np.testing.assert_array_equal(oh.cpu().numpy(), exp_oh)
+        _lib.check(lib.gvl_static_free(dst))
