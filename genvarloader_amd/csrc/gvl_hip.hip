@@ -2890,12 +2890,83 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A) 
 // interval (in order) that covers the position -- what sequential painting leaves behind.
 // `pmax[c]` = max(ends[list start .. c]): a position no earlier interval reaches is 0.0 without
 // walking back over the whole list (gaps between intervals are the common case).
+constexpr int PAINT_TILE = 256;
+constexpr int PAINT_CHUNK = 2048;
+struct PaintTile { u32 idx[2 * WAVE]; float cv[PAINT_TILE]; int ce[PAINT_TILE]; };     // start bitmap + prefix, candidate values / ends
+struct PaintImage { u32 idx[PAINT_CHUNK]; float cv[PAINT_TILE]; };                      // the leftovers kernel's image of one chunk
+struct PaintTodo { int flag; int n_c; i64 lo_c; };      // per (query, chunk): 0 = done, 1 = per-value kernel, 2 = image (candidates [lo_c, lo_c + n_c))
+
+// "Later intervals overwrite earlier ones" = every position takes the candidate with the HIGHEST index
+// that covers it: one wave paints candidate indices into an LDS image of the chunk with ds_max (order-free;
+// lane = interval for short ones, the whole wave for a long one) and streams the image out through the
+// candidates' values.
+__device__ __forceinline__ void paint_image(PaintImage &T, const int lane, const i64 lo_c, const int n_c, const i64 qs,
+                                            const i64 j0, const int clen, const int *itv_starts, const int *itv_ends,
+                                            const float *itv_values, float *row) {
+    {   // clear the image
+        const u32x4_a4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int t = 0; t < PAINT_CHUNK / (4 * WAVE); ++t) *reinterpret_cast<u32x4_a4 *>(&T.idx[4 * (t * WAVE + lane)]) = z;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int b = 0; b < n_c; b += WAVE) {
+        const int i = b + lane;
+        int s_rel = 0, w = 0;
+        if (i < n_c) {
+            i64 s64 = (i64)itv_starts[lo_c + i] - qs - j0, e64 = (i64)itv_ends[lo_c + i] - qs - j0;
+            s64 = s64 < 0 ? 0 : s64;
+            e64 = e64 > clen ? clen : e64;
+            if (e64 > s64) { s_rel = (int)s64; w = (int)(e64 - s64); }
+            T.cv[i] = itv_values[lo_c + i];
+        }
+        const u32 tag = (u32)(i + 1);
+        const bool is_long = w > 32;
+        // short intervals: lane = interval
+        for (int t = 0; __builtin_amdgcn_ballot_w64(!is_long && t < w) != 0; ++t)
+            if (!is_long && t < w) atomicMax(&T.idx[s_rel + t], tag);
+        // long intervals: the whole wave paints one at a time
+        u64 m_long = __builtin_amdgcn_ballot_w64(is_long);
+        while (m_long) {
+            const int l = __builtin_ctzll(m_long);
+            m_long &= m_long - 1;
+            const int ls = rdl(s_rel, l), lw = rdl(w, l);
+            const u32 lt = (u32)(b + l + 1);
+            for (int t = lane; t < lw; t += WAVE) atomicMax(&T.idx[ls + t], lt);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int t = 0; t < PAINT_CHUNK / TRIP; ++t) {
+        const int p = t * TRIP + GROUP * lane;
+        if (p < clen) {
+            const u32x4_a4 ix = *reinterpret_cast<const u32x4_a4 *>(&T.idx[p]);
+            const float v0 = ix.x ? T.cv[ix.x - 1] : 0.0f, v1 = ix.y ? T.cv[ix.y - 1] : 0.0f;
+            const float v2 = ix.z ? T.cv[ix.z - 1] : 0.0f, v3 = ix.w ? T.cv[ix.w - 1] : 0.0f;
+            if (p + GROUP <= clen) {
+                store_f32x4(row + p, v0, v1, v2, v3);
+            } else {
+                if (p < clen) row[p] = v0;
+                if (p + 1 < clen) row[p + 1] = v1;
+                if (p + 2 < clen) row[p + 2] = v2;
+            }
+        }
+    }
+}
+
+
 __global__ __launch_bounds__(256) void intervals_to_tracks_kernel(
     const i64 *offset_idxs, const int *starts, i64 starts_stride, i64 n_queries, const int *itv_starts,
     const int *itv_ends, const float *itv_values, const i64 *itv_offsets, const int *pmax, float *out,
-    const i64 *out_offsets, int chunk_len, const u8 *chunk_todo) {
+    const i64 *out_offsets, int chunk_len, const PaintTodo *chunk_todo) {
+    __shared__ PaintImage image;
     const i64 q = blockIdx.y;
     if (q >= n_queries) return;
+    // (chunk mode: almost every block has nothing to do -- look at its record before anything else)
+    if (chunk_todo && chunk_todo[q * gridDim.x + blockIdx.x].flag == 0) return;
     const i64 o0 = out_offsets[q];
     const i64 length = out_offsets[q + 1] - o0;
     const i64 idx = offset_idxs[q];
@@ -2905,7 +2976,17 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_kernel(
     // otherwise a grid-stride loop over the whole row
     i64 j_begin = (i64)blockIdx.x * blockDim.x + threadIdx.x, j_end = length, j_step = (i64)gridDim.x * blockDim.x;
     if (chunk_todo) {
-        if (!chunk_todo[q * gridDim.x + blockIdx.x]) return;
+        const PaintTodo td = chunk_todo[q * gridDim.x + blockIdx.x];
+        if (td.flag == 0) return;
+        if (td.flag == 2) {      // overlapping candidates: wave 0 paints the chunk into the LDS image
+            if (threadIdx.x < WAVE) {
+                const i64 c0 = (i64)blockIdx.x * chunk_len;
+                const i64 c1 = c0 + chunk_len < length ? c0 + chunk_len : length;
+                paint_image(image, (int)threadIdx.x, td.lo_c, td.n_c, qs, c0, (int)(c1 - c0), itv_starts, itv_ends, itv_values,
+                            out + o0 + c0);
+            }
+            return;
+        }
         j_begin = (i64)blockIdx.x * chunk_len + threadIdx.x;
         j_end = ((i64)blockIdx.x + 1) * chunk_len < length ? ((i64)blockIdx.x + 1) * chunk_len : length;
         j_step = blockDim.x;
@@ -2935,9 +3016,6 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_kernel(
 // LDS image of the chunk with ds_max (order-free; lane = interval for short ones, the whole wave
 // for a long one) and then streams the image out through the candidates' values.  Chunks with
 // more than PAINT_TILE candidates are left to the per-value kernel above.
-constexpr int PAINT_TILE = 256;
-constexpr int PAINT_CHUNK = 2048;
-struct PaintTile { u32 idx[PAINT_CHUNK]; float cv[PAINT_TILE]; };
 // Coarse per-list index (gvl_intervals_bucket_*): bucket b of list i covers positions
 // [base[i] + 2048 b, base[i] + 2048 (b + 1)); lo[] = first interval whose running max of ends passes
 // the bucket's start, hi[] = first interval that starts at or after the bucket's end (both relative
@@ -2948,7 +3026,7 @@ struct PaintIndex { const i64 *offsets; const int *base; const int *lo; const in
 __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
     const i64 *offset_idxs, const int *starts, i64 starts_stride, i64 n_queries, const int *itv_starts,
     const int *itv_ends, const float *itv_values, const i64 *itv_offsets, const int *pmax, float *out,
-    const i64 *out_offsets, int chunk_len, int n_chunks, u8 *chunk_todo, const PaintIndex X) {
+    const i64 *out_offsets, int chunk_len, int n_chunks, PaintTodo *chunk_todo, const PaintIndex X, const int force_image) {
     __shared__ PaintTile tiles[4];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = rfl((int)(threadIdx.x >> 6));
@@ -2973,7 +3051,7 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
     __syncthreads();
     if (chunk >= n_chunks) return;
     const i64 j0 = chunk * chunk_len;
-    if (j0 >= length) { if (lane == 0) chunk_todo[q * n_chunks + chunk] = 0; return; }
+    if (j0 >= length) { if (lane == 0) chunk_todo[q * n_chunks + chunk].flag = 0; return; }
     const i64 j1 = (length - j0 > chunk_len) ? j0 + chunk_len : length;
     // first start - qs >= j1 and first pmax - qs > j0: both searches advance together so that
     // their probe loads overlap (2 dependent rounds for lists of thousands instead of 4)
@@ -3033,64 +3111,95 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
         hi_c = b1; lo_c = b2 < hi_c ? b2 : hi_c;
     }
     const i64 n_c64 = hi_c - lo_c;
-    u8 *todo = chunk_todo + q * n_chunks + chunk;
-    if (n_c64 > PAINT_TILE) { if (lane == 0) *todo = 1; return; }              // the per-value kernel takes it
-    if (lane == 0) *todo = 0;
+    PaintTodo *todo = chunk_todo + q * n_chunks + chunk;
+    if (n_c64 > PAINT_TILE) { if (lane == 0) todo->flag = 1; return; }         // the per-value path takes it
+    if (lane == 0) todo->flag = 0;
     const int n_c = (int)n_c64;
     const int clen = (int)(j1 - j0);
-    {   // clear the image
-        const u32x4_a4 z = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int t = 0; t < PAINT_CHUNK / (4 * WAVE); ++t) *reinterpret_cast<u32x4_a4 *>(&T.idx[4 * (t * WAVE + lane)]) = z;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int b = 0; b < n_c; b += WAVE) {
-        const int i = b + lane;
-        int s_rel = 0, w = 0;
-        if (i < n_c) {
-            i64 s64 = (i64)itv_starts[lo_c + i] - qs - j0, e64 = (i64)itv_ends[lo_c + i] - qs - j0;
-            s64 = s64 < 0 ? 0 : s64;
-            e64 = e64 > clen ? clen : e64;
-            if (e64 > s64) { s_rel = (int)s64; w = (int)(e64 - s64); }
-            T.cv[i] = itv_values[lo_c + i];
-        }
-        const u32 tag = (u32)(i + 1);
-        const bool is_long = w > 32;
-        // short intervals: lane = interval
-        for (int t = 0; __builtin_amdgcn_ballot_w64(!is_long && t < w) != 0; ++t)
-            if (!is_long && t < w) atomicMax(&T.idx[s_rel + t], tag);
-        // long intervals: the whole wave paints one at a time
-        u64 m_long = __builtin_amdgcn_ballot_w64(is_long);
-        while (m_long) {
-            const int l = __builtin_ctzll(m_long);
-            m_long &= m_long - 1;
-            const int ls = rdl(s_rel, l), lw = rdl(w, l);
-            const u32 lt = (u32)(b + l + 1);
-            for (int t = lane; t < lw; t += WAVE) atomicMax(&T.idx[ls + t], lt);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float *row = out + o0 + j0;
-#pragma unroll
-    for (int t = 0; t < PAINT_CHUNK / TRIP; ++t) {
-        const int p = t * TRIP + GROUP * lane;
-        if (p < clen) {
-            const u32x4_a4 ix = *reinterpret_cast<const u32x4_a4 *>(&T.idx[p]);
-            const float v0 = ix.x ? T.cv[ix.x - 1] : 0.0f, v1 = ix.y ? T.cv[ix.y - 1] : 0.0f;
-            const float v2 = ix.z ? T.cv[ix.z - 1] : 0.0f, v3 = ix.w ? T.cv[ix.w - 1] : 0.0f;
-            if (p + GROUP <= clen) {
-                store_f32x4(row + p, v0, v1, v2, v3);
-            } else {
-                if (p < clen) row[p] = v0;
-                if (p + 1 < clen) row[p + 1] = v1;
-                if (p + 2 < clen) row[p + 2] = v2;
+    // ---- candidates that do not overlap (what a BigWig-like track is): no painting at all.  A start
+    // BITMAP of the chunk (64 words) + its exclusive popcount prefix give, for any position, the number of
+    // candidates that start at or before it -- i.e. the index of the only interval that can cover it --
+    // with two LDS reads; its end says whether it does.  Overlapping candidates or equal starts take the
+    // image path below (later intervals win: ds_max of candidate indices).
+    {
+        T.idx[lane] = 0u;                                     // bitmap: words 0..63, prefix: words 64..127
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        bool bad = force_image != 0;
+        int n_before = 0;
+        int carry_e = (int)0x80000000, carry_s = (int)0x80000000;          // end / start of the candidate in front
+        for (int b = 0; b < n_c; b += WAVE) {
+            const int i = b + lane;
+            int sr = 0x7FFFFFFF, er = 0x7FFFFFFF;
+            if (i < n_c) {
+                i64 s64 = (i64)itv_starts[lo_c + i] - qs - j0, e64 = (i64)itv_ends[lo_c + i] - qs - j0;
+                s64 = s64 < -(1ll << 30) ? -(1ll << 30) : (s64 > (1ll << 30) ? (1ll << 30) : s64);
+                e64 = e64 < -(1ll << 30) ? -(1ll << 30) : (e64 > (1ll << 30) ? (1ll << 30) : e64);
+                sr = (int)s64; er = (int)e64;
+                T.ce[i] = er;
+                T.cv[i] = itv_values[lo_c + i];
             }
+            int pe = __shfl_up(er, 1, WAVE), ps = __shfl_up(sr, 1, WAVE);
+            if (lane == 0) { pe = carry_e; ps = carry_s; }
+            if (i < n_c && (sr < pe || sr == ps)) bad = true;
+            if (i < n_c && sr >= 0 && sr < clen) atomicOr(&T.idx[sr >> 5], 1u << (sr & 31));
+            n_before += __builtin_popcountll(__builtin_amdgcn_ballot_w64(i < n_c && sr < 0));
+            const int last = (n_c - b > WAVE ? WAVE : n_c - b) - 1;
+            carry_e = rdl(er, last); carry_s = rdl(sr, last);
         }
+        if (__builtin_amdgcn_ballot_w64(bad) == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const u32 wbits = T.idx[lane];
+            const int cnt = __builtin_popcount(wbits);
+            const int incl = wave_scan_inclusive<OpAdd>(cnt);
+            T.idx[WAVE + lane] = (u32)(incl - cnt);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int base = n_before - 1;
+#pragma unroll
+            for (int t = 0; t < PAINT_CHUNK / TRIP; ++t) {
+                const int p = t * TRIP + GROUP * lane;
+                if (p < clen) {
+                    const u32 wd = T.idx[p >> 5];
+                    const int pre = base + (int)T.idx[WAVE + (p >> 5)];
+                    const int bp = p & 31;                      // (a multiple of 4: the 4 positions share the word)
+                    float v[GROUP];
+                    const int i0 = pre + __builtin_popcount(wd & (0xFFFFFFFFu >> (31 - bp)));
+                    const int i3 = pre + __builtin_popcount(wd & (0xFFFFFFFFu >> (28 - bp)));
+                    if (i0 == i3) {
+                        const int e0_ = i0 >= 0 ? T.ce[i0] : 0;
+                        const float c0 = i0 >= 0 ? T.cv[i0] : 0.0f;
+#pragma unroll
+                        for (int g = 0; g < GROUP; ++g) v[g] = e0_ > p + g ? c0 : 0.0f;
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < GROUP; ++g) {
+                            const int ig = pre + __builtin_popcount(wd & (0xFFFFFFFFu >> (31 - bp - g)));
+                            v[g] = (ig >= 0 && T.ce[ig] > p + g) ? T.cv[ig] : 0.0f;
+                        }
+                    }
+                    if (p + GROUP <= clen) {
+                        store_f32x4(row + p, v[0], v[1], v[2], v[3]);
+                    } else {
+                        row[p] = v[0];
+                        if (p + 1 < clen) row[p + 1] = v[1];
+                        if (p + 2 < clen) row[p + 2] = v[2];
+                    }
+                }
+            }
+            return;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    // overlapping candidates or equal starts: the leftovers kernel paints this chunk into an LDS image
+    if (lane == 0) { todo->flag = 2; todo->n_c = n_c; todo->lo_c = lo_c; }
 }
 
 // bucket counts of every list (written at counts[i + 1] for the scan) and the list's base position
@@ -3270,6 +3379,7 @@ int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
 //   128  no speculative reference reads in front of the plan
 //  1024  painter ignores the per-list bucket index (exact 64-ary searches per chunk)
 //  2048  length deltas (get_diffs_sparse, ragged sizing) always one wave per row
+//  8192  painter always paints an LDS image (no start-bitmap lookup for non-overlapping candidates)
 // and 1 / 2 / 4 = timing ablations (no variants / no stores / no loads).
 int g_debug_override = -1;
 int debug_flags() {
@@ -3747,13 +3857,14 @@ int gvl_intervals_bucket_fill(const int32_t *itv_starts, const int32_t *itv_pmax
 static int paint_launch(const int64_t *offset_idxs, const int32_t *starts, int64_t starts_stride, int64_t n_queries,
                         const int32_t *itv_starts, const int32_t *itv_ends, const float *itv_values,
                         const int64_t *itv_offsets, const int32_t *itv_pmax_ends, float *out, const int64_t *out_offsets,
-                        int64_t max_row_len, u8 *todo, hipStream_t s, const PaintIndex X = PaintIndex{nullptr, nullptr, nullptr, nullptr}) {
+                        int64_t max_row_len, PaintTodo *todo, hipStream_t s, const PaintIndex X = PaintIndex{nullptr, nullptr, nullptr, nullptr}) {
     const int chunk_len = 2048;
     const i64 n_chunks = (max_row_len + chunk_len - 1) / chunk_len;
     if (todo) {
         intervals_to_tracks_tiled_kernel<<<dim3((unsigned)((n_chunks + 3) / 4), (unsigned)n_queries), dim3(256), 0, s>>>(
             (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
-            (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, (int)n_chunks, todo, X);
+            (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, (int)n_chunks, todo, X,
+            (debug_flags() & 8192) ? 1 : 0);
         intervals_to_tracks_kernel<<<dim3((unsigned)n_chunks, (unsigned)n_queries), dim3(256), 0, s>>>(
             (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
             (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, todo);
@@ -3799,9 +3910,9 @@ int gvl_intervals_to_tracks(const int64_t *offset_idxs, const int32_t *starts, i
     // kernel for the chunks it left (more than PAINT_TILE candidate intervals) -- or for everything
     // when the flag scratch cannot be had
     const i64 n_chunks = (max_row_len + 2047) / 2048;
-    u8 *todo = nullptr;
+    PaintTodo *todo = nullptr;
     if (paint_can_tile(itv_pmax_ends, max_row_len) &&
-        hipMallocAsync((void **)&todo, (size_t)(n_queries * n_chunks), s) != hipSuccess) {
+        hipMallocAsync((void **)&todo, (size_t)(n_queries * n_chunks) * sizeof(PaintTodo), s) != hipSuccess) {
         (void)hipGetLastError();
         todo = nullptr;
     }
@@ -3847,10 +3958,10 @@ int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *t
 
 
 // scratch layout of gvl_tracks_batch: track_offsets i64 (batch + 1) | out_offsets i64 (batch * ploidy + 1) |
-// chunk flags u8 (batch * chunks) | scratch tracks f32 (batch * stride)
+// chunk records (16 B x batch * chunks) | scratch tracks f32 (batch * stride)
 static void tracks_scratch_parts(i64 batch, i64 ploidy, i64 stride, i64 part[5]) {
     const i64 n_chunks = (stride + 2047) / 2048;
-    const i64 sz[4] = {8 * (batch + 1), 8 * (batch * ploidy + 1), batch * n_chunks, 4 * batch * stride};
+    const i64 sz[4] = {8 * (batch + 1), 8 * (batch * ploidy + 1), batch * n_chunks * (i64)sizeof(PaintTodo), 4 * batch * stride};
     i64 off = 0;
     for (int i = 0; i < 4; ++i) { part[i] = off; off += (sz[i] + 255) & ~255ll; }
     part[4] = off;
@@ -3882,7 +3993,7 @@ int gvl_tracks_batch(const gvl_static *st, const gvl_batch *bt, const int64_t *o
     u8 *base = (u8 *)scratch;
     i64 *track_offsets = (i64 *)(base + part[0]);
     i64 *out_offsets = (i64 *)(base + part[1]);
-    u8 *todo = base + part[2];
+    PaintTodo *todo = (PaintTodo *)(base + part[2]);
     float *scr = (float *)(base + part[3]);
     // 1. scratch-track lengths -> offsets (the reference sizes the scratch track per query, _reconstruct.py:191)
     DiffArgs D;

@@ -22,7 +22,7 @@ def ffi():
 
 # the realignment walk has two implementations (wave-scan planner / scalar replay) and the
 # variant records two sources: every reference vector goes down each of them
-TRACK_PATHS = {0: "default", 8: "scalar-walk", 80: "csr-vrec-gather"}
+TRACK_PATHS = {0: "default", 8: "scalar-walk", 80: "csr-vrec-gather", 8192: "painter-image-path"}
 
 
 @pytest.fixture(params=sorted(TRACK_PATHS), ids=[TRACK_PATHS[k] for k in sorted(TRACK_PATHS)])
@@ -48,7 +48,7 @@ def test_golden_shift_and_realign_tracks_sparse(ffi, tpath):
         np.testing.assert_array_equal(bits(out), bits(exp), err_msg=f"case {ci} strategy {int(inp[13])}")
 
 
-def test_golden_intervals_to_tracks(ffi):
+def test_golden_intervals_to_tracks(ffi, tpath):
     cases = load_ref_cases("intervals_to_tracks")
     assert len(cases) == 200
     for ci, (inp, exp) in enumerate(cases):
@@ -83,7 +83,7 @@ def _track_batch(seed, q, L, contig, **kw):
 
 
 @pytest.mark.parametrize("strategy,param", [(0, 0.0), (1, 0.0), (2, 3.5), (3, 4.0), (4, 1.0), (4, 3.0)])
-def test_fused_tracks_synthetic(ffi, oracle, strategy, param):
+def test_fused_tracks_synthetic(ffi, oracle, strategy, param, tpath):
     st, bt, itv = _track_batch(40 + strategy, 24, 3000, 200_000, shifts=(strategy % 2 == 0))
     B, P = bt.geno_offset_idx.shape
     L = bt.output_length
@@ -171,7 +171,7 @@ def test_cfg4_full_haps_and_track(ffi, oracle, tpath):
     print(f"\ncfg4: V/row={bt.mean_variants:.0f}  haps+onehot {t_h*1e3:.2f} ms  track {t_t*1e3:.2f} ms (host-timed, incl. upload)")
 
 
-def test_painting_dense_nested_and_gappy_intervals(ffi, oracle):
+def test_painting_dense_nested_and_gappy_intervals(ffi, oracle, tpath):
     """Painting beyond the tiled kernel's comfort zone: thousands of 1-3 bp intervals per 2048-value
     chunk (more candidates than one LDS tile -> the per-value kernel takes those chunks), long
     intervals with many short ones nested inside (the walk-back), wide gaps (the prefix-max

@@ -322,7 +322,7 @@ def test_threaded_loader_matches_inline_loader_and_survives_abandoned_epochs(ora
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dbg", [0, 1024, 8], ids=["default", "painter-without-bucket-index", "scalar-walk"])
+@pytest.mark.parametrize("dbg", [0, 1024, 8, 8192], ids=["default", "painter-without-bucket-index", "scalar-walk", "painter-image-path"])
 def test_haps_tracks_dataset_matches_oracle(oracle, dbg):
     """cfg4's dataset shape at a small size: haplotypes + two realigned tracks per batch from dataset
     indices, against the oracle's fused paint + realign for the same request."""
@@ -385,7 +385,7 @@ def test_haps_tracks_dataset_matches_oracle(oracle, dbg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dbg", [0, 1024], ids=["bucket-index", "exact-searches"])
+@pytest.mark.parametrize("dbg", [0, 1024, 8192], ids=["bucket-index", "exact-searches", "painter-image-path"])
 def test_tracks_batch_long_rows_jitter_and_dense_lists(oracle, dbg):
     """gvl_tracks_batch on rows of many 2048-value chunks whose starts are not bucket aligned (jitter),
     with sparse, ordinary and very dense interval lists (a dense list overflows the painter's tile:
