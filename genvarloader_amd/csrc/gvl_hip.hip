@@ -3130,16 +3130,28 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
         bool bad = force_image != 0;
         int n_before = 0;
         int carry_e = (int)0x80000000, carry_s = (int)0x80000000;          // end / start of the candidate in front
-        for (int b = 0; b < n_c; b += WAVE) {
+        // all candidate records are requested before the first one is used (<= 4 rounds of 64: one memory
+        // round trip instead of one per round)
+        int c_s[PAINT_TILE / WAVE], c_e[PAINT_TILE / WAVE]; float c_v[PAINT_TILE / WAVE];
+#pragma unroll
+        for (int r_ = 0; r_ < PAINT_TILE / WAVE; ++r_) {
+            const int i = r_ * WAVE + lane;
+            c_s[r_] = 0; c_e[r_] = 0; c_v[r_] = 0.0f;
+            if (i < n_c) { c_s[r_] = itv_starts[lo_c + i]; c_e[r_] = itv_ends[lo_c + i]; c_v[r_] = itv_values[lo_c + i]; }
+        }
+#pragma unroll
+        for (int r_ = 0; r_ < PAINT_TILE / WAVE; ++r_) {
+            const int b = r_ * WAVE;
+            if (b >= n_c) break;
             const int i = b + lane;
             int sr = 0x7FFFFFFF, er = 0x7FFFFFFF;
             if (i < n_c) {
-                i64 s64 = (i64)itv_starts[lo_c + i] - qs - j0, e64 = (i64)itv_ends[lo_c + i] - qs - j0;
+                i64 s64 = (i64)c_s[r_] - qs - j0, e64 = (i64)c_e[r_] - qs - j0;
                 s64 = s64 < -(1ll << 30) ? -(1ll << 30) : (s64 > (1ll << 30) ? (1ll << 30) : s64);
                 e64 = e64 < -(1ll << 30) ? -(1ll << 30) : (e64 > (1ll << 30) ? (1ll << 30) : e64);
                 sr = (int)s64; er = (int)e64;
                 T.ce[i] = er;
-                T.cv[i] = itv_values[lo_c + i];
+                T.cv[i] = c_v[r_];
             }
             int pe = __shfl_up(er, 1, WAVE), ps = __shfl_up(sr, 1, WAVE);
             if (lane == 0) { pe = carry_e; ps = carry_s; }
