@@ -54,7 +54,7 @@ SYMBOLS = (
     "gvl_loader_destroy",
 )
 
-ABI_VERSION = 3          # include/gvl_hip.h: GVL_ABI_VERSION
+ABI_VERSION = 4          # include/gvl_hip.h: GVL_ABI_VERSION
 GVL_ONEHOT_LC = 0
 GVL_ONEHOT_CL = 1
 
@@ -104,13 +104,21 @@ class GvlLoaderConfig(C.Structure):
         ("want_haps", C.c_int32), ("want_onehot", C.c_int32), ("onehot_layout", C.c_int32),
         ("in_flight", C.c_int32), ("n_slots", C.c_int32), ("slot_arenas", C.POINTER(_vp)),
         ("threaded", C.c_int32), ("group", C.c_int32),
+        ("want_annot", C.c_int32), ("max_row_len", _i64), ("tracks", _vp), ("n_tracks", C.c_int32),
+        ("track_seed_mode", C.c_int32), ("strategy_id", _i64), ("track_param", C.c_double), ("track_seed", C.c_uint64),
+        ("scratch_stride", _i64),
     ]
+
+
+LOADER_SLOT_PARTS = 12       # GVL_LOADER_SLOT_PARTS
+LOADER_TABLE_PARTS = 5       # GVL_LOADER_TABLE_PARTS
 
 
 class GvlLoaderBatch(C.Structure):
     _fields_ = [
         ("slot", C.c_int32), ("batch", _i64), ("idx", _vp), ("onehot", _vp), ("haps", _vp),
         ("regions", _vp), ("geno_offset_idx", _vp), ("shifts", _vp), ("to_rc", _vp), ("out_offsets", _vp),
+        ("annot_v_idxs", _vp), ("annot_ref_pos", _vp), ("tracks", _vp), ("sizes", _vp), ("track_seed", _vp),
     ]
 
 

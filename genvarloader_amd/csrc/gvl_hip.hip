@@ -973,6 +973,15 @@ __device__ __forceinline__ void packed_plan(const ReconArgs &A, const RowIn *rin
 #define GVL_STAMP(i) do { } while (0)
 #endif
 
+__device__ __forceinline__ void set_prio(const int p) {     // (s_setprio takes an immediate)
+    switch (p) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
 template <int OH, bool HAPS, bool ANNOT>
 __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void reconstruct_kernel(const ReconArgs A) {
     __shared__ Luts luts;
@@ -993,6 +1002,14 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     const bool planned_ok = A.chunk_len <= CHUNK_TRIPS * TRIP && !(A.dbg & 8);
 
     GVL_STAMP(0);
+    // EXPERIMENT (dbg 4096 / 16384): stagger the co-resident waves of a SIMD by issue priority
+    int base_prio = 0;
+    if (A.dbg & (4096 | 16384 | 256)) {
+        const u32 hwid = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);      // HW_ID[15:0]
+        const int slot = (int)(hwid & 15u);
+        base_prio = (A.dbg & 4096) ? 3 - ((slot >> 1) & 3) : (A.dbg & 16384) ? 3 - (slot & 3) : ((blockIdx.x >> 3) & 1) * 2 + 1;
+        set_prio(base_prio);
+    }
     if (tid < 256) {  // LUTs
         const u32 d = onehot_dword((u32)tid);
         luts.oh[tid] = d;
@@ -1967,7 +1984,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         finish_partial(p0, wv, av4, ap4);
     }
     GVL_STAMP(7);
-    __builtin_amdgcn_s_setprio(0);
+    set_prio(base_prio);
     // pass B: finish the class-0 trips.  Store addresses are a scalar base per trip plus a
     // per-lane offset that never changes: forward rows put lane l at +16*l, reverse-complemented
     // rows mirror the index (lane l at +16*(63-l) from the trip's lowest address).
@@ -2080,6 +2097,9 @@ struct DiffArgs {
     int *diffs;
     // fused sizing (ffi/mod.rs:794-811)
     i64 output_length; i64 *lengths;
+    // the native loop's ragged batches live in slots of a fixed capacity: a row longer than len_cap (> 0) is
+    // cut to it and reported through *async_err (never silently)
+    i64 len_cap; int *async_err;
 };
 
 // length delta of one haplotype (genotype slot o_idx; keep slice at ks; optional query window)
@@ -2212,6 +2232,7 @@ __global__ __launch_bounds__(256) void diffs_kernel(const DiffArgs A, const int 
             const int *reg = regions + (k / A.ploidy) * regions_stride;
             len = imax((i64)(reg[2] - reg[1]) + d, 0);
         }
+        if (A.len_cap > 0 && len > A.len_cap) { len = A.len_cap; if (A.async_err) *A.async_err = 1; }
         A.lengths[k + 1] = len;
         if (k == 0) A.lengths[0] = 0;
     }
@@ -2238,6 +2259,7 @@ __global__ __launch_bounds__(256) void diffs_wave_kernel(const DiffArgs A, const
             const int *reg = regions + query * regions_stride;
             len = imax((i64)(reg[2] - reg[1]) + d, 0);
         }
+        if (A.len_cap > 0 && len > A.len_cap) { len = A.len_cap; if (A.async_err) *A.async_err = 1; }
         A.lengths[k + 1] = len;
         if (k == 0) A.lengths[0] = 0;
     }
@@ -2498,6 +2520,7 @@ struct TrackArgs {
     i64 n_rows; int ploidy; int ploidy_shift; int chunk_len;
     const float *tracks; const i64 *track_offsets;
     double param; i64 strategy; u64 base_seed;
+    const u64 *seed_ptr;        // non-NULL: base_seed is read from the device (the native loop's per-batch seeds)
     float *out;
     int dbg;
 };
@@ -2529,7 +2552,7 @@ __device__ float fill_value(const TrackArgs &A, const float *track, i64 tlen, i6
         const i64 width = (i64)A.param;
         const i64 lo = imax(vrp - width, 0), hi = imin(vrp + width, tlen - 1);
         const u64 pool = (u64)(hi - lo + 1);
-        const u64 seed = hash4_dev(A.base_seed, query, hap, (u64)pp);
+        const u64 seed = hash4_dev(A.seed_ptr ? *A.seed_ptr : A.base_seed, query, hap, (u64)pp);
         return tr(lo + (i64)(pool ? seed % pool : 0));
     }
     if (A.strategy == GVL_FILL_INTERPOLATE) {
@@ -3718,8 +3741,14 @@ int gvl_get_diffs_sparse(const gvl_static *st, const gvl_batch *bt, const int32_
     return check_launch("gvl_get_diffs_sparse");
 }
 
+static int hap_offsets_impl(const gvl_static *st, const gvl_batch *bt, int32_t *diffs, int64_t *out_offsets,
+                            int64_t *total_and_max, int64_t len_cap, void *stream);
 int gvl_hap_offsets(const gvl_static *st, const gvl_batch *bt, int32_t *diffs, int64_t *out_offsets,
                     int64_t *total_and_max, void *stream) {
+    return hap_offsets_impl(st, bt, diffs, out_offsets, total_and_max, 0, stream);
+}
+static int hap_offsets_impl(const gvl_static *st, const gvl_batch *bt, int32_t *diffs, int64_t *out_offsets,
+                            int64_t *total_and_max, int64_t len_cap, void *stream) {
     DiffArgs D;
     int rc = fill_diff_args(D, st, bt, "gvl_hap_offsets");
     if (rc) return rc;
@@ -3734,6 +3763,7 @@ int gvl_hap_offsets(const gvl_static *st, const gvl_batch *bt, int32_t *diffs, i
     if (!bt->regions || bt->regions_stride < 3) return fail(GVL_ERR_INVALID, "%s", "gvl_hap_offsets: NULL regions");
     D.q_starts = bt->regions + 1; D.q_ends = bt->regions + 2; D.q_stride = bt->regions_stride;
     D.diffs = diffs; D.output_length = bt->output_length; D.lengths = (i64 *)out_offsets;
+    if (len_cap > 0) { D.len_cap = len_cap; D.async_err = async_err_word(); }
     if (diffs_long_rows(st)) {
         const i64 grid = (D.n_rows * WAVE + 255) / 256;
         if (grid > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_hap_offsets: batch too large");
@@ -3935,9 +3965,17 @@ int gvl_intervals_to_tracks(const int64_t *offset_idxs, const int32_t *starts, i
     return rc;
 }
 
+static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const float *tracks,
+                               const int64_t *track_offsets, const double *params, int64_t strategy_id,
+                               uint64_t base_seed, const u64 *seed_ptr, float *out, void *stream);
 int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *tracks,
                        const int64_t *track_offsets, const double *params, int64_t strategy_id,
                        uint64_t base_seed, float *out, void *stream) {
+    return realign_tracks_impl(st, bt, tracks, track_offsets, params, strategy_id, base_seed, nullptr, out, stream);
+}
+static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const float *tracks,
+                               const int64_t *track_offsets, const double *params, int64_t strategy_id,
+                               uint64_t base_seed, const u64 *seed_ptr, float *out, void *stream) {
     if (!st || !bt) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: NULL struct");
     if (bt->batch < 0 || bt->ploidy <= 0) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: bad batch/ploidy");
     if (bt->batch == 0) return GVL_OK;
@@ -3959,7 +3997,7 @@ int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *t
     int chunks = 1;
     if (pick_chunk(bt->max_row_len, &chunks, &A.chunk_len)) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: too many chunks");
     A.tracks = tracks; A.track_offsets = (const i64 *)track_offsets;
-    A.param = params[0]; A.strategy = strategy_id; A.base_seed = base_seed;
+    A.param = params[0]; A.strategy = strategy_id; A.base_seed = base_seed; A.seed_ptr = seed_ptr;
     A.out = out;
     A.dbg = debug_flags();
     if (A.n_rows > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: batch too large");
@@ -3986,9 +4024,18 @@ int64_t gvl_tracks_scratch_bytes(int64_t batch, int64_t ploidy, int64_t scratch_
     return part[4] > 0 ? part[4] : 256;
 }
 
+static int tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const int64_t *offset_idxs, const gvl_track_set *tracks,
+                             int32_t n_tracks, const double *params, int64_t strategy_id, uint64_t base_seed, const u64 *seed_ptr,
+                             float *out, int64_t out_track_stride, void *scratch, int64_t scratch_stride, void *stream);
 int gvl_tracks_batch(const gvl_static *st, const gvl_batch *bt, const int64_t *offset_idxs, const gvl_track_set *tracks,
                      int32_t n_tracks, const double *params, int64_t strategy_id, uint64_t base_seed, float *out,
                      int64_t out_track_stride, void *scratch, int64_t scratch_stride, void *stream) {
+    return tracks_batch_impl(st, bt, offset_idxs, tracks, n_tracks, params, strategy_id, base_seed, nullptr, out, out_track_stride,
+                             scratch, scratch_stride, stream);
+}
+static int tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const int64_t *offset_idxs, const gvl_track_set *tracks,
+                             int32_t n_tracks, const double *params, int64_t strategy_id, uint64_t base_seed, const u64 *seed_ptr,
+                             float *out, int64_t out_track_stride, void *scratch, int64_t scratch_stride, void *stream) {
     if (!st || !bt || n_tracks < 0) return fail(GVL_ERR_INVALID, "%s", "gvl_tracks_batch: bad arguments");
     if (bt->batch < 0 || bt->ploidy <= 0 || bt->output_length < 0)
         return fail(GVL_ERR_INVALID, "%s", "gvl_tracks_batch: needs batch >= 0, ploidy > 0 and a fixed output_length");
@@ -4037,8 +4084,8 @@ int gvl_tracks_batch(const gvl_static *st, const gvl_batch *bt, const int64_t *o
                           T.itv_pmax_ends, scr, (const int64_t *)track_offsets, scratch_stride,
                           paint_can_tile(T.itv_pmax_ends, scratch_stride) ? todo : nullptr, s, X);
         if (rc) return rc;
-        rc = gvl_realign_tracks(st, &rb, scr, (const int64_t *)track_offsets, params, strategy_id, base_seed,
-                                out + (i64)t * out_track_stride, stream);
+        rc = realign_tracks_impl(st, &rb, scr, (const int64_t *)track_offsets, params, strategy_id, base_seed, seed_ptr,
+                                 out + (i64)t * out_track_stride, stream);
         if (rc) return rc;
     }
     return GVL_OK;
@@ -4080,11 +4127,41 @@ int gvl_prepare_request(const gvl_static *st, const int64_t *idx, int64_t batch,
 // of the prep kernel (the "epoch table": regions / geno_offset_idx / shifts / to_rc for every query of
 // the epoch, 26 + 13 P bytes per query), so that a batch costs the host one launch, one event record
 // and at most two stream waits -- per GROUP of `group` batches (gvl_reconstruct_many).
+__device__ __forceinline__ u64 splitmix64_dev(u64 x) {
+    u64 z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// per-batch base_seed of the seed-dependent track fills (_reconstruct.py:215-222): deterministic -> xor of the
+// batch's dataset indices; else a draw keyed by (seed, epoch, batch).  One wave per batch.
+__global__ __launch_bounds__(256) void batch_seeds_kernel(const i64 *order, i64 n, i64 bs, i64 n_batches, int deterministic,
+                                                          u64 seed, u64 epoch, u64 *out) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const i64 j = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (j >= n_batches) return;
+    if (!deterministic) {
+        if (lane == 0) out[j] = splitmix64_dev(seed ^ splitmix64_dev((epoch << 32) + (u64)j));
+        return;
+    }
+    const i64 lo = j * bs, hi = (lo + bs < n) ? lo + bs : n;
+    u64 acc = 0;
+    for (i64 i = lo + lane; i < hi; i += WAVE) acc ^= (u64)order[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const u32 lo32 = (u32)__shfl_xor((int)(u32)acc, off, WAVE), hi32 = (u32)__shfl_xor((int)(u32)(acc >> 32), off, WAVE);
+        acc ^= ((u64)hi32 << 32) | lo32;
+    }
+    if (lane == 0) out[j] = acc;
+}
+
 struct gvl_loader {
     gvl_static st;
     gvl_loader_config cfg;
     void *arenas[64];
-    int64_t part[7];
+    int64_t part[GVL_LOADER_SLOT_PARTS];
+    gvl_track_set tracks[16];     // copy of cfg.tracks
+    u64 *e_seeds;                 // epoch table: per-batch track seeds
     hipStream_t streams[16];
     hipEvent_t done[64], released[64], epoch_ready;    // per slot SET (group of `G` slots)
     bool set_used[64];
@@ -4113,12 +4190,21 @@ struct LoaderSync {
 
 static i64 align256(i64 x) { return (x + 255) & ~255ll; }
 
+static bool loader_ragged(const gvl_loader_config *c) { return c->output_length == -1; }
+// bases per row a slot reserves: the fixed length, or the ragged bound
+static i64 loader_row_cap(const gvl_loader_config *c) { return loader_ragged(c) ? c->max_row_len : c->output_length; }
+
 int64_t gvl_loader_slot_bytes(const gvl_loader_config *cfg, int64_t *part_offsets) {
-    if (!cfg || cfg->batch_size <= 0 || cfg->ploidy <= 0 || cfg->output_length <= 0) return -1;
-    const i64 b = cfg->batch_size, K = b * cfg->ploidy, L = cfg->output_length;
-    const i64 sizes[7] = {cfg->want_onehot ? 4 * K * L : 0, cfg->want_haps ? K * L : 0, 16 * b, 8 * K, 4 * K, K, 8 * (K + 1)};
+    if (!cfg || cfg->batch_size <= 0 || cfg->ploidy <= 0 || loader_row_cap(cfg) <= 0 || cfg->n_tracks < 0) return -1;
+    const i64 b = cfg->batch_size, K = b * cfg->ploidy, L = loader_row_cap(cfg);
+    const bool hp = cfg->want_haps || cfg->want_annot;
+    const i64 scr = cfg->n_tracks > 0 ? gvl_tracks_scratch_bytes(b, cfg->ploidy, cfg->scratch_stride) : 0;
+    if (scr < 0) return -1;
+    const i64 sizes[GVL_LOADER_SLOT_PARTS] = {cfg->want_onehot ? 4 * K * L : 0, hp ? K * L : 0, 0, 0, 0, 0, 8 * (K + 1),
+                                              cfg->want_annot ? 4 * K * L : 0, cfg->want_annot ? 4 * K * L : 0,
+                                              4 * (i64)cfg->n_tracks * K * L, scr, 16};
     i64 off = 0;
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < GVL_LOADER_SLOT_PARTS; ++i) {
         if (part_offsets) part_offsets[i] = off;
         off += align256(sizes[i]);
     }
@@ -4126,11 +4212,11 @@ int64_t gvl_loader_slot_bytes(const gvl_loader_config *cfg, int64_t *part_offset
 }
 
 int64_t gvl_loader_table_bytes(const gvl_loader_config *cfg, int64_t n, int64_t *part_offsets) {
-    if (!cfg || cfg->ploidy <= 0 || n < 0) return -1;
+    if (!cfg || cfg->ploidy <= 0 || cfg->batch_size <= 0 || n < 0) return -1;
     const i64 P = cfg->ploidy;
-    const i64 sizes[4] = {16 * n, 8 * n * P, 4 * n * P, n * P};
+    const i64 sizes[GVL_LOADER_TABLE_PARTS] = {16 * n, 8 * n * P, 4 * n * P, n * P, 8 * ((n + cfg->batch_size - 1) / cfg->batch_size)};
     i64 off = 0;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < GVL_LOADER_TABLE_PARTS; ++i) {
         if (part_offsets) part_offsets[i] = off;
         off += align256(sizes[i]);
     }
@@ -4149,14 +4235,26 @@ int gvl_loader_create(const gvl_static *st, const gvl_loader_config *cfg, gvl_lo
         return fail(GVL_ERR_INVALID, "%s", "gvl_loader_create: need 1 <= in_flight <= 16, n_slots <= 64 a multiple of group, "
                                            "n_slots / group >= in_flight + 1");
     if (!cfg->full_regions || !cfg->slot_arenas || cfg->n_regions <= 0 || cfg->n_samples <= 0 || cfg->batch_size <= 0 ||
-        cfg->ploidy <= 0 || cfg->output_length <= 0 || (!cfg->want_haps && !cfg->want_onehot))
+        cfg->ploidy <= 0 || (cfg->output_length <= 0 && cfg->output_length != -1) ||
+        (!cfg->want_haps && !cfg->want_onehot && !cfg->want_annot))
         return fail(GVL_ERR_INVALID, "%s", "gvl_loader_create: bad config");
+    if (loader_ragged(cfg) && (cfg->max_row_len <= 0 || cfg->max_row_len > 0x7FFFFF00ll || !cfg->deterministic || cfg->n_tracks > 0 ||
+                               (cfg->want_onehot && cfg->onehot_layout != GVL_ONEHOT_LC)))
+        return fail(GVL_ERR_INVALID, "%s", "gvl_loader_create: ragged rows (output_length -1) need max_row_len > 0, deterministic != 0, "
+                                           "row-major one-hot and no tracks");
+    if (cfg->n_tracks < 0 || cfg->n_tracks > 16 || (cfg->n_tracks > 0 && (!cfg->tracks || cfg->scratch_stride <= 0 || cfg->batch_size > 65535 ||
+                                                                          cfg->strategy_id < 0 || cfg->strategy_id > GVL_FILL_INTERPOLATE)))
+        return fail(GVL_ERR_INVALID, "%s", "gvl_loader_create: tracks need 1..16 interval stores, scratch_stride > 0, batch_size <= 65535 "
+                                           "and a valid strategy_id");
     gvl_loader *ld = new (std::nothrow) gvl_loader;
     if (!ld) return fail(GVL_ERR_HIP, "%s", "gvl_loader_create: out of host memory");
     memset(ld, 0, sizeof(*ld));
     ld->st = *st; ld->cfg = *cfg;
     ld->G = G; ld->n_sets = cfg->n_slots / G;
-    gvl_loader_slot_bytes(cfg, ld->part);
+    for (int t = 0; t < cfg->n_tracks; ++t) ld->tracks[t] = cfg->tracks[t];
+    ld->cfg.tracks = ld->tracks;
+    if (cfg->want_annot) ld->cfg.want_haps = 1;
+    if (gvl_loader_slot_bytes(cfg, ld->part) <= 0) { delete ld; return fail(GVL_ERR_INVALID, "%s", "gvl_loader_create: bad slot sizes"); }
     for (int i = 0; i < cfg->n_slots; ++i) {
         ld->arenas[i] = cfg->slot_arenas[i];
         if (!ld->arenas[i] || ((uintptr_t)ld->arenas[i] & 255)) {
@@ -4228,13 +4326,14 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
         if (ld->set_used[i] && hipStreamWaitEvent(s, ld->done[i], 0) != hipSuccess)
             return fail(GVL_ERR_HIP, "%s", "gvl_loader_start_epoch: hipStreamWaitEvent failed");
     {
-        int64_t po[4];
+        int64_t po[GVL_LOADER_TABLE_PARTS];
         gvl_loader_table_bytes(&c, n, po);
         u8 *base = (u8 *)table;
         ld->e_regions = (int *)(base + po[0]);
         ld->e_goi = (i64 *)(base + po[1]);
         ld->e_shifts = (int *)(base + po[2]);
         ld->e_to_rc = base + po[3];
+        ld->e_seeds = (u64 *)(base + po[4]);
     }
     const i64 bs = c.batch_size;
     ld->order = order; ld->n_order = n;
@@ -4245,9 +4344,16 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
     const i64 n_used = drop_last ? ld->n_batches * bs : n;
     if (n_used > 0) {
         const int rc = gvl_prepare_request(&ld->st, order, n_used, c.full_regions, c.n_regions, c.n_samples, c.ploidy, c.jitter,
-                                           c.rc_neg, c.deterministic, c.output_length, c.seed, ld->counter, ld->e_regions,
-                                           (int64_t *)ld->e_goi, ld->e_to_rc, ld->e_shifts, s);
+                                           c.rc_neg, c.deterministic, c.output_length < 0 ? 0 : c.output_length, c.seed, ld->counter,
+                                           ld->e_regions, (int64_t *)ld->e_goi, ld->e_to_rc, ld->e_shifts, s);
         if (rc) return rc;
+        if (c.n_tracks > 0 && c.track_seed_mode == 1) {
+            const i64 grid = (ld->n_batches * WAVE + 255) / 256;
+            batch_seeds_kernel<<<dim3((unsigned)grid), dim3(256), 0, s>>>((const i64 *)order, n_used, bs, ld->n_batches, c.deterministic,
+                                                                          c.seed, ld->counter, ld->e_seeds);
+            const int rc2 = check_launch("gvl_loader_start_epoch(seeds)");
+            if (rc2) return rc2;
+        }
     }
     if (hipEventRecord(ld->epoch_ready, s) != hipSuccess)
         return fail(GVL_ERR_HIP, "%s", "gvl_loader_start_epoch: hipEventRecord failed");
@@ -4269,6 +4375,11 @@ static int loader_parts(gvl_loader *ld, i64 j, gvl_loader_batch *o) {
     o->idx = ld->order + j * bs;
     o->onehot = ld->cfg.want_onehot ? base + ld->part[0] : nullptr;
     o->haps = ld->cfg.want_haps ? base + ld->part[1] : nullptr;
+    o->annot_v_idxs = ld->cfg.want_annot ? (int32_t *)(base + ld->part[7]) : nullptr;
+    o->annot_ref_pos = ld->cfg.want_annot ? (int32_t *)(base + ld->part[8]) : nullptr;
+    o->tracks = ld->cfg.n_tracks > 0 ? (float *)(base + ld->part[9]) : nullptr;
+    o->sizes = loader_ragged(&ld->cfg) ? (int64_t *)(base + ld->part[11]) : nullptr;
+    o->track_seed = (ld->cfg.n_tracks > 0 && ld->cfg.track_seed_mode == 1) ? (const uint64_t *)(ld->e_seeds + j) : nullptr;
     // the request arrays of the batch are rows of the epoch table
     o->regions = ld->e_regions + 4 * j * bs;
     o->geno_offset_idx = (int64_t *)(ld->e_goi + j * bs * P);
@@ -4300,14 +4411,39 @@ static int loader_submit(gvl_loader *ld, i64 g) {
         memset(&bt, 0, sizeof(bt));
         bt.regions = o.regions; bt.regions_stride = 4; bt.shifts = o.shifts; bt.geno_offset_idx = o.geno_offset_idx;
         bt.batch = o.batch; bt.ploidy = c.ploidy; bt.to_rc = c.rc_neg ? o.to_rc : nullptr;
-        bt.output_length = c.output_length; bt.max_row_len = c.output_length;
+        bt.output_length = c.output_length; bt.max_row_len = loader_row_cap(&c);
         gvl_out &oc = ocs[m];
         memset(&oc, 0, sizeof(oc));
         oc.haps = o.haps; oc.onehot = o.onehot; oc.onehot_layout = c.onehot_layout; oc.out_offsets = o.out_offsets;
+        oc.annot_v_idxs = o.annot_v_idxs; oc.annot_ref_pos = o.annot_ref_pos;
+        if (loader_ragged(&c)) {
+            // row lengths and offsets on the device (rows cut to the slot's capacity are reported, never silent);
+            // the reconstruct launch below then reads them -- no host round trip
+            const int rc0 = hap_offsets_impl(&ld->st, &bt, nullptr, o.out_offsets, o.sizes, c.max_row_len, s);
+            if (rc0) return rc0;
+            bt.out_offsets = o.out_offsets;
+            oc.out_offsets = nullptr;
+        }
     }
     int rc = GVL_OK;
     (void)traced("launch reconstruct", [&] { rc = gvl_reconstruct_many(&ld->st, bts, ocs, m, s); return hipSuccess; });
     if (rc) return rc;
+    if (c.n_tracks > 0) {
+        m = 0;
+        for (i64 j = g * ld->G; j < (g + 1) * ld->G && j < ld->n_batches; ++j, ++m) {
+            gvl_loader_batch o;
+            loader_parts(ld, j, &o);
+            const i64 K = c.batch_size * c.ploidy;
+            const double par[1] = {c.track_param};
+            u8 *base = (u8 *)ld->arenas[o.slot];
+            (void)traced("launch tracks", [&] {
+                rc = tracks_batch_impl(&ld->st, &bts[m], (const int64_t *)o.idx, ld->tracks, c.n_tracks, par, c.strategy_id, c.track_seed,
+                                       (const u64 *)o.track_seed, o.tracks, K * c.output_length, base + ld->part[10], c.scratch_stride, s);
+                return hipSuccess;
+            });
+            if (rc) return rc;
+        }
+    }
     if (traced("record done", [&] { return hipEventRecord(ld->done[set], s); }) != hipSuccess) return fail(GVL_ERR_HIP, "%s", "gvl_loader: hipEventRecord failed");
     ld->set_used[set] = true;
     return GVL_OK;

@@ -65,6 +65,9 @@ class Batch:
     out_offsets: torch.Tensor | None = None      # ragged mode: (b * P + 1,) i64; haps / onehot are then flat
     annot_v_idxs: torch.Tensor | None = None     # annotate=True: i32, same shape as haps
     annot_ref_pos: torch.Tensor | None = None
+    sizes: torch.Tensor | None = None            # ragged batches of the native loop: device i64[2] = {total bases,
+    #                                              longest row}; haps / onehot are then views of the slot's whole
+    #                                              capacity, rows packed at out_offsets (no host read per batch)
 
 
 class DeviceHapsDataset:
@@ -106,6 +109,22 @@ class DeviceHapsDataset:
         self.seed = (0 if seed is None else int(seed)) & 0xFFFFFFFFFFFFFFFF
         self._counter = 0          # random draws are keyed by (seed, counter, dataset index): one tick per request
         self._loaders = 0          # ... and every loader gets its own derived seed, so a new loader does not replay
+
+    def max_row_len(self) -> int:
+        """A true bound on a ragged row's length (what a ring slot of the native loop reserves per row):
+        the longest region plus the largest sum of insertion lengths over the genotype slots."""
+        m = getattr(self, "_max_row_len", None)
+        if m is None:
+            reg, dev = self.full_regions, self.dev
+            longest = int((reg[:, 2] - reg[:, 1]).max().item()) if self.n_regions else 0
+            grow = 0
+            if int(dev.geno_v_idxs.numel()):
+                gain = dev.ilens.index_select(0, dev.geno_v_idxs.to(torch.int64)).clamp_(min=0).to(torch.int64)
+                c = torch.cat([gain.new_zeros(1), gain.cumsum(0)])
+                go = dev.geno_offsets
+                grow = int((c[go[1].clamp(0, gain.numel())] - c[go[0].clamp(0, gain.numel())]).max().item())
+            m = self._max_row_len = max(longest + max(grow, 0), 1)
+        return m
 
     def _loader_seed(self) -> int:
         """A seed per loader (splitmix64 of seed and the loaders created so far)."""
@@ -226,7 +245,8 @@ class DeviceHapsDataset:
 
     def to_dataloader(self, batch_size: int = 1, shuffle: bool = False, sampler=None, drop_last: bool = False,
                       generator: torch.Generator | None = None, in_flight: int = 2, rank: int = 0,
-                      world_size: int = 1, seed: int = 0, threaded: bool = False, group: int = 4) -> "DeviceLoader":
+                      world_size: int = 1, seed: int = 0, threaded: bool = False, group: int = 4,
+                      python_loop: bool = False) -> "DeviceLoader":
         """``Dataset.to_dataloader`` (``_impl.py:1963-2072``) for device consumers.  With
         ``world_size > 1`` the epoch is sharded across ranks like ``DistributedSampler``
         (:func:`genvarloader_amd.sharding.epoch_order`): same permutation on every rank, disjoint
@@ -234,7 +254,7 @@ class DeviceHapsDataset:
         groups are submitted ahead.  ``threaded=True``: a producer thread inside the library
         submits them (launches overlap the consumer's own host work per batch)."""
         return DeviceLoader(self, batch_size, shuffle, sampler, drop_last, generator, in_flight, rank, world_size,
-                            seed, threaded, group, python_loop=self.ragged or self.annotate)
+                            seed, threaded, group, python_loop=python_loop)
 
 
 @dataclass
@@ -345,14 +365,12 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
 
     def to_dataloader(self, batch_size: int = 1, shuffle: bool = False, sampler=None, drop_last: bool = False,
                       generator=None, in_flight: int = 2, rank: int = 0, world_size: int = 1, seed: int = 0,
-                      **unsupported) -> "DeviceLoader":
-        """Tracks go through the Python submit loop (each batch owns its memory); the epoch order is
-        drawn per epoch like the native loop's (``epoch_order``: reshuffled every epoch, sharded
-        across ranks)."""
-        if unsupported:
-            raise TypeError(f"DeviceHapsTracksDataset.to_dataloader: unsupported arguments {sorted(unsupported)}")
+                      threaded: bool = False, group: int = 2, python_loop: bool = False) -> "DeviceLoader":
+        """The native ring carries the tracks too (``gvl_tracks_batch`` per batch into the slot, per-batch
+        FlankSample seeds computed on the device); ``python_loop=True`` (or a custom sampler) submits every
+        batch from Python instead and lets it own its memory."""
         return DeviceLoader(self, batch_size, shuffle, sampler, drop_last, generator, in_flight, rank, world_size,
-                            seed, False, 1, python_loop=True)
+                            seed, threaded, group, python_loop=python_loop)
 
 
 class DeviceLoader:
@@ -400,8 +418,17 @@ class DeviceLoader:
             batch_size=self.batch_size, output_length=ds.output_length, jitter=ds.jitter, rc_neg=int(ds.rc_neg),
             deterministic=int(ds.deterministic), seed=ds._loader_seed(), want_haps=int(ds.haps), want_onehot=int(ds.onehot),
             onehot_layout=_lib.GVL_ONEHOT_LC if ds.layout == "lc" else _lib.GVL_ONEHOT_CL, in_flight=self.in_flight,
-            n_slots=n_slots, slot_arenas=None, threaded=int(self.threaded), group=self.group)
-        parts = (C.c_int64 * 7)()
+            n_slots=n_slots, slot_arenas=None, threaded=int(self.threaded), group=self.group,
+            want_annot=int(ds.annotate), max_row_len=ds.max_row_len() if ds.ragged else 0)
+        track_sets = getattr(ds, "_track_sets", None)
+        if track_sets is not None and len(getattr(ds, "_itv", ())):
+            cfg.tracks = C.cast(track_sets, C.c_void_p)
+            cfg.n_tracks = len(ds._itv)
+            cfg.track_seed_mode = 1 if ds.base_seed is None else 0
+            cfg.strategy_id, cfg.track_param = ds.strategy_id, ds.param
+            cfg.track_seed = ds.base_seed or 0
+            cfg.scratch_stride = ds._stride
+        parts = (C.c_int64 * _lib.LOADER_SLOT_PARTS)()
         nbytes = int(lib.gvl_loader_slot_bytes(C.byref(cfg), parts))
         if nbytes <= 0:
             raise ValueError("bad loader configuration")
@@ -428,9 +455,25 @@ class DeviceLoader:
             n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
             return arena[parts[i]:parts[i] + n].view(dtype).view(shape)
 
-        oh = view(0, torch.uint8, (b, P, L, 4) if ds.layout == "lc" else (b, P, 4, L)) if ds.onehot else None
-        hp = view(1, torch.uint8, (b, P, L)) if ds.haps else None
-        v = (oh, hp)        # the request arrays of a batch are rows of the epoch table (see _epoch_table)
+        oo = av = ap = tr = sz = None
+        if ds.ragged:
+            # rows packed at out_offsets inside the slot's capacity (K * max_row_len bases)
+            cap = K * int(nat["cfg"].max_row_len)
+            oh = view(0, torch.uint8, (cap, 4)) if ds.onehot else None
+            hp = view(1, torch.uint8, (cap,)) if ds.haps else None
+            oo, sz = view(6, torch.int64, (K + 1,)), view(11, torch.int64, (2,))
+            if ds.annotate:
+                av, ap = view(7, torch.int32, (cap,)), view(8, torch.int32, (cap,))
+        else:
+            oh = view(0, torch.uint8, (b, P, L, 4) if ds.layout == "lc" else (b, P, 4, L)) if ds.onehot else None
+            hp = view(1, torch.uint8, (b, P, L)) if ds.haps else None
+            if ds.annotate:
+                av, ap = view(7, torch.int32, (b, P, L)), view(8, torch.int32, (b, P, L))
+            T = int(nat["cfg"].n_tracks)
+            if T:       # track t of a short last batch still starts at t * batch_size * P * L
+                full = view(9, torch.float32, (T, self.batch_size * P, L))
+                tr = full[:, :K].view(T, b, P, L).permute(1, 0, 2, 3)
+        v = (oh, hp, oo, av, ap, tr, sz)   # the request arrays of a batch are rows of the epoch table (see _epoch_table)
         nat["views"][key] = v
         return v
 
@@ -441,7 +484,9 @@ class DeviceLoader:
 
         nat, ds, d = self._native, self.ds, self.ds.dev.device
         lib = ds.dev.lib
-        po = (C.c_int64 * 4)()
+        from . import _lib
+
+        po = (C.c_int64 * _lib.LOADER_TABLE_PARTS)()
         nbytes = int(lib.gvl_loader_table_bytes(C.byref(nat["cfg"]), C.c_int64(n), po))
         tab = nat.get("table")
         if tab is None or tab.numel() < nbytes:
@@ -454,9 +499,12 @@ class DeviceLoader:
 
         reg, goi = part(0, torch.int32, (n, 4)), part(1, torch.int64, (n, P))
         sh, rc = part(2, torch.int32, (n, P)), part(3, torch.uint8, (n * P,))
+        seeds = None
+        if int(nat["cfg"].n_tracks) and int(nat["cfg"].track_seed_mode) == 1:
+            seeds = part(4, torch.int64, (-(-n // bs),))      # (u64 bit patterns; one device scalar per batch)
         if n == 0:
-            return tab, (), (), (), ()
-        return tab, reg.split(bs), goi.split(bs), sh.split(bs), (rc.split(bs * P) if ds.rc_neg else None)
+            return tab, (), (), (), (), None
+        return tab, reg.split(bs), goi.split(bs), sh.split(bs), (rc.split(bs * P) if ds.rc_neg else None), seeds
 
     def _iter_native(self):
         import ctypes as C
@@ -484,7 +532,7 @@ class DeviceLoader:
                                     device=d, generator=g)
             self.epoch += 1
             n = int(order.numel())
-            tab, reg_v, goi_v, sh_v, rc_v = self._epoch_table(n)
+            tab, reg_v, goi_v, sh_v, rc_v, seeds_v = self._epoch_table(n)
             _lib.check(lib.gvl_loader_start_epoch(handle, C.c_void_p(order.data_ptr()), C.c_int64(n),
                                                   C.c_int32(int(self.drop_last)), C.c_void_p(tab.data_ptr()),
                                                   C.c_void_p(cur.cuda_stream)))
@@ -506,8 +554,13 @@ class DeviceLoader:
                     _lib.check(rc)
                 if out.slot < 0:
                     return
-                oh, hp = views(out.slot, out.batch)
-                batch = Batch(oh, hp, idx_views[i], reg_v[i], sh_v[i], goi_v[i], None if none_rc else rc_v[i])
+                oh, hp, oo, av, ap, tr, sz = views(out.slot, out.batch)
+                if tr is None:
+                    batch = Batch(oh, hp, idx_views[i], reg_v[i], sh_v[i], goi_v[i], None if none_rc else rc_v[i], oo, av, ap, sz)
+                else:
+                    batch = TrackBatch(oh, hp, idx_views[i], reg_v[i], sh_v[i], goi_v[i], None if none_rc else rc_v[i],
+                                       tracks=tr)
+                    batch.base_seed = (seeds_v[i] if seeds_v is not None else ds.base_seed)
                 i += 1
                 yield batch
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GVL_ABI_VERSION 3
+#define GVL_ABI_VERSION 4
 
 enum {
     GVL_OK = 0,
@@ -404,6 +404,25 @@ typedef struct gvl_loader_config {
     int32_t group;               /* batches per launch (gvl_reconstruct_many): 0 / 1 .. GVL_MANY_MAX;
                                     in_flight then counts GROUPS, n_slots must be a multiple of group
                                     and >= (in_flight + 1) * group */
+    /* ---- the reference loader's other outputs (_torch.py:94-211, _reconstruct.py:132-307) ---- */
+    int32_t want_annot;          /* annotated haplotypes: annot_v_idxs / annot_ref_pos (i32 per base) next to haps
+                                    (reconstruct_annotated_haplotypes_fused); forces want_haps */
+    int64_t max_row_len;         /* RAGGED rows: output_length == -1 (deterministic only, row-major one-hot).  Row k
+                                    has length region length + its haplotype's length delta (_haps.py:794-811),
+                                    rows are packed back to back at out_offsets.  A slot holds
+                                    batch_size * ploidy * max_row_len bases; a row longer than max_row_len is cut
+                                    to it and reported by gvl_async_error() -- choose a true bound (longest
+                                    region + the largest sum of insertion lengths of any genotype slot) */
+    const gvl_track_set *tracks; /* HOST array of n_tracks interval stores (copied); list index = dataset index.
+                                    Fixed-length rows only.  Per batch: gvl_tracks_batch into the slot */
+    int32_t n_tracks;
+    int32_t track_seed_mode;     /* 0: track_seed for every batch; 1: per batch like the reference
+                                    (_reconstruct.py:215-222): deterministic -> xor of the batch's dataset
+                                    indices, else a draw keyed by (seed, epoch, batch) */
+    int64_t strategy_id;         /* insertion fill, see gvl_realign_tracks */
+    double track_param;
+    uint64_t track_seed;
+    int64_t scratch_stride;      /* values reserved per query's scratch track (gvl_tracks_batch) */
 } gvl_loader_config;
 
 typedef struct gvl_loader_batch {
@@ -417,10 +436,19 @@ typedef struct gvl_loader_batch {
     int32_t *shifts;             /* (batch, ploidy)          | valid until the epoch ends             */
     uint8_t *to_rc;              /* (batch * ploidy)        /                                        */
     int64_t *out_offsets;        /* (batch * ploidy + 1), in the slot */
+    int32_t *annot_v_idxs;       /* want_annot: i32 per base, laid out like haps */
+    int32_t *annot_ref_pos;
+    float *tracks;               /* n_tracks > 0: f32 (n_tracks, batch_size * ploidy, output_length) -- track t of
+                                    a short last batch still starts at t * batch_size * ploidy * output_length */
+    int64_t *sizes;              /* ragged: device i64[2] = {total bases of the batch, longest row} */
+    const uint64_t *track_seed;  /* device: the base_seed this batch's FlankSample fills used (mode 1) */
 } gvl_loader_batch;
 
-/* Bytes of one slot and the offsets of its parts (7 values: onehot, haps, regions,
- * geno_offset_idx, shifts, to_rc, out_offsets), for a full batch. */
+/* Bytes of one slot and the offsets of its parts (GVL_LOADER_SLOT_PARTS values: onehot, haps, regions,
+ * geno_offset_idx, shifts, to_rc, out_offsets, annot_v_idxs, annot_ref_pos, tracks, track scratch,
+ * sizes), for a full batch.  (Parts 2-5 are unused since the request arrays live in the epoch table.) */
+#define GVL_LOADER_SLOT_PARTS 12
+#define GVL_LOADER_TABLE_PARTS 5
 int64_t gvl_loader_slot_bytes(const gvl_loader_config *cfg, int64_t *part_offsets);
 /* `st` is copied; the device arrays it points to must outlive the loader. */
 int gvl_loader_create(const gvl_static *st, const gvl_loader_config *cfg, gvl_loader **out);
@@ -431,8 +459,9 @@ int gvl_loader_create(const gvl_static *st, const gvl_loader_config *cfg, gvl_lo
  * (cfg.seed, epochs started so far, dataset index). */
 int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int32_t drop_last,
                            void *table, void *stream);
-/* Bytes of the epoch table for n queries and the offsets of its 4 parts (regions i32 (n, 4),
- * geno_offset_idx i64 (n, ploidy), shifts i32 (n, ploidy), to_rc u8 (n * ploidy)).  The table is the
+/* Bytes of the epoch table for n queries and the offsets of its GVL_LOADER_TABLE_PARTS parts (regions i32
+ * (n, 4), geno_offset_idx i64 (n, ploidy), shifts i32 (n, ploidy), to_rc u8 (n * ploidy), per-batch track
+ * seeds u64 (ceil(n / batch_size))).  The table is the
  * caller's device memory (256-byte aligned) and must stay alive until the epoch ends; batch j's
  * request arrays are rows [j * batch_size, ...) of its parts. */
 int64_t gvl_loader_table_bytes(const gvl_loader_config *cfg, int64_t n, int64_t *part_offsets);

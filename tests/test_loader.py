@@ -349,11 +349,14 @@ def test_haps_tracks_dataset_matches_oracle(oracle, dbg):
     from genvarloader_amd import _lib
 
     _lib.load().gvl_set_debug_flags(dbg)
-    for strategy, param, pinned in ((0, 0.0, 11), (4, 3.0, 11), (3, 6.0, None), (3, 6.0, 5)):
+    loops = (False, True) if dbg == 0 else (False,)       # the native ring; batches submitted from Python
+    for strategy, param, pinned, python_loop in [(*c, pl) for c in ((0, 0.0, 11), (4, 3.0, 11), (3, 6.0, None), (3, 6.0, 5))
+                                                 for pl in loops]:
         ds = DeviceHapsTracksDataset(dev, full_regions, S, P, tracks=tracks, strategy_id=strategy, param=param,
                                      base_seed=pinned, output_length=L, onehot=False, haps=True)
         seen = 0
-        for batch in ds.to_dataloader(batch_size=7, shuffle=True, generator=torch.Generator().manual_seed(1)):
+        for batch in ds.to_dataloader(batch_size=7, shuffle=True, generator=torch.Generator().manual_seed(1),
+                                      python_loop=python_loop):
             idx = batch.idx.cpu().numpy()
             r_idx, s_idx = np.unravel_index(idx, (R, S))
             regions = full_regions[r_idx]
@@ -413,7 +416,7 @@ def test_tracks_batch_long_rows_jitter_and_dense_lists(oracle, dbg):
     try:
         ds = DeviceHapsTracksDataset(dev, full_regions, S, P, tracks=tracks, strategy_id=0, output_length=L, jitter=37,
                                      onehot=False, haps=True, seed=3)
-        for batch in ds.to_dataloader(batch_size=5, shuffle=True, seed=2):
+        for batch in ds.to_dataloader(batch_size=5, shuffle=True, seed=2, in_flight=2, group=2):
             idx = batch.idx.cpu().numpy()
             regions, shifts = batch.regions.cpu().numpy(), batch.shifts.cpu().numpy()
             goi = batch.geno_offset_idx.cpu().numpy()
@@ -434,10 +437,12 @@ def test_tracks_batch_long_rows_jitter_and_dense_lists(oracle, dbg):
 
 
 @pytest.mark.gpu
-def test_loader_ragged_and_annotated_modes(oracle):
+@pytest.mark.parametrize("python_loop", [False, True], ids=["native-ring", "python-loop"])
+def test_loader_ragged_and_annotated_modes(oracle, python_loop):
     """The reference loader's other haplotype outputs from dataset indices: ragged rows (its default,
-    _haps.py:794-811) and annotated haplotypes (ffi/mod.rs:2237-2397), through the Python submit loop;
-    sharded across two ranks like the native loop."""
+    _haps.py:794-811) and annotated haplotypes (ffi/mod.rs:2237-2397), through the native ring (rows packed
+    inside a slot of fixed capacity, sizes stay on the device) and through the Python submit loop
+    (exactly-sized batches); sharded across two ranks."""
     from genvarloader_amd import HapsDevice
     from genvarloader_amd.loader import DeviceHapsDataset
 
@@ -456,21 +461,28 @@ def test_loader_ragged_and_annotated_modes(oracle):
     ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=-1, onehot=True, haps=True)
     seen, lens = [], []
     for rank in range(2):
-        for batch in ds.to_dataloader(batch_size=6, shuffle=True, seed=4, rank=rank, world_size=2, drop_last=False):
+        for batch in ds.to_dataloader(batch_size=6, shuffle=True, seed=4, rank=rank, world_size=2, drop_last=False,
+                                      python_loop=python_loop, group=2):
             idx = batch.idx.cpu().numpy()
             regions, goi, to_rc, shifts = request(idx)
             exp, exp_off, exp_oh = oracle.reconstruct_haplotypes_fused(
                 regions, shifts, goi, go, gv, st.v_starts, st.ilens, st.alt_alleles, st.alt_offsets, st.ref,
                 st.ref_offsets, st.pad_char, -1, None, None, to_rc, False, onehot=True)
             np.testing.assert_array_equal(batch.out_offsets.cpu().numpy(), exp_off)
-            np.testing.assert_array_equal(batch.haps.cpu().numpy(), exp)
-            np.testing.assert_array_equal(batch.onehot.cpu().numpy(), exp_oh)
+            tot = len(exp)
+            if python_loop:
+                assert batch.sizes is None and batch.haps.numel() == tot
+            else:       # a view of the slot's capacity; {total, longest row} on the device
+                assert batch.sizes.cpu().tolist() == [tot, int(np.diff(exp_off).max())]
+                assert batch.haps.numel() == len(idx) * P * ds.max_row_len() >= tot
+            np.testing.assert_array_equal(batch.haps[:tot].cpu().numpy(), exp)
+            np.testing.assert_array_equal(batch.onehot[:tot].cpu().numpy(), exp_oh.reshape(-1, 4))
             seen.extend(idx.tolist()); lens.extend(np.diff(exp_off).tolist())
     assert sorted(set(seen)) == list(range(R * S)) and len(set(lens)) > 5          # every index, genuinely ragged
 
     ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, onehot=False, annotate=True)
     n = 0
-    for batch in ds.to_dataloader(batch_size=9, shuffle=False):
+    for batch in ds.to_dataloader(batch_size=9, shuffle=False, python_loop=python_loop):
         idx = batch.idx.cpu().numpy()
         regions, goi, to_rc, shifts = request(idx)
         exp, av, ap, _ = oracle.reconstruct_annotated_haplotypes_fused(
@@ -482,3 +494,49 @@ def test_loader_ragged_and_annotated_modes(oracle):
         np.testing.assert_array_equal(batch.annot_ref_pos.cpu().numpy().ravel(), ap)
         n += len(idx)
     assert n == R * S
+
+    # ragged AND annotated
+    ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=-1, onehot=False, annotate=True)
+    n = 0
+    for batch in ds.to_dataloader(batch_size=8, shuffle=True, seed=1, python_loop=python_loop, in_flight=2, group=1):
+        idx = batch.idx.cpu().numpy()
+        regions, goi, to_rc, shifts = request(idx)
+        exp, av, ap, exp_off = oracle.reconstruct_annotated_haplotypes_fused(
+            regions, shifts, goi, go, gv, st.v_starts, st.ilens, st.alt_alleles, st.alt_offsets, st.ref,
+            st.ref_offsets, st.pad_char, -1, None, None, to_rc, False)
+        tot = len(exp)
+        np.testing.assert_array_equal(batch.out_offsets.cpu().numpy(), exp_off)
+        np.testing.assert_array_equal(batch.haps[:tot].cpu().numpy(), exp)
+        np.testing.assert_array_equal(batch.annot_v_idxs[:tot].cpu().numpy(), av)
+        np.testing.assert_array_equal(batch.annot_ref_pos[:tot].cpu().numpy(), ap)
+        n += len(idx)
+    assert n == R * S
+
+
+@pytest.mark.gpu
+def test_native_ragged_rows_longer_than_the_slot_bound_are_reported(oracle):
+    """A ragged slot reserves max_row_len bases per row.  With a bound that is too small the rows are cut
+    to it (nothing is written outside the slot) and the cut is reported like a sticky HIP error."""
+    from genvarloader_amd import HapsDevice, _lib
+    from genvarloader_amd.loader import DeviceHapsDataset
+
+    R, S, P, L = 4, 3, 2, 300
+    st, full_regions, go, gv = _grid_dataset(5, R, S, P, L, indel_frac=0.5)
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+    ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=-1, onehot=False, haps=True)
+    true_bound = ds.max_row_len()
+    ds._max_row_len = 200                        # every region is 300 long
+    lib = _lib.load()
+    lib.gvl_async_error(1)
+    for batch in ds.to_dataloader(batch_size=5, shuffle=False):
+        assert int(batch.sizes[1]) == 200 and int(batch.sizes[0]) == 200 * batch.idx.numel() * P
+    torch.cuda.synchronize()
+    assert lib.gvl_async_error(1) != 0
+    ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=-1, onehot=False, haps=True)
+    assert ds.max_row_len() == true_bound >= L
+    for batch in ds.to_dataloader(batch_size=5, shuffle=False):
+        assert int(batch.sizes[1]) <= true_bound
+    torch.cuda.synchronize()
+    assert lib.gvl_async_error(1) == 0

@@ -76,10 +76,25 @@ def main(args) -> None:
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(1)]
     keep = [None] * (len(streams) + 1)
 
-    def step(i):
-        s = streams[i % len(streams)]
-        with torch.cuda.stream(s):
-            keep[i % len(keep)] = ds[batches[i % nb]]
+    loop = os.environ.get("GVL_CFG4_LOOP", "native")
+    if loop == "native":
+        # the native ring: epochs chained, shuffled on the device; request prep once per epoch, then per batch
+        # reconstruct + gvl_tracks_batch into a ring slot, 3 batches ahead on the loader's streams
+        dl = ds.to_dataloader(batch_size=bs, shuffle=True, seed=1, in_flight=int(os.environ.get("GVL_CFG4_INFLIGHT", 3)),
+                              group=int(os.environ.get("GVL_CFG4_GROUP", 1)))
+
+        def forever():
+            while True:
+                yield from dl
+        it = forever()
+
+        def step(i):
+            keep[0] = next(it)
+    else:
+        def step(i):
+            s = streams[i % len(streams)]
+            with torch.cuda.stream(s):
+                keep[i % len(keep)] = ds[batches[i % nb]]
 
     def barrier():
         if dist is not None:
@@ -165,7 +180,8 @@ def main(args) -> None:
                                    "+ 1 track painted from intervals and realigned (Repeat5p)",
                        "windows_per_step_per_rank": K, "length_bp": L, "ploidy": P, "mean_variants_per_window": round(mean_v, 1),
                        "dataset": f"{R} regions x {S} samples, 256 Mbp contig, {int(a.numel())} intervals",
-                       "batches_in_flight": len(streams), "parallelism": f"world_size {world}: one batch per rank per step"},
+                       "batches_in_flight": len(streams) if loop != "native" else dl.in_flight * dl.group,
+                       "loop": "native ring (gvl_loader_*)" if loop == "native" else "python submit loop", "parallelism": f"world_size {world}: one batch per rank per step"},
             "timing": {"how": "median of K-step regions between barrier + synchronize, host clock", "regions": len(spans)},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "reconstruct_kernel<OH_LC, haps=true, annot=false>", "kernel_ms": t_recon,
