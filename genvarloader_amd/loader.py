@@ -373,6 +373,134 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
                             seed, threaded, group, python_loop=python_loop)
 
 
+def splice_plan_device(lengths: torch.Tensor, pair_len: torch.Tensor):
+    """``build_splice_plan`` (``_dataset/_splice.py:54-160``) with torch ops on ``lengths.device``.
+
+    ``lengths`` (B, E) per-query lengths in (splice_row, sample, element) order, ``pair_len``
+    (n_pairs,) elements per (row, sample) pair (``sum == B``).  Returns ``permutation`` (B * E: new
+    position -> old k = query * E + e, i.e. (pair, e, element) order), ``permuted_out_offsets``
+    (B * E + 1) and ``group_offsets`` (n_pairs * E + 1: one spliced sequence per (pair, e) cell).
+    No host synchronisation."""
+    d = lengths.device
+    B, E = int(lengths.shape[0]), int(lengths.shape[1])
+    pair_len = pair_len.to(device=d, dtype=torch.int64)
+    n_pairs = int(pair_len.numel())
+    start = torch.cumsum(pair_len, 0) - pair_len                                  # first element of each pair
+    pair_of_q = torch.repeat_interleave(torch.arange(n_pairs, device=d), pair_len, output_size=B)
+    i_local = torch.arange(B, device=d) - start[pair_of_q]
+    # element q of pair p, inner cell e, goes to E * start[p] + e * len[p] + i  (:82-88)
+    dest = (E * start[pair_of_q] + i_local)[:, None] + torch.arange(E, device=d)[None, :] * pair_len[pair_of_q][:, None]
+    perm = torch.empty(B * E, dtype=torch.int64, device=d)
+    perm[dest.reshape(-1)] = torch.arange(B * E, device=d)
+    plen = lengths.reshape(-1).to(torch.int64)[perm]
+    out_offsets = torch.zeros(B * E + 1, dtype=torch.int64, device=d)
+    torch.cumsum(plen, 0, out=out_offsets[1:])
+    cells = torch.zeros(n_pairs * E + 1, dtype=torch.int64, device=d)
+    torch.cumsum(pair_len.repeat_interleave(E), 0, out=cells[1:])                 # :137-151
+    return perm, out_offsets, out_offsets[cells]
+
+
+@dataclass
+class SplicedBatch:
+    haps: torch.Tensor | None           # flat u8: cell (pair, ploid) = [group_offsets[c], group_offsets[c + 1])
+    onehot: torch.Tensor | None         # flat (total, 4) u8
+    pairs: torch.Tensor                 # (n_pairs,) indices over the (splice rows x samples) grid
+    idx: torch.Tensor                   # (B,) dataset indices of the elements, (pair, element) order
+    group_offsets: torch.Tensor         # (n_pairs * P + 1,) i64: one spliced haplotype per (pair, ploid)
+    out_offsets: torch.Tensor           # (B * P + 1,) i64: the elements inside them, (pair, ploid, element) order
+    permutation: torch.Tensor           # (B * P,) new row -> old k = element * P + ploid
+    annot_v_idxs: torch.Tensor | None = None
+    annot_ref_pos: torch.Tensor | None = None
+
+
+class DeviceSplicedHapsDataset(DeviceHapsDataset):
+    """Spliced haplotypes (``Dataset`` with a splice map, ``_dataset/_query.py:207-313``): an item is a
+    (splice row, sample) pair, its value the concatenation of the row's elements (exons) per haplotype.
+
+    ``splice_offsets`` (n_rows + 1) / ``splice_region_idx``: the splice map (``SpliceMap.splice_map``:
+    row -> ordered region indices).  Per batch, on the device: element dataset indices, request prep,
+    per-element haplotype lengths (``haplotype_lengths_for_plan``, ``_haps.py:536-569``; with
+    ``exonic=True`` under the ``choose_exonic_variants`` keep mask), the splice plan
+    (:func:`splice_plan_device`), then ONE ploidy-1 launch over the permuted elements that writes every
+    element where it belongs in its spliced haplotype (``reconstruct_haplotypes_spliced_fused``,
+    ``ffi/mod.rs:1981-2076``); negative-strand elements are reverse-complemented in place when
+    ``rc_neg``.  Like the reference: ragged only, deterministic, no jitter (``_query.py:225-226``).
+    One host read per batch (the total size, for the exactly-sized allocation)."""
+
+    def __init__(self, dev, regions, n_samples, ploidy, *, splice_offsets, splice_region_idx, rc_neg: bool = True,
+                 onehot: bool = False, haps: bool = True, annotate: bool = False, exonic: bool = False):
+        super().__init__(dev, regions, n_samples, ploidy, output_length=-1, jitter=0, rc_neg=rc_neg, deterministic=True,
+                         onehot=onehot, haps=haps, annotate=annotate)
+        so = np.ascontiguousarray(splice_offsets, np.int64)
+        sr = np.ascontiguousarray(splice_region_idx, np.int64)
+        if so.ndim != 1 or so.size < 1 or so[0] != 0 or np.any(np.diff(so) < 0) or so[-1] != sr.size:
+            raise ValueError("splice_offsets must be a non-decreasing (n_rows + 1,) array ending at len(splice_region_idx)")
+        if sr.size and (sr.min() < 0 or sr.max() >= self.n_regions):
+            raise ValueError("splice_region_idx out of range")
+        self.n_rows = int(so.size - 1)
+        self._so_host, self._len_host = so, np.diff(so)
+        d = dev.device
+        self._so, self._sr = torch.as_tensor(so).to(d), torch.as_tensor(sr).to(d)
+        self.exonic = bool(exonic)
+
+    @property
+    def shape(self):
+        return (self.n_rows, self.n_samples)
+
+    def __len__(self):
+        return self.n_rows * self.n_samples
+
+    def __getitem__(self, pairs) -> SplicedBatch:
+        d, P, S = self.dev.device, self.ploidy, self.n_samples
+        if isinstance(pairs, torch.Tensor):
+            pairs_h = pairs.detach().cpu().numpy()          # (host indices avoid this read)
+        else:
+            pairs_h = np.asarray(pairs)
+        pairs_h = pairs_h.astype(np.int64).reshape(-1)
+        if pairs_h.size and (pairs_h.min() < 0 or pairs_h.max() >= len(self)):
+            raise IndexError("pair index out of range")
+        row_h = pairs_h // S
+        B = int(self._len_host[row_h].sum())                # elements of the batch: known on the host, no sync
+        pairs_d = torch.as_tensor(pairs_h).to(d)
+        row, smp = pairs_d // S, pairs_d % S
+        pair_len = (self._so[row + 1] - self._so[row])
+        n_pairs = int(pairs_h.size)
+        start = torch.cumsum(pair_len, 0) - pair_len
+        pair_of_q = torch.repeat_interleave(torch.arange(n_pairs, device=d), pair_len, output_size=B)
+        i_local = torch.arange(B, device=d) - start[pair_of_q]
+        r_idx = self._sr[self._so[row[pair_of_q]] + i_local] if B else torch.zeros(0, dtype=torch.int64, device=d)
+        ds_idx = r_idx * S + smp[pair_of_q]
+        _, regions, shifts, goi, to_rc = self.request(ds_idx)
+        # per-element lengths -> plan.  The lengths come out of the ragged sizing of the permuted launch
+        # itself (region length + length delta, under the keep mask when exonic), so the plan only needs
+        # the permutation first: its offsets are the launch's own out_offsets.
+        perm, _, _ = splice_plan_device(torch.zeros((B, P), dtype=torch.int32, device=d), pair_len)
+        q_of = torch.div(perm, P, rounding_mode="floor")
+        regions_p = regions.index_select(0, q_of).contiguous()
+        goi_p = goi.reshape(-1).index_select(0, perm).view(-1, 1).contiguous()
+        shifts_p = torch.zeros((B * P, 1), dtype=torch.int32, device=d)
+        to_rc_p = None if to_rc is None else to_rc.index_select(0, perm).contiguous()
+        keep = keep_offsets = None
+        if self.exonic and B:
+            keep, keep_offsets = self.dev.choose_exonic_variants(regions_p[:, 1].contiguous(), regions_p[:, 2].contiguous(), goi_p)
+        out = self.dev.reconstruct(regions_p, shifts_p, goi_p, -1, keep, keep_offsets, to_rc=to_rc_p, haps=self.haps,
+                                   onehot=self.onehot, annotate=self.annotate)
+        cells = torch.zeros(n_pairs * P + 1, dtype=torch.int64, device=d)
+        torch.cumsum(pair_len.repeat_interleave(P), 0, out=cells[1:])
+        batch = SplicedBatch(out.haps, out.onehot, pairs_d, ds_idx, out.out_offsets[cells], out.out_offsets, perm,
+                             out.annot_v_idxs, out.annot_ref_pos)
+        batch._arena = out.haps if out.haps is not None else out.onehot
+        batch._keep = out
+        return batch
+
+    def to_dataloader(self, batch_size: int = 1, shuffle: bool = False, sampler=None, drop_last: bool = False,
+                      generator=None, in_flight: int = 2, rank: int = 0, world_size: int = 1, seed: int = 0) -> "DeviceLoader":
+        """Spliced batches are submitted from Python (sizes differ per batch; each owns its memory); the
+        epoch order over the (rows x samples) pairs is drawn and sharded like the native loop's."""
+        return DeviceLoader(self, batch_size, shuffle, sampler, drop_last, generator, in_flight, rank, world_size,
+                            seed, False, 1, python_loop=True)
+
+
 class DeviceLoader:
     """Iterates batches of a :class:`DeviceHapsDataset`, ``in_flight`` batches ahead, each on
     its own HIP stream; the consumer's current stream waits on the batch's event.

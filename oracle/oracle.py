@@ -404,3 +404,37 @@ def intervals_and_realign_track_fused(
                                     keep_offsets, strategy_id, base_seed)
     if to_rc is not None:
         reverse_flat_rows_inplace(out, out_offsets, to_rc)
+
+
+def build_splice_plan(lengths, splice_row_offsets, n_samples: int, n_rows: int) -> dict:
+    """The reference's ``build_splice_plan`` (``_dataset/_splice.py:54-160``), restated with plain loops.
+
+    ``lengths`` (B,) or (B, E): per-query lengths in (splice_row, sample, element) C-order, E inner
+    cells per query (the ploidy); ``splice_row_offsets`` (n_rows * n_samples + 1): elements per
+    (row, sample) pair.  The plan re-targets a ploidy-1 kernel call over the B * E flattened rows so
+    that the bytes land in (row, sample, inner, element) C-order: ``permutation`` (new position ->
+    old k = query * E + e), ``permuted_lengths``, ``permuted_out_offsets`` (per element) and
+    ``group_offsets`` (one spliced sequence per (row, sample, inner) cell)."""
+    lengths = np.asarray(lengths)
+    off = np.asarray(splice_row_offsets, np.int64)
+    n_pairs = int(n_rows) * int(n_samples)
+    assert off.shape == (n_pairs + 1,)
+    flat = lengths.reshape(lengths.shape[0], -1).astype(np.int32)
+    B, E = flat.shape
+    perm = []
+    cells = [0]
+    for p in range(n_pairs):                       # _splice.py:82-88: for pair, for e, for element
+        s, e_ = int(off[p]), int(off[p + 1])
+        for e in range(E):
+            for q in range(s, e_):
+                perm.append(q * E + e)
+            cells.append(len(perm))
+    perm = np.asarray(perm, np.intp)
+    assert len(perm) == B * E
+    permuted_lengths = flat.reshape(-1)[perm].astype(np.int32)
+    out_offsets = np.zeros(len(perm) + 1, np.int64)
+    np.cumsum(permuted_lengths, out=out_offsets[1:])
+    group_offsets = out_offsets[np.asarray(cells, np.int64)]          # :137-151
+    inner = tuple(lengths.shape[1:])
+    return dict(permutation=perm, permuted_lengths=permuted_lengths, permuted_out_offsets=out_offsets,
+                group_offsets=group_offsets, out_shape=(int(n_rows), int(n_samples), *inner, None))

@@ -248,7 +248,42 @@ def generate_pyref_tracks():
     print(f"pyref_tracks.npz: rows={B * P} L={L} V/row={bt.mean_variants:.2f}")
 
 
+def generate_pyref_splice_plan():
+    """Splice plans (permutation + offsets that put a ploidy-1 kernel call into spliced layout) from the
+    reference's own ``build_splice_plan`` (_dataset/_splice.py:54-160), AST-extracted and exec'd with a
+    numpy-only namespace, on seeded random inputs incl. empty pairs, E = 1, 2, 3 and 1-D lengths."""
+    import types
+
+    ns = extract_namespace(REF / "python/genvarloader/_utils.py", {"lengths_to_offsets"})
+    tree = ast.parse((REF / "python/genvarloader/_dataset/_splice.py").read_text())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "build_splice_plan"]
+    ns["SplicePlan"] = lambda **kw: types.SimpleNamespace(**kw)
+    exec(compile(ast.Module(body=fn, type_ignores=[]), "_splice.py", "exec"), ns)
+    build = ns["build_splice_plan"]
+    rng = np.random.default_rng(20260802 + 31)
+    d = {}
+    n = 0
+    for n_rows, n_samples, E, max_el in ((3, 2, 2, 4), (5, 3, 1, 3), (4, 1, 3, 5), (6, 4, 2, 1), (2, 2, 0, 4), (7, 2, 2, 6)):
+        per_row = rng.integers(0 if n_rows > 3 else 1, max_el + 1, n_rows)
+        pair_len = np.repeat(per_row, n_samples)
+        off = np.concatenate([[0], np.cumsum(pair_len)]).astype(np.int64)
+        B = int(off[-1])
+        lengths = rng.integers(0, 50, (B, E) if E else (B,)).astype(np.int32)
+        plan = build(lengths=lengths, splice_row_offsets=off, n_samples=n_samples, n_rows=n_rows)
+        d[f"{n}/lengths"], d[f"{n}/offsets"] = lengths, off
+        d[f"{n}/n_samples"], d[f"{n}/n_rows"] = np.int64(n_samples), np.int64(n_rows)
+        d[f"{n}/permutation"] = np.asarray(plan.permutation, np.int64)
+        d[f"{n}/permuted_lengths"] = np.asarray(plan.permuted_lengths, np.int32)
+        d[f"{n}/permuted_out_offsets"] = np.asarray(plan.permuted_out_offsets, np.int64)
+        d[f"{n}/group_offsets"] = np.asarray(plan.group_offsets, np.int64)
+        n += 1
+    d["n"] = np.int64(n)
+    np.savez_compressed(HERE / "pyref_splice_plan.npz", **d)
+    print(f"pyref_splice_plan.npz: {n} plans")
+
+
 if __name__ == "__main__":
     convert_reference_goldens()
     generate_pyref()
     generate_pyref_tracks()
+    generate_pyref_splice_plan()
