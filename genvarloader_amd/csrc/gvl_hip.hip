@@ -973,15 +973,6 @@ __device__ __forceinline__ void packed_plan(const ReconArgs &A, const RowIn *rin
 #define GVL_STAMP(i) do { } while (0)
 #endif
 
-__device__ __forceinline__ void set_prio(const int p) {     // (s_setprio takes an immediate)
-    switch (p) {
-        case 0: __builtin_amdgcn_s_setprio(0); break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        default: __builtin_amdgcn_s_setprio(3); break;
-    }
-}
-
 template <int OH, bool HAPS, bool ANNOT>
 __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void reconstruct_kernel(const ReconArgs A) {
     __shared__ Luts luts;
@@ -1002,14 +993,6 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     const bool planned_ok = A.chunk_len <= CHUNK_TRIPS * TRIP && !(A.dbg & 8);
 
     GVL_STAMP(0);
-    // EXPERIMENT (dbg 4096 / 16384): stagger the co-resident waves of a SIMD by issue priority
-    int base_prio = 0;
-    if (A.dbg & (4096 | 16384 | 256)) {
-        const u32 hwid = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);      // HW_ID[15:0]
-        const int slot = (int)(hwid & 15u);
-        base_prio = (A.dbg & 4096) ? 3 - ((slot >> 1) & 3) : (A.dbg & 16384) ? 3 - (slot & 3) : ((blockIdx.x >> 3) & 1) * 2 + 1;
-        set_prio(base_prio);
-    }
     if (tid < 256) {  // LUTs
         const u32 d = onehot_dword((u32)tid);
         luts.oh[tid] = d;
@@ -1984,7 +1967,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         finish_partial(p0, wv, av4, ap4);
     }
     GVL_STAMP(7);
-    set_prio(base_prio);
+    __builtin_amdgcn_s_setprio(0);
     // pass B: finish the class-0 trips.  Store addresses are a scalar base per trip plus a
     // per-lane offset that never changes: forward rows put lane l at +16*l, reverse-complemented
     // rows mirror the index (lane l at +16*(63-l) from the trip's lowest address).
