@@ -253,6 +253,14 @@ def _diffs_static(geno_offsets, geno_v_idxs, v_starts, ilens) -> HapsDevice:
     key = tuple(_key(a) for a in arrs) + (v_starts is None,)
     dev = _DIFF_CACHE.get(key)
     if dev is None:
+        # a full dataset that was uploaded with the same genotype CSR + variant table already has
+        # everything these entry points read: one HBM copy instead of two
+        for full in _STATIC_CACHE.values():
+            h = full._host_refs          # (geno_offsets, geno_v_idxs, v_starts, ilens, ...)
+            if (_key(h[0]), _key(h[1]), _key(h[3])) == key[:3] and (v_starts is None or _key(h[2]) == key[3]):
+                _DIFF_CACHE[key] = dev = full          # (alias: later calls hit directly)
+                break
+    if dev is None:
         n = len(ilens)
         dev = HapsDevice(ref=np.zeros(1, np.uint8), ref_offsets=np.array([0, 1], np.int64),
                          v_starts=np.zeros(n, np.int32) if v_starts is None else arrs[3], ilens=ilens,
@@ -298,23 +306,9 @@ _TRACK_CACHE: "OrderedDict[tuple, HapsDevice]" = OrderedDict()
 
 
 def _track_static(geno_offsets, geno_v_idxs, v_starts, ilens) -> HapsDevice:
-    """Realignment reads only the genotype CSR + v_starts / ilens."""
-    arrs = tuple(np.asarray(a) for a in (geno_offsets, geno_v_idxs, v_starts, ilens))
-    geno_offsets, geno_v_idxs, v_starts, ilens = arrs
-    key = tuple(_key(a) for a in arrs)
-    dev = _TRACK_CACHE.get(key)
-    if dev is None:
-        n = len(ilens)
-        dev = HapsDevice(ref=np.zeros(1, np.uint8), ref_offsets=np.array([0, 1], np.int64),
-                         v_starts=_req(v_starts, np.int32, "v_starts", 1), ilens=_req(ilens, np.int32, "ilens", 1),
-                         alt_alleles=np.zeros(1, np.uint8), alt_offsets=np.zeros(n + 1, np.int64),
-                         geno_offsets=_starts_stops(geno_offsets),
-                         geno_v_idxs=_req(geno_v_idxs, np.int32, "geno_v_idxs", 1), slot_records=False)
-        dev._host_refs = arrs
-        _TRACK_CACHE[key] = dev
-        while len(_TRACK_CACHE) > _STATIC_CACHE_MAX:
-            _TRACK_CACHE.popitem(last=False)
-    return dev
+    """Realignment reads only the genotype CSR + v_starts / ilens: the same device arrays as the
+    length-delta entry points in query mode (one HBM copy, shared with a full dataset when there is one)."""
+    return _diffs_static(geno_offsets, geno_v_idxs, v_starts, ilens)
 
 
 _ITV_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()
