@@ -244,7 +244,7 @@ class DeviceHapsDataset:
         return batch
 
     def to_dataloader(self, batch_size: int = 1, shuffle: bool = False, sampler=None, drop_last: bool = False,
-                      generator: torch.Generator | None = None, in_flight: int = 2, rank: int = 0,
+                      generator: torch.Generator | None = None, in_flight: int = 3, rank: int = 0,
                       world_size: int = 1, seed: int = 0, threaded: bool = False, group: int = 4,
                       python_loop: bool = False) -> "DeviceLoader":
         """``Dataset.to_dataloader`` (``_impl.py:1963-2072``) for device consumers.  With
@@ -364,8 +364,8 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
         return out
 
     def to_dataloader(self, batch_size: int = 1, shuffle: bool = False, sampler=None, drop_last: bool = False,
-                      generator=None, in_flight: int = 2, rank: int = 0, world_size: int = 1, seed: int = 0,
-                      threaded: bool = False, group: int = 2, python_loop: bool = False) -> "DeviceLoader":
+                      generator=None, in_flight: int = 3, rank: int = 0, world_size: int = 1, seed: int = 0,
+                      threaded: bool = False, group: int = 1, python_loop: bool = False) -> "DeviceLoader":
         """The native ring carries the tracks too (``gvl_tracks_batch`` per batch into the slot, per-batch
         FlankSample seeds computed on the device); ``python_loop=True`` (or a custom sampler) submits every
         batch from Python instead and lets it own its memory."""

@@ -10,13 +10,23 @@ from genvarloader_amd.loader import DeviceHapsDataset
 
 R, S, P, L = 200, int(os.environ.get("S", 2504)), 2, 2048
 bs = int(os.environ.get("BATCH", 2048))            # (region, sample) pairs per batch = 4096 windows
-rng = np.random.default_rng(20260802 + 5)
-st = synth.make_static(rng, (64 << 20,), indel_frac=0.15)
-t0 = time.time()
-full_regions, go, gv = synth.make_grid(rng, st, R, S, P, L)
-print(f"grid: {R}x{S}x{P} = {R*S*P} windows, CSR nnz {len(gv)} ({time.time()-t0:.1f} s to generate)")
-dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens, alt_alleles=st.alt_alleles,
-                 alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv, pad_char=st.pad_char)
+if os.environ.get("SCALE"):
+    # SCALE=hg38: the bench's genome-scale dataset (3.09 Gbp, 8.4 M regions x 1 sample x 2 haplotypes, 6.8 GB): an
+    # epoch of 16.8 M windows whose batches are COLD (every window read once per epoch)
+    g = synth.make_genome(os.environ["SCALE"], "cfg3", device="cuda")
+    dev = HapsDevice(**g.static_kwargs())
+    full_regions, S = g.full_regions.cpu().numpy(), 1
+    R = int(full_regions.shape[0])
+    print(f"genome-scale dataset: {R} regions x 1 sample x {P} = {R*P} windows per epoch")
+    os.environ.setdefault("REPS", "2")
+else:
+    rng = np.random.default_rng(20260802 + 5)
+    st = synth.make_static(rng, (64 << 20,), indel_frac=0.15)
+    t0 = time.time()
+    full_regions, go, gv = synth.make_grid(rng, st, R, S, P, L)
+    print(f"grid: {R}x{S}x{P} = {R*S*P} windows, CSR nnz {len(gv)} ({time.time()-t0:.1f} s to generate)")
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens, alt_alleles=st.alt_alleles,
+                     alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv, pad_char=st.pad_char)
 for det in (True, False):
     ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, jitter=0 if det else 16, deterministic=det, seed=1)
     combos = ((1, 1, None, False), (3, 1, None, False), (4, 1, None, False), (2, 4, None, False), (3, 4, None, False),
