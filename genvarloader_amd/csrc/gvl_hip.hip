@@ -90,6 +90,11 @@ __device__ __forceinline__ void store_f32x4(float *dst, float a, float b, float 
     v4f_t v = {a, b, c, d};
     __builtin_nontemporal_store(v, reinterpret_cast<v4f_a4 *>(dst));
 }
+// (write-back, not nontemporal: the painter's scratch track is read back by the realignment right away)
+__device__ __forceinline__ void store_f32x4_wb(float *dst, float a, float b, float c, float d) {
+    v4f_t v = {a, b, c, d};
+    *reinterpret_cast<v4f_a4 *>(dst) = v;
+}
 __device__ __forceinline__ void store_u32_unaligned(u8 *dst, u32 v) {
     __builtin_nontemporal_store(v, reinterpret_cast<u32_a1 *>(dst));
 }
@@ -2953,7 +2958,7 @@ __device__ __forceinline__ void paint_image(PaintImage &T, const int lane, const
             const float v0 = ix.x ? T.cv[ix.x - 1] : 0.0f, v1 = ix.y ? T.cv[ix.y - 1] : 0.0f;
             const float v2 = ix.z ? T.cv[ix.z - 1] : 0.0f, v3 = ix.w ? T.cv[ix.w - 1] : 0.0f;
             if (p + GROUP <= clen) {
-                store_f32x4(row + p, v0, v1, v2, v3);
+                store_f32x4_wb(row + p, v0, v1, v2, v3);
             } else {
                 if (p < clen) row[p] = v0;
                 if (p + 1 < clen) row[p + 1] = v1;
@@ -3202,7 +3207,7 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
                         }
                     }
                     if (p + GROUP <= clen) {
-                        store_f32x4(row + p, v[0], v[1], v[2], v[3]);
+                        store_f32x4_wb(row + p, v[0], v[1], v[2], v[3]);
                     } else {
                         row[p] = v[0];
                         if (p + 1 < clen) row[p + 1] = v[1];
