@@ -356,7 +356,7 @@ def test_haps_tracks_dataset_matches_oracle(oracle, dbg):
                                      base_seed=pinned, output_length=L, onehot=False, haps=True)
         seen = 0
         for batch in ds.to_dataloader(batch_size=7, shuffle=True, generator=torch.Generator().manual_seed(1),
-                                      python_loop=python_loop):
+                                      python_loop=python_loop, threaded=(strategy == 4 and not python_loop)):
             idx = batch.idx.cpu().numpy()
             r_idx, s_idx = np.unravel_index(idx, (R, S))
             regions = full_regions[r_idx]
@@ -498,7 +498,8 @@ def test_loader_ragged_and_annotated_modes(oracle, python_loop):
     # ragged AND annotated
     ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=-1, onehot=False, annotate=True)
     n = 0
-    for batch in ds.to_dataloader(batch_size=8, shuffle=True, seed=1, python_loop=python_loop, in_flight=2, group=1):
+    for batch in ds.to_dataloader(batch_size=8, shuffle=True, seed=1, python_loop=python_loop, in_flight=2, group=1,
+                                  threaded=not python_loop):          # (the library's producer thread submits the batches)
         idx = batch.idx.cpu().numpy()
         regions, goi, to_rc, shifts = request(idx)
         exp, av, ap, exp_off = oracle.reconstruct_annotated_haplotypes_fused(
