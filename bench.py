@@ -208,6 +208,7 @@ def main() -> None:
     ap.add_argument("--workload", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg4"])
     ap.add_argument("--scale", default="hg38", choices=["hg38", "small"],
                     help="dataset size: hg38 = 3.09 Gbp / > 1 GB of genotype records (cold inputs); small = 64 Mbp")
+    ap.add_argument("--out-slots", type=int, default=0, help="output buffers the steps rotate over (default: streams + 1 per batch of a launch)")
     ap.add_argument("--rotate", type=int, default=64, help="distinct batches the steps cycle through (1 = cache-hot)")
     ap.add_argument("--queries", type=int, default=None, help="override the number of queries in the dataset")
     ap.add_argument("--haps", action="store_true", help="also materialise haplotype bytes (h=1)")
@@ -286,8 +287,10 @@ def main() -> None:
     K = batches[0].n_rows                      # windows per step on this rank
     stream = torch.cuda.current_stream()
     streams = [stream] + [torch.cuda.Stream() for _ in range(max(0, args.streams - 1))]
-    G = max(1, min(8, args.many))
+    G = max(1, min(16, args.many))
     n_slots = (len(streams) + 1) * G           # an output slot per batch in flight (+1 launch being consumed)
+    if args.out_slots > 0:                     # (more slots than the 256 MiB Infinity Cache holds: see DESIGN 5)
+        n_slots = args.out_slots
     slots = [dev.alloc_output(batches[0], K * L, haps=args.haps, onehot=True) for _ in range(n_slots)]
     mean_v = float(np.mean([float((dev.geno_offsets[1][b.geno_offset_idx.reshape(-1)]
                                    - dev.geno_offsets[0][b.geno_offset_idx.reshape(-1)]).double().mean())

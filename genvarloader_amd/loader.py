@@ -245,13 +245,15 @@ class DeviceHapsDataset:
 
     def to_dataloader(self, batch_size: int = 1, shuffle: bool = False, sampler=None, drop_last: bool = False,
                       generator: torch.Generator | None = None, in_flight: int = 3, rank: int = 0,
-                      world_size: int = 1, seed: int = 0, threaded: bool = False, group: int = 4,
+                      world_size: int = 1, seed: int = 0, threaded: bool = False, group: int | None = None,
                       python_loop: bool = False) -> "DeviceLoader":
         """``Dataset.to_dataloader`` (``_impl.py:1963-2072``) for device consumers.  With
         ``world_size > 1`` the epoch is sharded across ranks like ``DistributedSampler``
         (:func:`genvarloader_amd.sharding.epoch_order`): same permutation on every rank, disjoint
-        strided shares, no collective.  ``group`` batches share one launch and ``in_flight`` such
-        groups are submitted ahead.  ``threaded=True``: a producer thread inside the library
+        strided shares, no collective.  ``group`` batches share one host call and one event pair (every
+        event between two kernels of a stream costs the GPU a few microseconds of idle queue) and
+        ``in_flight`` such groups are submitted ahead; ``group=None`` takes the largest of 16, 8, 4, 2, 1
+        whose ring of ``(in_flight + 1) * group`` output slots stays under 4 GiB.  ``threaded=True``: a producer thread inside the library
         submits them (launches overlap the consumer's own host work per batch)."""
         return DeviceLoader(self, batch_size, shuffle, sampler, drop_last, generator, in_flight, rank, world_size,
                             seed, threaded, group, python_loop=python_loop)
@@ -260,6 +262,55 @@ class DeviceHapsDataset:
 @dataclass
 class TrackBatch(Batch):
     tracks: torch.Tensor | None = None     # (b, n_tracks, P, L) f32, realigned to each haplotype
+
+
+class _EpochArrays:
+    """The epoch's request arrays (the native loop's epoch table) and order, as whole-epoch tensors."""
+    __slots__ = ("order", "regions", "goi", "shifts", "to_rc", "seeds", "bs", "P")
+
+
+class RingBatch:
+    """A batch of the native loop (ONE object per ring slot, handed out again when the slot comes round): the
+    outputs are views of the slot (valid until the next iteration), the
+    request arrays (``idx``, ``regions``, ``shifts``, ``geno_offset_idx``, ``to_rc``) are rows of the epoch table,
+    sliced when they are asked for -- an epoch of 245 batches does not pay for 1 200 tensor views up front.
+    Same attributes as :class:`Batch` / :class:`TrackBatch`."""
+    __slots__ = ("onehot", "haps", "out_offsets", "annot_v_idxs", "annot_ref_pos", "sizes", "tracks", "_ev", "_i", "_b")
+
+    def __init__(self, onehot, haps, out_offsets, annot_v_idxs, annot_ref_pos, sizes, tracks, ev, i, b):
+        self.onehot, self.haps, self.out_offsets = onehot, haps, out_offsets
+        self.annot_v_idxs, self.annot_ref_pos, self.sizes, self.tracks = annot_v_idxs, annot_ref_pos, sizes, tracks
+        self._ev, self._i, self._b = ev, i, b
+
+    def _rows(self, t, per=1):
+        lo = self._i * self._ev.bs * per
+        return t[lo:lo + self._b * per]
+
+    @property
+    def idx(self):
+        return self._rows(self._ev.order)
+
+    @property
+    def regions(self):
+        return self._rows(self._ev.regions)
+
+    @property
+    def shifts(self):
+        return self._rows(self._ev.shifts)
+
+    @property
+    def geno_offset_idx(self):
+        return self._rows(self._ev.goi)
+
+    @property
+    def to_rc(self):
+        return None if self._ev.to_rc is None else self._rows(self._ev.to_rc, self._ev.P)
+
+    @property
+    def base_seed(self):
+        """The FlankSample base seed of this batch's tracks: a device scalar (per-batch mode) or the pinned int."""
+        s = self._ev.seeds
+        return s[self._i] if isinstance(s, torch.Tensor) else s
 
 
 class DeviceHapsTracksDataset(DeviceHapsDataset):
@@ -515,10 +566,10 @@ class DeviceLoader:
     its memory."""
 
     def __init__(self, ds: DeviceHapsDataset, batch_size=1, shuffle=False, sampler=None, drop_last=False,
-                 generator=None, in_flight=2, rank=0, world_size=1, seed=0, threaded=False, group=4,
+                 generator=None, in_flight=2, rank=0, world_size=1, seed=0, threaded=False, group=None,
                  python_loop=False):
         self.threaded = bool(threaded)
-        self.group = max(1, min(8, int(group)))
+        self.group = None if group is None else max(1, min(16, int(group)))
         self.python_loop = bool(python_loop)
         self.ds, self.batch_size, self.shuffle, self.drop_last = ds, int(batch_size), shuffle, drop_last
         self.sampler, self.generator = sampler, generator
@@ -540,6 +591,12 @@ class DeviceLoader:
 
         ds, d = self.ds, self.ds.dev.device
         lib = ds.dev.lib
+        if self.group is None:
+            self.group = 1
+            for g in (16, 8, 4, 2):              # the largest group whose ring stays under 4 GiB (and 64 slots)
+                if (self.in_flight + 1) * g <= 64 and (self.in_flight + 1) * g * self._slot_bytes(g) <= (4 << 30):
+                    self.group = g
+                    break
         n_slots = (self.in_flight + 1) * self.group
         cfg = GvlLoaderConfig(
             full_regions=ds.full_regions.data_ptr(), n_regions=ds.n_regions, n_samples=ds.n_samples, ploidy=ds.ploidy,
@@ -568,6 +625,23 @@ class DeviceLoader:
             _lib.check(lib.gvl_loader_create(C.byref(ds.dev.c), C.byref(cfg), C.byref(handle)))
         self._native = dict(handle=handle, arenas=arenas, parts=[int(x) for x in parts], cfg=cfg, ptrs=ptrs,
                             out=GvlLoaderBatch(), views={})
+
+    def _slot_bytes(self, group: int) -> int:
+        """Bytes of one ring slot for this dataset (gvl_loader_slot_bytes on a probe configuration)."""
+        import ctypes as C
+
+        from . import _lib
+        from ._lib import GvlLoaderConfig
+
+        ds = self.ds
+        cfg = GvlLoaderConfig(n_regions=ds.n_regions, n_samples=ds.n_samples, ploidy=ds.ploidy, batch_size=self.batch_size,
+                              output_length=ds.output_length, want_haps=int(ds.haps), want_onehot=int(ds.onehot),
+                              onehot_layout=_lib.GVL_ONEHOT_LC if ds.layout == "lc" else _lib.GVL_ONEHOT_CL,
+                              want_annot=int(ds.annotate), max_row_len=ds.max_row_len() if ds.ragged else 0, group=group)
+        if len(getattr(ds, "_itv", ())):
+            cfg.n_tracks, cfg.scratch_stride = len(ds._itv), ds._stride
+        parts = (C.c_int64 * _lib.LOADER_SLOT_PARTS)()
+        return max(1, int(ds.dev.lib.gvl_loader_slot_bytes(C.byref(cfg), parts)))
 
     def _slot_views(self, slot: int, b: int) -> Batch:
         nat, ds = self._native, self.ds
@@ -630,9 +704,10 @@ class DeviceLoader:
         seeds = None
         if int(nat["cfg"].n_tracks) and int(nat["cfg"].track_seed_mode) == 1:
             seeds = part(4, torch.int64, (-(-n // bs),))      # (u64 bit patterns; one device scalar per batch)
-        if n == 0:
-            return tab, (), (), (), (), None
-        return tab, reg.split(bs), goi.split(bs), sh.split(bs), (rc.split(bs * P) if ds.rc_neg else None), seeds
+        ev = _EpochArrays()
+        ev.regions, ev.goi, ev.shifts, ev.to_rc, ev.seeds = reg, goi, sh, (rc if ds.rc_neg else None), seeds
+        ev.bs, ev.P = bs, P
+        return tab, ev
 
     def _iter_native(self):
         import ctypes as C
@@ -660,21 +735,23 @@ class DeviceLoader:
                                     device=d, generator=g)
             self.epoch += 1
             n = int(order.numel())
-            tab, reg_v, goi_v, sh_v, rc_v, seeds_v = self._epoch_table(n)
+            tab, ev = self._epoch_table(n)
+            ev.order = order
+            if ev.seeds is None:
+                ev.seeds = getattr(ds, "base_seed", None)
             _lib.check(lib.gvl_loader_start_epoch(handle, C.c_void_p(order.data_ptr()), C.c_int64(n),
                                                   C.c_int32(int(self.drop_last)), C.c_void_p(tab.data_ptr()),
                                                   C.c_void_p(cur.cuda_stream)))
             nat["order"] = order                       # keep the epoch order alive
             nxt, ref_out, bs = lib.gvl_loader_next, C.byref(out), self.batch_size
             nxt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]          # plain ints in, no wrapper objects per call
-            idx_views = order.split(bs) if n else ()          # one C++ loop instead of a slice per batch
             # the consumer's CURRENT stream, read every iteration (it may change), through the raw getter
             raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
             dev_i = d.index if d.index is not None else torch.cuda.current_device()
             if raw_stream is None:
                 raw_stream = lambda i_: torch.cuda.current_stream(i_).cuda_stream
             views, h = self._slot_views, handle.value
-            none_rc = rc_v is None
+            ring = nat.setdefault("ring_batches", {})
             i = 0
             while True:
                 rc = nxt(h, raw_stream(dev_i), ref_out)
@@ -682,13 +759,12 @@ class DeviceLoader:
                     _lib.check(rc)
                 if out.slot < 0:
                     return
-                oh, hp, oo, av, ap, tr, sz = views(out.slot, out.batch)
-                if tr is None:
-                    batch = Batch(oh, hp, idx_views[i], reg_v[i], sh_v[i], goi_v[i], None if none_rc else rc_v[i], oo, av, ap, sz)
-                else:
-                    batch = TrackBatch(oh, hp, idx_views[i], reg_v[i], sh_v[i], goi_v[i], None if none_rc else rc_v[i],
-                                       tracks=tr)
-                    batch.base_seed = (seeds_v[i] if seeds_v is not None else ds.base_seed)
+                key = (out.slot, out.batch)
+                batch = ring.get(key)
+                if batch is None:            # one object per (slot, size): its outputs never change, its rows do
+                    oh, hp, oo, av, ap, tr, sz = views(*key)
+                    batch = ring[key] = RingBatch(oh, hp, oo, av, ap, sz, tr, ev, i, key[1])
+                batch._ev, batch._i = ev, i
                 i += 1
                 yield batch
 

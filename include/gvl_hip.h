@@ -200,7 +200,7 @@ int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *ou
  * (One launch for all n batches, blockIdx.z = batch, was built and measured: the per-batch
  * arguments then sit behind an index in the kernarg segment, which cost 1.2-1.8 us per batch, and
  * the batches overlapped no better than launches on separate streams -- DESIGN.md 4.1.) */
-#define GVL_MANY_MAX 8
+#define GVL_MANY_MAX 16
 int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_out *outs,
                          int32_t n, void *stream);
 

@@ -143,9 +143,9 @@ def test_native_loop_ring_reuse_drop_last_and_epochs(oracle):
         st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, L, None, None, np.repeat(full_regions[r_idx, 3] == -1, P),
         False)
     exp = exp.reshape(R * S, P, L)
-    for drop_last in (False, True):
+    for drop_last, group in ((False, 2), (True, 1), (False, None)):      # (None: the largest group the ring budget allows)
         dl = ds.to_dataloader(batch_size=3, shuffle=True, generator=torch.Generator().manual_seed(5), drop_last=drop_last,
-                              in_flight=2)
+                              in_flight=2, group=group)
         assert len(dl) == (R * S) // 3 + (0 if drop_last or (R * S) % 3 == 0 else 1)
         for epoch in range(2):
             copies, idxs = [], []

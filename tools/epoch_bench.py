@@ -29,11 +29,14 @@ else:
                      alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv, pad_char=st.pad_char)
 for det in (True, False):
     ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, jitter=0 if det else 16, deterministic=det, seed=1)
-    combos = ((1, 1, None, False), (3, 1, None, False), (4, 1, None, False), (2, 4, None, False), (3, 4, None, False),
-              (4, 4, None, False), (4, 2, None, False), (4, 4, None, True), (3, 4, None, True),
-              (3, 4, torch.Generator().manual_seed(0), False))
+    combos = ((1, 1, None, False), (3, 1, None, False), (2, 4, None, False), (3, 4, None, False), (4, 4, None, False),
+              (3, 4, None, True), (3, 8, None, False), (3, 16, None, False), (3, 16, None, True), (2, 16, None, False),
+              (3, None, None, False), (3, 16, torch.Generator().manual_seed(0), False))      # (group None = the loader's default)
     if os.environ.get("QUICK"):
         combos = ((4, 4, None, False),)
+    if os.environ.get("COMBOS"):          # e.g. COMBOS=3x4,3x8t,2x8  (in_flight x group, t = producer thread)
+        combos = tuple((int(c.rstrip("t").split("x")[0]), int(c.rstrip("t").split("x")[1]), None, c.endswith("t"))
+                       for c in os.environ["COMBOS"].split(","))
     for in_flight, group, gen, thr in combos:
         dl = ds.to_dataloader(batch_size=bs, shuffle=True, generator=gen, in_flight=in_flight, threaded=thr, group=group)
         for rep in range(int(os.environ.get("REPS", 4))):                        # first pass warms up
