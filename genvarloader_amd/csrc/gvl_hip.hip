@@ -1183,6 +1183,13 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     // slot lines (its own reads would otherwise sit in front of them: loads return in order)
     const bool spec_late = use_srec && wave == 0;
     if (!spec_late) issue_spec();
+#ifdef GVL_DIAG
+    // diagnostic (GVL_DBG 256): when do wave 1's speculative reference bytes arrive?  (stamp 15)
+    if (A.stamps && (A.dbg & 256) && wave == 1) {
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0) A.stamps[((u64)blockIdx.x * gridDim.y + blockIdx.y) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 
     // Who plans a row: see below (SNP-only rows plan themselves, the first wave that holds a row with
     // an indel plans all such rows of the workgroup).  Measured and dropped in round 2: wave 0 planning

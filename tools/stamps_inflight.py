@@ -45,5 +45,8 @@ for j, n in enumerate(names):
 lw = np.concatenate([s[:, 11] - s[:, 0] for s in acc]); ew = np.concatenate([s[:, 12] - s[:, 0] for s in acc])
 print(f"  {'last wave of the workgroup':28s} {np.median(lw):8.0f} {np.percentile(lw, 90):8.0f}")
 print(f"  {'first wave of the workgroup':28s} {np.median(ew):8.0f} {np.percentile(ew, 90):8.0f}")
+if dbg & 256:
+    ra = np.concatenate([s[:, 15] - s[:, 0] for s in acc]); ra = ra[ra > 0]
+    print(f"  {'wave 1: reference bytes back':28s} {np.median(ra):8.0f} {np.percentile(ra, 90):8.0f}   (diagnostic wait, GVL_DBG 256)")
 span = np.array([s[:, 11].max() - s[:, 0].min() for s in acc]); spread = np.array([s[:, 0].max() - s[:, 0].min() for s in acc])
 print(f"  launch span (first start -> last end) median {np.median(span):.0f} ns; workgroup starts spread over {np.median(spread):.0f} ns")
