@@ -3634,7 +3634,9 @@ static int launch_recon(const ReconArgs &A, int chunks, int variant, void *strea
     const i64 grid = (A.n_rows + WG_WAVES - 1) / WG_WAVES;
     if (grid <= 0) return GVL_OK;
     recon_fn fn = recon_table(variant & 3, (variant & 4) != 0, (variant & 8) != 0);
-    fn<<<dim3((unsigned)grid, (unsigned)chunks), dim3(WG_THREADS), 0, (hipStream_t)stream>>>(A);
+    // GVL_EXTRA_LDS=<bytes>: occupancy experiments (unused dynamic LDS caps the workgroups per CU)
+    static const unsigned extra_lds = [] { const char *e = getenv("GVL_EXTRA_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
+    fn<<<dim3((unsigned)grid, (unsigned)chunks), dim3(WG_THREADS), extra_lds, (hipStream_t)stream>>>(A);
     return check_launch("gvl_reconstruct");
 }
 
