@@ -46,6 +46,43 @@ __global__ __launch_bounds__(256) void k_win(const u8 *ref, const i64 *starts, u
 // reads 8 rows' slot indices (coalesced, cold), then their 128-byte slot lines (random, cold) and parks them
 // in LDS; the 8 waves read their windows meanwhile (independent of the slot line), wait for the barrier, and
 // stream the one-hot out.
+// k_shape with the request entries spread over `NARR` more cold arrays (regions / shifts / to_rc / ... of the C-ABI):
+// wave 0 reads 8 rows' entries from each before it can go for the slot lines
+template <int NARR>
+__global__ __launch_bounds__(512) void k_shape_req(const u8 *ref, const i64 *starts, const i64 *slot_idx, const u32x4 *slots,
+                                                   const int *req, i64 req_stride, u8 *out, int L, int rows) {
+    __shared__ u32 lut[256];
+    __shared__ u32x4 lrec[64];
+    __shared__ int dep[8];
+    if (threadIdx.x < 256) lut[threadIdx.x] = oh(threadIdx.x);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const i64 row = (i64)blockIdx.x * 8 + wave;
+    if (wave == 0) {
+        const i64 r8 = (i64)blockIdx.x * 8 + (lane >> 3);
+        int acc = 0;
+#pragma unroll
+        for (int a = 0; a < NARR; ++a) acc += req[(i64)a * req_stride + (r8 < rows ? r8 : 0)];      // level 1: NARR small reads
+        const i64 si = slot_idx[r8 < rows ? r8 : 0] + (acc & 0);                                      // (level 2 depends on them)
+        lrec[lane] = slots[si * 8 + (lane & 7)];
+        if (lane < 8) dep[lane] = acc & 0;
+    }
+    __syncthreads();
+    const i64 s = starts[row < rows ? row : 0] + dep[wave];
+    u32 w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { u32 v; __builtin_memcpy(&v, ref + s + u * 256 + 4 * lane, 4); w[u] = v; }
+    if (row >= rows) return;
+    const u32 salt = lrec[wave * 8 + (lane & 7)].x & 0x20202020u;
+    u8 *o = out + row * 4 * (i64)L;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int p = u * 256 + 4 * lane;
+        const u32 x = w[u] | salt;
+        u32x4 v = {lut[x & 0xFF], lut[(x >> 8) & 0xFF], lut[(x >> 16) & 0xFF], lut[x >> 24]};
+        __builtin_nontemporal_store(v, (u32x4 *)(o + 4 * (i64)p));
+    }
+}
+
 __global__ __launch_bounds__(512) void k_shape(const u8 *ref, const i64 *starts, const i64 *slot_idx, const u32x4 *slots,
                                                u8 *out, int L, int rows, int hold_ticks = 0, int hold_before_loads = 0) {
     __shared__ u32 lut[256];
@@ -130,6 +167,34 @@ int main(int argc, char **argv) {
             const float t5 = timeit([&](int i, hipStream_t s) { k_shape<<<rows / 8, 512, 0, s>>>(ref, starts + (size_t)(i % T) * rows, slot_idx + (size_t)(i % T) * rows, slots, out[i & 3], L, rows); }, 4);
             printf("%6lld MB  %-7s %9.2f us %9.2f us %9.2f us %11.2f us %11.2f us %11.2f us\n", fp >> 20, aligned ? "2 KB" : "byte", t0, t1, t2, t3, t4, t5);
         }
+    }
+    // the request entries as 0 / 2 / 4 separate cold arrays in front of the slot lines; window reads AFTER the barrier
+    {
+        int *req; const i64 req_stride = (i64)T * rows;
+        CK(hipMalloc(&req, (size_t)4 * req_stride * 4)); CK(hipMemset(req, 0, (size_t)4 * req_stride * 4));
+        std::vector<i64> hs((size_t)T * rows);
+        const i64 fp = max_fp < (3072ll << 20) ? max_fp : (3072ll << 20);
+        for (size_t r = 0; r < hs.size(); ++r) { i64 s = (i64)(rng() % (unsigned long long)(fp - L - 64)); hs[r] = (r & 1) ? hs[r - 1] : s; }
+        CK(hipMemcpy(starts, hs.data(), hs.size() * 8, hipMemcpyHostToDevice));
+        printf("kernel shape with the window reads behind P1 (as in the reconstruct kernel) and N more cold request arrays: 1 / 4 streams\n");
+        auto run = [&](auto launch) {
+            float t[2];
+            for (int k = 0; k < 2; ++k) {
+                const int ns = k ? 4 : 1;
+                hipEvent_t a, b2; CK(hipEventCreate(&a)); CK(hipEventCreate(&b2));
+                for (int i = 0; i < 64; ++i) launch(i, st[i % ns]);
+                CK(hipDeviceSynchronize());
+                CK(hipEventRecord(a, st[0]));
+                for (int i = 0; i < 640; ++i) launch(i, st[i % ns]);
+                for (int i = 1; i < ns; ++i) { hipEvent_t ev; CK(hipEventCreate(&ev)); CK(hipEventRecord(ev, st[i])); CK(hipStreamWaitEvent(st[0], ev, 0)); }
+                CK(hipEventRecord(b2, st[0])); CK(hipEventSynchronize(b2));
+                float ms; CK(hipEventElapsedTime(&ms, a, b2)); t[k] = ms / 640 * 1000.f;
+            }
+            printf("%7.2f us  %7.2f us\n", t[0], t[1]);
+        };
+        printf("  N = 0: "); run([&](int i, hipStream_t s_) { k_shape_req<0><<<rows / 8, 512, 0, s_>>>(ref, starts + (size_t)(i % T) * rows, slot_idx + (size_t)(i % T) * rows, slots, req + (size_t)(i % T) * rows, req_stride, out[i & 3], L, rows); });
+        printf("  N = 2: "); run([&](int i, hipStream_t s_) { k_shape_req<2><<<rows / 8, 512, 0, s_>>>(ref, starts + (size_t)(i % T) * rows, slot_idx + (size_t)(i % T) * rows, slots, req + (size_t)(i % T) * rows, req_stride, out[i & 3], L, rows); });
+        printf("  N = 4: "); run([&](int i, hipStream_t s_) { k_shape_req<4><<<rows / 8, 512, 0, s_>>>(ref, starts + (size_t)(i % T) * rows, slot_idx + (size_t)(i % T) * rows, slots, req + (size_t)(i % T) * rows, req_stride, out[i & 3], L, rows); });
     }
     // waves that live longer (3 GB footprint, byte-aligned windows, 4 streams)
     {
