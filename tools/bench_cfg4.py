@@ -23,6 +23,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 HBM_PEAK_GBS = 8000.0
 
 
+def _traffic(key):
+    """Memory-side bytes per launch from the PMC passes (profiles/traffic.json), or None."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")) as f:
+            return json.load(f).get(key)
+    except Exception:
+        return None
+
+
 def build(device, R=16, S=64, P=2, L=131072, seed=20260802 + 4):
     import torch
 
@@ -184,7 +193,7 @@ def main(args) -> None:
                        "loop": "native ring (gvl_loader_*)" if loop == "native" else "python submit loop", "parallelism": f"world_size {world}: one batch per rank per step"},
             "timing": {"how": "median of K-step regions between barrier + synchronize, host clock", "regions": len(spans)},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "reconstruct_kernel<OH_LC, haps=true, annot=false>", "kernel_ms": t_recon,
+                         "traffic": _traffic("cfg4"), "kernel": "reconstruct_kernel<OH_LC, haps=true, annot=false>", "kernel_ms": t_recon,
                          "kernel_ms_how": "HIP events around 30 back-to-back launches on one stream",
                          "algorithmic_bytes_per_launch": hap_bytes,
                          "step_GBps": (hap_bytes + realign_bytes + paint_bytes) / (ms_step * 1e-3) / 1e9},
