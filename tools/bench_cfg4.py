@@ -78,7 +78,7 @@ def main(args) -> None:
         dist.init_process_group(backend, **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
     R, S, P, L = 16, 64, 2, 131072
     st, dev, ds, tracks, mean_v = build(f"cuda:{local}", R, S, P, L, seed=20260802 + 4 + 1000 * rank)
-    bs = 128                                                    # queries per batch = 256 windows
+    bs = int(os.environ.get("GVL_CFG4_BS", 128))                # queries per batch = 256 windows
     order = np.random.default_rng(1).permutation(R * S)
     batches = [torch.from_numpy(order[i:i + bs].astype(np.int64)).cuda() for i in range(0, len(order), bs)]
     nb = len(batches)
