@@ -2976,39 +2976,11 @@ __device__ __forceinline__ void paint_image(PaintImage &T, const int lane, const
 }
 
 
-__global__ __launch_bounds__(256) void intervals_to_tracks_kernel(
-    const i64 *offset_idxs, const int *starts, i64 starts_stride, i64 n_queries, const int *itv_starts,
-    const int *itv_ends, const float *itv_values, const i64 *itv_offsets, const int *pmax, float *out,
-    const i64 *out_offsets, int chunk_len, const PaintTodo *chunk_todo) {
-    __shared__ PaintImage image;
-    const i64 q = blockIdx.y;
-    if (q >= n_queries) return;
-    // (chunk mode: almost every block has nothing to do -- look at its record before anything else)
-    if (chunk_todo && chunk_todo[q * gridDim.x + blockIdx.x].flag == 0) return;
-    const i64 o0 = out_offsets[q];
-    const i64 length = out_offsets[q + 1] - o0;
-    const i64 idx = offset_idxs[q];
-    const i64 s0 = itv_offsets[idx], e0 = itv_offsets[idx + 1];
-    const i64 qs = starts[q * starts_stride];
-    // chunk mode (after the tiled kernel): block = one chunk, only the chunks it left behind;
-    // otherwise a grid-stride loop over the whole row
-    i64 j_begin = (i64)blockIdx.x * blockDim.x + threadIdx.x, j_end = length, j_step = (i64)gridDim.x * blockDim.x;
-    if (chunk_todo) {
-        const PaintTodo td = chunk_todo[q * gridDim.x + blockIdx.x];
-        if (td.flag == 0) return;
-        if (td.flag == 2) {      // overlapping candidates: wave 0 paints the chunk into the LDS image
-            if (threadIdx.x < WAVE) {
-                const i64 c0 = (i64)blockIdx.x * chunk_len;
-                const i64 c1 = c0 + chunk_len < length ? c0 + chunk_len : length;
-                paint_image(image, (int)threadIdx.x, td.lo_c, td.n_c, qs, c0, (int)(c1 - c0), itv_starts, itv_ends, itv_values,
-                            out + o0 + c0);
-            }
-            return;
-        }
-        j_begin = (i64)blockIdx.x * chunk_len + threadIdx.x;
-        j_end = ((i64)blockIdx.x + 1) * chunk_len < length ? ((i64)blockIdx.x + 1) * chunk_len : length;
-        j_step = blockDim.x;
-    }
+// values [j_begin, j_end) (step j_step) of query q, one thread per value: binary search + walk-back, cut short by
+// the running maximum of ends where nothing covers the position
+__device__ __forceinline__ void paint_values(const i64 j_begin, const i64 j_end, const i64 j_step, const i64 s0, const i64 e0,
+                                             const i64 qs, const int *itv_starts, const int *itv_ends, const float *itv_values,
+                                             const int *pmax, float *row) {
     for (i64 j = j_begin; j < j_end; j += j_step) {
         // c = last interval with start - qs <= j  (intervals are sorted by start)
         i64 lo = s0, hi = e0;   // first interval with start - qs > j
@@ -3022,7 +2994,56 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_kernel(
                 if ((i64)itv_ends[c] - qs > j) { v = itv_values[c]; break; }
             }
         }
-        __builtin_nontemporal_store(v, out + o0 + j);
+        __builtin_nontemporal_store(v, row + j);
+    }
+}
+
+// Two modes.  chunk_todo == NULL: the whole painting, grid (x, n_queries), a grid-stride loop over each row.
+// chunk_todo != NULL (after the tiled kernel): only the chunks it left behind.  Almost every chunk is done by then,
+// so a workgroup looks at 256 records at once (one per thread, grid = records / 256: 33 workgroups for cfg4 instead
+// of 8 320) and works through the few that are flagged: 1 = per-value painting by the whole workgroup, 2 =
+// overlapping candidates, wave 0 paints the chunk into the LDS image.
+__global__ __launch_bounds__(256) void intervals_to_tracks_kernel(
+    const i64 *offset_idxs, const int *starts, i64 starts_stride, i64 n_queries, const int *itv_starts,
+    const int *itv_ends, const float *itv_values, const i64 *itv_offsets, const int *pmax, float *out,
+    const i64 *out_offsets, int chunk_len, const PaintTodo *chunk_todo, i64 n_chunks) {
+    __shared__ PaintImage image;
+    __shared__ int flags[256];
+    if (!chunk_todo) {
+        const i64 q = blockIdx.y;
+        if (q >= n_queries) return;
+        const i64 o0 = out_offsets[q];
+        const i64 idx = offset_idxs[q];
+        paint_values((i64)blockIdx.x * blockDim.x + threadIdx.x, out_offsets[q + 1] - o0, (i64)gridDim.x * blockDim.x, itv_offsets[idx],
+                     itv_offsets[idx + 1], starts[q * starts_stride], itv_starts, itv_ends, itv_values, pmax, out + o0);
+        return;
+    }
+    const i64 total = n_chunks * n_queries;
+    const i64 rec0 = (i64)blockIdx.x * 256;
+    const int mine = rec0 + threadIdx.x < total ? chunk_todo[rec0 + threadIdx.x].flag : 0;
+    flags[threadIdx.x] = mine;
+    if (!__syncthreads_or(mine != 0)) return;
+    for (int r = 0; r < 256; ++r) {
+        const int flag = flags[r];              // (uniform)
+        if (flag == 0) continue;
+        const i64 rec = rec0 + r;
+        const i64 q = rec / n_chunks, chunk = rec - q * n_chunks;
+        const PaintTodo td = chunk_todo[rec];
+        const i64 o0 = out_offsets[q];
+        const i64 length = out_offsets[q + 1] - o0;
+        const i64 idx = offset_idxs[q];
+        const i64 qs = starts[q * starts_stride];
+        const i64 c0 = chunk * chunk_len;
+        const i64 c1 = c0 + chunk_len < length ? c0 + chunk_len : length;
+        if (flag == 2) {
+            if (threadIdx.x < WAVE)
+                paint_image(image, (int)threadIdx.x, td.lo_c, td.n_c, qs, c0, (int)(c1 - c0), itv_starts, itv_ends, itv_values,
+                            out + o0 + c0);
+        } else {
+            paint_values(c0 + threadIdx.x, c1, blockDim.x, itv_offsets[idx], itv_offsets[idx + 1], qs, itv_starts, itv_ends,
+                         itv_values, pmax, out + o0);
+        }
+        __syncthreads();                        // the image is reused by the next flagged chunk
     }
 }
 
@@ -3904,15 +3925,15 @@ static int paint_launch(const int64_t *offset_idxs, const int32_t *starts, int64
             (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
             (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, (int)n_chunks, todo, X,
             (debug_flags() & 8192) ? 1 : 0);
-        intervals_to_tracks_kernel<<<dim3((unsigned)n_chunks, (unsigned)n_queries), dim3(256), 0, s>>>(
+        intervals_to_tracks_kernel<<<dim3((unsigned)((n_chunks * n_queries + 255) / 256)), dim3(256), 0, s>>>(
             (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
-            (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, todo);
+            (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, todo, n_chunks);
     } else {
         i64 gx = (max_row_len + 255) / 256;
         if (gx > 1024) gx = 1024;
         intervals_to_tracks_kernel<<<dim3((unsigned)gx, (unsigned)n_queries), dim3(256), 0, s>>>(
             (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
-            (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, nullptr);
+            (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, nullptr, (i64)0);
     }
     return check_launch("gvl_intervals_to_tracks");
 }
