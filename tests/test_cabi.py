@@ -98,3 +98,35 @@ def test_no_cpu_fallback_and_oracle_isolation():
             "except _lib.GvlError as e: print('RAISED')")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=REPO)
     assert r.stdout.strip() == "RAISED", r.stdout + r.stderr
+
+
+def test_loader_slot_and_table_layout(lib):
+    """gvl_loader_slot_bytes / gvl_loader_table_bytes are pure host arithmetic: the parts of a ring slot for the
+    reference loader's output kinds (fixed, annotated, ragged, haplotypes + tracks) and of the epoch table."""
+    from genvarloader_amd import _lib
+
+    def slot(**kw):
+        cfg = _lib.GvlLoaderConfig(n_regions=10, n_samples=4, ploidy=2, batch_size=8, **kw)
+        parts = (C.c_int64 * _lib.LOADER_SLOT_PARTS)()
+        lib.gvl_loader_slot_bytes.restype = C.c_int64
+        return int(lib.gvl_loader_slot_bytes(C.byref(cfg), parts)), [int(x) for x in parts]
+
+    up = lambda x: (x + 255) & ~255
+    K, L = 16, 300
+    n, p = slot(output_length=L, want_onehot=1, want_haps=1)
+    assert p[0] == 0 and p[1] == up(4 * K * L) and n == up(4 * K * L) + up(K * L) + up(8 * (K + 1)) + 256
+    n_a, p_a = slot(output_length=L, want_annot=1)                     # annotations imply the haplotype bytes
+    assert n_a == up(K * L) + up(8 * (K + 1)) + 2 * up(4 * K * L) + 256 and p_a[8] - p_a[7] == up(4 * K * L)
+    n_r, _ = slot(output_length=-1, max_row_len=500, want_haps=1, deterministic=1)
+    assert n_r == up(K * 500) + up(8 * (K + 1)) + 256
+    assert slot(output_length=-1, want_haps=1)[0] <= 0                 # ragged rows need a bound
+    lib.gvl_tracks_scratch_bytes.restype = C.c_int64
+    scr = int(lib.gvl_tracks_scratch_bytes(C.c_int64(8), C.c_int64(2), C.c_int64(700)))
+    n_t, p_t = slot(output_length=L, want_haps=1, n_tracks=3, scratch_stride=700)
+    assert p_t[10] - p_t[9] == up(4 * 3 * K * L) and p_t[11] - p_t[10] == up(scr)
+    cfg = _lib.GvlLoaderConfig(ploidy=2, batch_size=8)
+    po = (C.c_int64 * _lib.LOADER_TABLE_PARTS)()
+    lib.gvl_loader_table_bytes.restype = C.c_int64
+    nb = int(lib.gvl_loader_table_bytes(C.byref(cfg), C.c_int64(100), po))
+    assert [int(x) for x in po] == [0, up(1600), up(1600) + up(1600), up(1600) + up(1600) + up(800), up(1600) + up(1600) + up(800) + 256]
+    assert nb == int(po[4]) + up(8 * 13)
