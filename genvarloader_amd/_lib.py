@@ -27,6 +27,8 @@ SYMBOLS = (
     "gvl_pack_variants",
     "gvl_pack_genotypes",
     "gvl_pack_slots",
+    "gvl_ref4_bytes",
+    "gvl_pack_reference",
     "gvl_reconstruct",
     "gvl_reconstruct_many",
     "gvl_get_diffs_sparse",
@@ -54,7 +56,7 @@ SYMBOLS = (
     "gvl_loader_destroy",
 )
 
-ABI_VERSION = 4          # include/gvl_hip.h: GVL_ABI_VERSION
+ABI_VERSION = 5          # include/gvl_hip.h: GVL_ABI_VERSION
 GVL_ONEHOT_LC = 0
 GVL_ONEHOT_CL = 1
 
@@ -69,7 +71,7 @@ class GvlStatic(C.Structure):
         ("n_variants", _i64), ("alt_len", _i64), ("vrec", _vp),
         ("geno_o_starts", _vp), ("geno_o_stops", _vp), ("n_geno_offsets", _i64),
         ("geno_v_idxs", _vp), ("n_geno", _i64), ("pad_char", C.c_uint8), ("geno_rec", _vp),
-        ("slot_rec", _vp),
+        ("slot_rec", _vp), ("ref4", _vp),
     ]
 
 
@@ -163,11 +165,14 @@ def load() -> C.CDLL:
         fn = getattr(lib, name, None)
         if fn is None:
             raise GvlError(f"{p} does not export {name}")
-        if name not in ("gvl_last_error", "gvl_loader_slot_bytes", "gvl_loader_table_bytes", "gvl_tracks_scratch_bytes"):
+        if name not in ("gvl_last_error", "gvl_loader_slot_bytes", "gvl_loader_table_bytes", "gvl_tracks_scratch_bytes",
+                        "gvl_ref4_bytes"):
             fn.restype = C.c_int
     lib.gvl_loader_slot_bytes.restype = C.c_int64
     lib.gvl_loader_table_bytes.restype = C.c_int64
     lib.gvl_tracks_scratch_bytes.restype = C.c_int64
+    lib.gvl_ref4_bytes.restype = C.c_int64
+    lib.gvl_ref4_bytes.argtypes = [C.c_int64]
     _LIB = lib
     return lib
 

@@ -171,6 +171,7 @@ struct ReconArgs {
     u8 *haps; u8 *onehot; int *av; int *ap; i64 *out_offsets_w;
     u64 *stamps;        // diagnostic builds (-DGVL_DIAG): per-workgroup phase time stamps
     int *async_err;     // host-mapped word: set when the launch finds a row longer than the max_row_len hint
+    const u8 *ref4;     // nibble-packed reference (gvl_static.ref4): read by recon_lean_kernel only
 };
 
 // Per-wave mirror of the segment table + staging, used only by "general" trips.
@@ -666,6 +667,7 @@ __device__ __forceinline__ int wave_scan_exclusive(int v, int &inclusive) {
 // ---------------------------------------------------------------------------------
 struct RowIn {
     i64 c_s, R, ref_start, shift, o_s, keep_off, row_base;
+    int k;                       // the row (list mode: rows of a workgroup are not consecutive)
     int n_var, L, rc, flags;     // flags: 1 = no work (row out of range / chunk past the row), 2 = scalar path, 4 = zero fill, 8 = packable (<= 8 variants),
                                  // 16 = records come from the slot-major table (o_s = the slot, n_var = 8 until the line is read)
 };
@@ -978,16 +980,40 @@ __device__ __forceinline__ void packed_plan(const ReconArgs &A, const RowIn *rin
 #define GVL_STAMP(i) do { } while (0)
 #endif
 
-template <int OH, bool HAPS, bool ANNOT>
-__global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void reconstruct_kernel(const ReconArgs A) {
-    __shared__ Luts luts;
-    __shared__ SegMirror mirror[WG_WAVES];
-    __shared__ Stage<ANNOT> stage[WG_WAVES];
-    __shared__ RowIn rin[WG_WAVES];
-    __shared__ RowPlan<ANNOT> plan[WG_WAVES];
-    __shared__ TripDesc desc[WG_WAVES];
-    __shared__ RowMeta meta[WG_WAVES];
-    __shared__ i32x4 lrec[WG_WAVES * GVL_SLOT_RECS];   // slot-major records of the 8 rows (read once, by wave 0)
+template <bool ANNOT>
+struct ReconShared {
+    Luts luts;
+    SegMirror mirror[WG_WAVES];
+    Stage<ANNOT> stage[WG_WAVES];
+    RowIn rin[WG_WAVES];
+    RowPlan<ANNOT> plan[WG_WAVES];
+    TripDesc desc[WG_WAVES];
+    RowMeta meta[WG_WAVES];
+    i32x4 lrec[WG_WAVES * GVL_SLOT_RECS];   // slot-major records of the 8 rows (read once, by wave 0)
+};
+
+// What one wave needs in LDS when it runs a row on its own (SOLO): the scalar walk's mirror only ever
+// replaces a plan that failed, so the two share their memory.
+template <bool ANNOT>
+struct SoloLds {
+    union { RowPlan<ANNOT> pl; SegMirror M; } u;
+    Stage<ANNOT> G;
+    RowIn ri;
+};
+
+// One workgroup's 8 (row, chunk)s: rows 8 wg .. 8 wg + 7 of the batch (S = the workgroup's tables).
+// SOLO: ONE wave runs ONE row on its own -- the caller (recon_lean_kernel, for a row it cannot express)
+// has put the row's parameters into solo->ri; no P1, no barrier, no packed plan: the row takes the
+// per-wave scans (or the scalar walk) and streams from the byte reference like any row here.
+template <int OH, bool HAPS, bool ANNOT, bool SOLO>
+__device__ __forceinline__ void recon_body(const ReconArgs &A, ReconShared<ANNOT> *Sp, SoloLds<ANNOT> *solo, Luts &luts, const i64 wg) {
+    SegMirror *const mirror = SOLO ? nullptr : Sp->mirror;
+    Stage<ANNOT> *const stage = SOLO ? nullptr : Sp->stage;
+    RowIn *const rin = SOLO ? nullptr : Sp->rin;
+    RowPlan<ANNOT> *const plan = SOLO ? nullptr : Sp->plan;
+    TripDesc *const desc = SOLO ? nullptr : Sp->desc;
+    RowMeta *const meta = SOLO ? nullptr : Sp->meta;
+    i32x4 *const lrec = SOLO ? nullptr : Sp->lrec;
 
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
@@ -998,7 +1024,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     const bool planned_ok = A.chunk_len <= CHUNK_TRIPS * TRIP && !(A.dbg & 8);
 
     GVL_STAMP(0);
-    if (tid < 256) {  // LUTs
+    if (!SOLO && tid < 256) {  // LUTs
         const u32 d = onehot_dword((u32)tid);
         luts.oh[tid] = d;
         luts.oh_rc[tid] = __builtin_bswap32(d);
@@ -1009,17 +1035,17 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     // 128-byte lines of the workgroup in ONE wave-load), all parked in LDS.  After the barrier no wave
     // needs a global read before its plan, so the reference bytes it requests next (below) stay in
     // flight behind nothing.
-    const bool use_srec = A.srec != nullptr && !A.ref_only && planned_ok && !(A.dbg & 512) && !ANNOT;
+    const bool use_srec = !SOLO && A.srec != nullptr && !A.ref_only && planned_ok && !(A.dbg & 512) && !ANNOT;
     // wave 0's carry from P1a to P1b (the slot-line read stays in flight across the first barrier)
     i32x4 p1_rec = {0, 0, (int)GVL_SREC_EMPTY, 0};
     i64 p1_oidx = 0;
     int p1_fl = 1;
     bool p1_want = false;
-    if (tid < WAVE) {
+    if (!SOLO && tid < WAVE) {
         // Every load of a level is issued before anything waits (no branch in between: an absent
         // array is replaced by a pointer that is always readable, and a lane without a row reads
         // row 0), so P1 costs two memory round trips, not one per array.
-        const i64 k_raw = (i64)blockIdx.x * WG_WAVES + tid;
+        const i64 k_raw = wg * WG_WAVES + tid;
         const bool row_lane = tid < WG_WAVES && k_raw < A.n_rows;
         const i64 k = row_lane ? k_raw : 0;
         const i64 query = A.ploidy_shift >= 0 ? (k >> A.ploidy_shift) : (i64)((u32)k / (u32)A.ploidy);
@@ -1037,6 +1063,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         RowIn ri;
         ri.c_s = ri.R = ri.o_s = 0;
         ri.n_var = 0;
+        ri.k = (int)k;
         ri.ref_start = l_start;
         ri.shift = A.ref_only ? 0 : (i64)l_shift;
         ri.keep_off = (has_keep && !A.ref_only) ? l_ko : 0;
@@ -1098,7 +1125,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         }
     }
     GVL_STAMP(1);
-    lds_barrier();      // (not __syncthreads: its fence would wait for wave 0's slot-line read)
+    if (!SOLO) lds_barrier();      // (not __syncthreads: its fence would wait for wave 0's slot-line read)
     // Every wave "uses" the slot-line registers here: a no-op for waves 1..7 (they have nothing in flight),
     // wave 0 needs the line next anyway.  Without it the compiler's wait-count model carries "a load into
     // these registers may be pending" past the reference reads below and, as soon as a register is reused,
@@ -1106,11 +1133,11 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     asm volatile("" :: "v"(p1_rec.x), "v"(p1_rec.y), "v"(p1_rec.z), "v"(p1_rec.w));
 
     GVL_STAMP(2);
-    const RowIn &ri = rin[wave];
+    const RowIn &ri = SOLO ? solo->ri : rin[wave];
     int flags = rfl(ri.flags);
-    const i64 k = (i64)blockIdx.x * WG_WAVES + wave;
-    RowPlan<ANNOT> &pl = plan[wave];
-    Stage<ANNOT> &G = stage[wave];
+    const i64 k = SOLO ? (i64)rfl(ri.k) : wg * WG_WAVES + wave;
+    RowPlan<ANNOT> &pl = SOLO ? solo->u.pl : plan[wave];
+    Stage<ANNOT> &G = SOLO ? solo->G : stage[wave];
     const int L = rfl(ri.L);
     const i64 c_s = rfl64(ri.c_s);
     const int hi_clip = (L - lo_clip > A.chunk_len) ? lo_clip + A.chunk_len : L;
@@ -1124,7 +1151,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     //  * the other packable rows are SLOW: the first slow wave plans all of them at once
     //    (packed_plan), the other slow waves wait for their flag.
     //  * rows with more than 8 variants run the per-wave scans (P2 + P3 further down).
-    bool packable = (flags & 11) == 8;
+    bool packable = !SOLO && (flags & 11) == 8;
     int row_n_var = rfl(ri.n_var);        // (a slot-major row that overflows its line re-reads these from the CSR)
     i64 row_o_s = rfl64(ri.o_s);
 
@@ -1216,7 +1243,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     if (use_srec) {
         lds_barrier();
         flags = rfl(ri.flags);
-        packable = (flags & 11) == 8;
+        packable = !SOLO && (flags & 11) == 8;
         row_n_var = rfl(ri.n_var);
         row_o_s = rfl64(ri.o_s);
         ell = (flags & 16) != 0 && packable;
@@ -1549,7 +1576,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if (flags & 1) return;
-    if (packed) {
+    if (!SOLO && packed) {
         if (rfl(meta[wave].bad)) flags |= 2;
         nseg = rfl(meta[wave].nseg); npatch = rfl(meta[wave].npatch);
     }
@@ -1558,7 +1585,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     if (A.stamps && lane == 0 && (flags & 2)) atomicAdd((unsigned long long *)&A.stamps[((u64)blockIdx.x * gridDim.y + blockIdx.y) * 16 + 9], 1ull);
 #endif
     if (flags & 2) {
-        recon_wave_scalar<OH, HAPS, ANNOT>(A, luts, mirror[wave], stage[wave], k, chunk, lane);
+        recon_wave_scalar<OH, HAPS, ANNOT>(A, luts, SOLO ? solo->u.M : mirror[wave], G, k, chunk, lane);
         return;
     }
 
@@ -1572,7 +1599,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     int d_cls = 3, d_b1 = 0, d_b2 = 0, d_pc0 = 0, d_pcn = 0, d_idx = 0;
     u32 d_ldlo = 0, d_ldhi = 0;     // class 0: address of the trip's first source byte
     u32 d_lo0 = 0, d_hi0 = 0, d_lo1 = 0, d_hi1 = 0, d_lo2 = 0, d_hi2 = 0;
-    if (packed) {
+    if (!SOLO && packed) {
         if (lane < CHUNK_TRIPS) {
             const TripDesc &D = desc[wave];
             d_cls = D.cls[lane]; d_b1 = D.b1[lane]; d_b2 = D.b2[lane]; d_pc0 = D.pc0[lane]; d_pcn = D.pcn[lane];
@@ -2065,6 +2092,13 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
 }
 
 #undef GVL_STAMP
+
+template <int OH, bool HAPS, bool ANNOT>
+__global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void reconstruct_kernel(const ReconArgs A) {
+    __shared__ ReconShared<ANNOT> S;
+    recon_body<OH, HAPS, ANNOT, false>(A, &S, nullptr, S.luts, (i64)blockIdx.x);
+}
+
 typedef void (*recon_fn)(const ReconArgs);
 static recon_fn recon_table(int oh, bool haps, bool annot) {
 #define GVL_K(o, h, a) reconstruct_kernel<o, h, a>
@@ -2078,6 +2112,8 @@ static recon_fn recon_table(int oh, bool haps, bool annot) {
     return haps ? GVL_K(OH_CL, true, false) : GVL_K(OH_CL, false, false);
 #undef GVL_K
 }
+
+#include "gvl_lean.inc"
 
 // ---------------------------------------------------------------------------
 // get_diffs_sparse (genotypes/mod.rs:15-125): one lane per (query, hap) row.
@@ -3431,6 +3467,8 @@ int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
 //  1024  painter ignores the per-list bucket index (exact 64-ary searches per chunk)
 //  2048  length deltas (get_diffs_sparse, ragged sizing) always one wave per row
 //  8192  painter always paints an LDS image (no start-bitmap lookup for non-overlapping candidates)
+// 16384  no lean kernel (the all-purpose kernel over every row, as before round 3)
+// 32768  the lean kernel hands EVERY row to its solo general path (per-wave scans from the byte reference)
 // and 1 / 2 / 4 = timing ablations (no variants / no stores / no loads).
 int g_debug_override = -1;
 int debug_flags() {
@@ -3516,6 +3554,17 @@ int gvl_pack_genotypes(const gvl_static *st, gvl_grec *grec_out, void *stream) {
     return check_launch("gvl_pack_genotypes");
 }
 
+int64_t gvl_ref4_bytes(int64_t ref_len) { return ref_len < 0 ? 0 : (ref_len + 1) / 2 + GVL_REF4_PAD; }
+
+int gvl_pack_reference(const uint8_t *ref, int64_t ref_len, uint8_t *ref4_out, void *stream) {
+    if (ref_len < 0 || !ref4_out || (ref_len > 0 && !ref)) return fail(GVL_ERR_INVALID, "%s", "gvl_pack_reference: bad arguments");
+    const i64 out_len = gvl_ref4_bytes(ref_len);
+    const i64 grid = ((out_len + 3) / 4 + 255) / 256;
+    if (grid > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_pack_reference: reference too long");
+    pack_ref4_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(ref, ref_len, ref4_out, out_len);
+    return check_launch("gvl_pack_reference");
+}
+
 // ---- per-dataset arrays for callers without a device allocator of their own -----------------------
 struct StaticOwner { gvl_static st; void *bufs[16]; int n; };
 
@@ -3563,6 +3612,11 @@ int gvl_static_upload(const gvl_static *host, int32_t with_layouts, gvl_static *
     if (!rc && ok && with_layouts && no > 0 && nv > 0 && host->alt_len < (1ll << 32)) {
         gvl_srec *sr = (gvl_srec *)dev_copy(o, nullptr, (size_t)no * GVL_SLOT_RECS * sizeof(gvl_srec), s, &ok);
         if (ok) { rc = gvl_pack_slots(&d, sr, stream); if (!rc) d.slot_rec = sr; }
+    }
+    d.ref4 = nullptr;
+    if (!rc && ok && with_layouts && host->ref_len > 0) {
+        uint8_t *r4 = (uint8_t *)dev_copy(o, nullptr, (size_t)gvl_ref4_bytes(host->ref_len), s, &ok);
+        if (ok) { rc = gvl_pack_reference(d.ref, host->ref_len, r4, stream); if (!rc) d.ref4 = r4; }
     }
     if (!rc && !ok) rc = fail(GVL_ERR_HIP, "%s", "gvl_static_upload: device allocation failed");
     if (rc) { gvl_static_free(&o->st); return rc; }
@@ -3623,6 +3677,7 @@ static int fill_recon_args(const gvl_static *st, const gvl_batch *bt, const gvl_
     A.geno_v_idxs = st->geno_v_idxs;
     A.grec = (debug_flags() & 16) ? nullptr : st->geno_rec;
     A.srec = (debug_flags() & (64 | 512 | 8)) ? nullptr : st->slot_rec;
+    A.ref4 = st->ref4;
     A.n_geno_offsets = st->n_geno_offsets;
     A.n_contigs = (int)(st->n_contigs < 0 ? 0 : (st->n_contigs > 0x7FFFFFFFll ? 0x7FFFFFFF : st->n_contigs));
     A.regions = bt->regions; A.regions_stride = bt->regions_stride; A.shifts = bt->shifts;
@@ -3661,11 +3716,39 @@ static int launch_recon(const ReconArgs &A, int chunks, int variant, void *strea
     return check_launch("gvl_reconstruct");
 }
 
+// Can this batch take the lean kernel?  One-hot only, row-major, fixed-length rows of one chunk, no keep
+// mask, no annotations, both derived layouts present -- and no path-forcing debug flag (those exist to
+// walk the all-purpose kernel).
+static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_out *out) {
+    if (!st->ref4 || !st->slot_rec || !out->onehot || out->haps) return false;
+    if (out->annot_v_idxs || out->annot_ref_pos || out->onehot_layout != GVL_ONEHOT_LC) return false;
+    if (bt->out_offsets || bt->keep || bt->keep_offsets) return false;
+    if (bt->output_length <= 0 || bt->output_length > LEAN_MAX_TRIPS * TRIP || (bt->output_length & 3)) return false;
+    if (bt->batch * bt->ploidy <= 0 || bt->batch * bt->ploidy > 0x7FFFFFFFll / (4 * LEAN_MAX_TRIPS * TRIP)) return false;
+    if (st->alt_len >= (1ll << 32)) return false;
+    return (debug_flags() & ~(2 | 4 | 32768)) == 0;
+}
+
+static int launch_lean(const ReconArgs &RA, void *stream) {
+    LeanArgs A;
+    memset(&A, 0, sizeof(A));
+    A.ref4 = RA.ref4; A.ref_offsets = RA.ref_offsets; A.srec = RA.srec;
+    A.regions = RA.regions; A.shifts = RA.shifts; A.geno_offset_idx = RA.geno_offset_idx; A.to_rc = RA.to_rc;
+    A.onehot = RA.onehot; A.out_offsets_w = RA.out_offsets_w;
+    A.n_geno_offsets = RA.n_geno_offsets;
+    A.n_rows = (int)RA.n_rows; A.n_contigs = RA.n_contigs; A.regions_stride = (int)RA.regions_stride;
+    A.ploidy_shift = RA.ploidy_shift; A.ploidy = RA.ploidy; A.L = (int)RA.fixed_len; A.dbg = RA.dbg;
+    const unsigned grid = (unsigned)((A.n_rows + LEAN_WAVES - 1) / LEAN_WAVES);
+    recon_lean_kernel<<<dim3(grid), dim3(LEAN_THREADS), 0, (hipStream_t)stream>>>(A, RA);
+    return check_launch("gvl_reconstruct (lean)");
+}
+
 int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *out, void *stream) {
     ReconArgs A;
     int chunks = 1, variant = 0;
     const int rc = fill_recon_args(st, bt, out, A, &chunks, &variant);
     if (rc) return rc;
+    if (A.n_rows > 0 && chunks == 1 && lean_eligible(st, bt, out)) return launch_lean(A, stream);
     return launch_recon(A, chunks, variant, stream);
 }
 
@@ -3684,7 +3767,8 @@ int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_o
         if (rc) return rc;
     }
     for (int i = 0; i < n; ++i) {
-        const int rc = launch_recon(A[i], chunks[i], variant[i], stream);
+        const bool lean = A[i].n_rows > 0 && chunks[i] == 1 && lean_eligible(st, &bts[i], &outs[i]);
+        const int rc = lean ? launch_lean(A[i], stream) : launch_recon(A[i], chunks[i], variant[i], stream);
         if (rc) return rc;
     }
     return GVL_OK;

@@ -98,7 +98,7 @@ class ReconOutput:
 class HapsDevice:
     def __init__(self, *, ref, ref_offsets, v_starts, ilens, alt_alleles, alt_offsets,
                  geno_offsets, geno_v_idxs, pad_char=ord("N"), device="cuda", inline_genotypes=None,
-                 slot_records=None):
+                 slot_records=None, packed_reference=None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.GvlError("genvarloader_amd needs a HIP device (no CPU fallback)")
@@ -132,7 +132,7 @@ class HapsDevice:
             n_variants=n_var, alt_len=self.alt_alleles.numel(), vrec=self.vrec.data_ptr(),
             geno_o_starts=self.geno_offsets[0].data_ptr(), geno_o_stops=self.geno_offsets[1].data_ptr(),
             n_geno_offsets=n_go, geno_v_idxs=self.geno_v_idxs.data_ptr(),
-            n_geno=self.geno_v_idxs.numel(), pad_char=self.pad_char, geno_rec=None, slot_rec=None,
+            n_geno=self.geno_v_idxs.numel(), pad_char=self.pad_char, geno_rec=None, slot_rec=None, ref4=None,
         )
         # Derived layout: the variant's fields next to each genotype CSR entry (gvl_grec, 16 B per
         # entry) removes one of the dependent gathers in the kernel head.  Default: build it
@@ -158,6 +158,17 @@ class HapsDevice:
                 self.slot_rec = torch.empty((n_go * 8, 4), dtype=torch.int32, device=d)
                 _lib.check(self.lib.gvl_pack_slots(C.byref(self.c), _ptr(self.slot_rec), _stream_ptr()))
             self.c.slot_rec = self.slot_rec.data_ptr()
+        # Nibble-packed reference (gvl_pack_reference, ref_len / 2 bytes): what the lean one-hot kernel reads
+        # instead of the byte reference -- half the bytes and cache lines behind the cold window reads.
+        self.ref4 = None
+        n_ref = int(self.ref.numel())
+        if packed_reference is None:
+            packed_reference = self.slot_rec is not None and n_ref > 0 and n_ref // 2 <= torch.cuda.mem_get_info(d)[0] // 4
+        if packed_reference and n_ref > 0:
+            with torch.cuda.device(d):
+                self.ref4 = torch.empty(int(self.lib.gvl_ref4_bytes(n_ref)), dtype=torch.uint8, device=d)
+                _lib.check(self.lib.gvl_pack_reference(_ptr(self.ref), C.c_int64(n_ref), _ptr(self.ref4), _stream_ptr()))
+            self.c.ref4 = self.ref4.data_ptr()
 
     # ------------------------------------------------------------------ batches
     def prepare_batch(self, regions, shifts, geno_offset_idx, output_length, keep=None,

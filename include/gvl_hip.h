@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GVL_ABI_VERSION 4
+#define GVL_ABI_VERSION 5
 
 enum {
     GVL_OK = 0,
@@ -85,6 +85,19 @@ typedef struct gvl_srec {
     uint32_t a0;       /* alt_offsets[v] (the table is only built when alt_len < 2^32) */
 } gvl_srec;
 
+/* Nibble-packed reference ("ref4"): base i of `ref` is nibble i & 1 of byte i >> 1 (low nibble first),
+ *   bits 0-1  (byte >> 1) & 3  -- A 0, C 1, T 2, G 3
+ *   bit  2    the byte is exactly one of "ACGT"
+ *   bit  3    the byte is 'N'
+ * so that the one-hot of 4 bases is two LDS lookups on 16 bits read from HALF the bytes (and half the
+ * cache lines / DRAM pages) of the byte reference: the window reads are the cold, scattered part of
+ * the path's traffic.  Any other byte (IUPAC codes, lower case) packs to 0 = "no channel", which is
+ * what the one-hot definition gives it.  Built once per dataset by gvl_pack_reference(); optional:
+ * ref_len / 2 + GVL_REF4_PAD bytes of HBM (the padding lets a window that starts anywhere inside the
+ * reference read 2048 bases ahead without a bounds test per lane).  Only the one-hot-only fixed-length entry reads it (haplotype BYTES
+ * always come from `ref`). */
+#define GVL_REF4_PAD 1088
+
 /* Per-dataset, device-resident arrays.  Mirrors `_HapsFfiStatic`
  * (_haps.py:233-247) + `Reference` (_reference.py:31-50) + the sparse genotype
  * CSR (`genotypes/offsets.npy`, `variant_idxs.npy`). */
@@ -108,6 +121,7 @@ typedef struct gvl_static {
     uint8_t pad_char;
     const gvl_grec *geno_rec;    /* nullable: n_geno, from gvl_pack_genotypes() */
     const gvl_srec *slot_rec;    /* nullable: GVL_SLOT_RECS * n_geno_offsets, from gvl_pack_slots() */
+    const uint8_t *ref4;         /* nullable: (ref_len + 1) / 2 + GVL_REF4_PAD bytes, from gvl_pack_reference() */
 } gvl_static;
 
 /* Per-batch arrays.  Mirrors `ReconstructionRequest` (_haps.py:58-93) as
@@ -176,6 +190,11 @@ int gvl_pack_variants(const int32_t *v_starts, const int32_t *ilens,
 /* Build the per-genotype-entry records (once per dataset; optional, see gvl_grec).
  * Needs st->vrec, st->geno_v_idxs, st->n_geno, st->n_variants. */
 int gvl_pack_genotypes(const gvl_static *st, gvl_grec *grec_out, void *stream);
+
+/* Build the nibble-packed reference (once per dataset; optional, see "ref4" above).
+ * ref4_out: gvl_ref4_bytes(ref_len) = (ref_len + 1) / 2 + GVL_REF4_PAD bytes. */
+int64_t gvl_ref4_bytes(int64_t ref_len);
+int gvl_pack_reference(const uint8_t *ref, int64_t ref_len, uint8_t *ref4_out, void *stream);
 
 /* Build the slot-major records (once per dataset; optional, see gvl_srec).
  * Needs st->vrec, alt_offsets, geno_o_starts/stops, geno_v_idxs, n_geno_offsets, n_variants;

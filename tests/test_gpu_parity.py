@@ -41,7 +41,8 @@ def gpu():
 # (tests/parity/test_rayon_equivalence.py:31-62); here every reference vector goes down every
 # kernel path: gvl_set_debug_flags removes one way at a time.
 KERNEL_PATHS = {0: "default", 8: "scalar-walk", 64: "csr-inline-records", 80: "csr-vrec-gather", 32: "no-scan-free-plan",
-                128: "no-speculative-reads", 512: "per-wave-scans", 2048: "wave-per-row-diffs"}
+                128: "no-speculative-reads", 512: "per-wave-scans", 2048: "wave-per-row-diffs",
+                16384: "no-lean-kernel", 32768: "lean-lists-every-row"}
 
 
 @pytest.fixture(params=sorted(KERNEL_PATHS), ids=[KERNEL_PATHS[k] for k in sorted(KERNEL_PATHS)])
