@@ -3725,7 +3725,7 @@ static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_o
     if (bt->out_offsets || bt->keep || bt->keep_offsets) return false;
     if (bt->output_length <= 0 || bt->output_length > LEAN_MAX_TRIPS * TRIP || (bt->output_length & 3)) return false;
     if (bt->batch * bt->ploidy <= 0 || bt->batch * bt->ploidy > 0x7FFFFFFFll / (4 * LEAN_MAX_TRIPS * TRIP)) return false;
-    if (st->alt_len >= (1ll << 32)) return false;
+    if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;     // u32 positions in the kernel
     return (debug_flags() & ~(2 | 4 | 32768)) == 0;
 }
 
@@ -3734,7 +3734,7 @@ static int launch_lean(const ReconArgs &RA, void *stream) {
     memset(&A, 0, sizeof(A));
     A.ref4 = RA.ref4; A.ref_offsets = RA.ref_offsets; A.srec = RA.srec;
     A.regions = RA.regions; A.shifts = RA.shifts; A.geno_offset_idx = RA.geno_offset_idx; A.to_rc = RA.to_rc;
-    A.onehot = RA.onehot; A.out_offsets_w = RA.out_offsets_w;
+    A.onehot = RA.onehot; A.out_offsets_w = RA.out_offsets_w; A.alt_alleles = RA.alt_alleles;
     A.n_geno_offsets = RA.n_geno_offsets;
     A.n_rows = (int)RA.n_rows; A.n_contigs = RA.n_contigs; A.regions_stride = (int)RA.regions_stride;
     A.ploidy_shift = RA.ploidy_shift; A.ploidy = RA.ploidy; A.L = (int)RA.fixed_len; A.dbg = RA.dbg;

@@ -65,3 +65,14 @@ def test_fuzz_tracks_planned_walk():
 
 def test_fuzz_tracks_scalar_walk():
     _run("fuzz_tracks.py", 200, 104, dbg=8)
+
+
+def test_fuzz_lean_kernel():
+    """One-hot only, fixed-length rows of at most 2048 bases: recon_lean_kernel (nibble-packed reference, plan on
+    the row's record lanes) and, for the rows it hands over, its solo general path."""
+    _run("fuzz_lean.py", 600, 201)
+
+
+def test_fuzz_lean_kernel_every_row_solo():
+    """GVL_DBG=32768: the lean kernel hands EVERY row to the all-purpose body in SOLO mode."""
+    _run("fuzz_lean.py", 300, 202, dbg=32768)
