@@ -29,7 +29,10 @@ Timing.  After W warmup steps:
     region).  This is what makes ``--steps 20`` and ``--steps 2000`` agree;
   * ``roofline``: K back-to-back launches on ONE stream between two HIP events, repeated the
     same way -> the kernel's own average duration (what ``rocprofv3 --kernel-trace --stats``
-    reports) -> ``achieved`` = algorithmic bytes per launch / that.
+    reports) -> ``achieved`` = algorithmic bytes per launch / that;
+  * ``sustained``: >= ``--sustained-s`` (3) seconds of back-to-back cold batches on the same
+    4-stream schedule between ONE pair of HIP events (no gate, no per-region synchronisation):
+    the rate at seconds, with the shader / memory clocks read from rocm-smi before and after.
 
 For N > 1 the driver launches one rank per GPU (torch.distributed.run); rows are independent,
 so each rank processes its own 4096-window batches (weak scaling, no data-path collective)
@@ -133,14 +136,31 @@ def cpu_only(args) -> None:
         "cpu_baseline": res}), flush=True)
 
 
+def gpu_clocks(dev_index: int = 0):
+    """Shader / memory clock of the device as rocm-smi reports them right now ({} when it cannot be read)."""
+    import re
+    import subprocess
+
+    try:
+        out = subprocess.run(["rocm-smi", "-d", str(dev_index), "--showclocks"], capture_output=True, text=True, timeout=20).stdout
+    except Exception:
+        return {}
+    res = {}
+    for key in ("sclk", "mclk", "fclk"):
+        m = re.search(key + r"\s+clock level:?\s*\S*:?\s*\(?(\d+)\s*Mhz", out, re.I)
+        if m:
+            res[key + "_mhz"] = int(m.group(1))
+    return res
+
+
 class Timer:
     """Repeated K-step regions, each bracketed by barrier + synchronize; GPU time of a region from
     HIP events on the work streams, the launches queued behind a gate kernel."""
 
-    def __init__(self, torch, dist, backend, streams, min_region_ms, max_regions):
+    def __init__(self, torch, dist, backend, streams, min_region_ms, max_regions, max_wall_s=8.0):
         self.torch, self.dist, self.backend = torch, dist, backend
         self.streams = streams
-        self.min_ms, self.max_regions = float(min_region_ms), int(max_regions)
+        self.min_ms, self.max_regions, self.max_wall_s = float(min_region_ms), int(max_regions), float(max_wall_s)
         self.gate = torch.cuda.Stream()
         # calibrate torch.cuda._sleep (spins on the shader clock)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -190,14 +210,52 @@ class Timer:
         return gpu_ms, (t1 - t0) * 1e3
 
     def measure(self, step, K, streams):
-        """Repeat the region until >= min_ms of GPU time is sampled -> (median GPU ms of a
-        region, max over ranks per region; number of regions)."""
-        first, _ = self.region(step, K, streams)
-        first = self.allmax([first])[0]
+        """Repeat the region until >= min_ms of GPU time is sampled (or max_wall_s of host time is
+        spent) -> (median GPU ms of a region, max over ranks per region; number of regions)."""
+        first, w = self.region(step, K, streams)
+        first, w = self.allmax([first, w])
         n = int(min(self.max_regions, max(5, np.ceil(self.min_ms / max(first, 1e-6)))))
+        n = int(max(5, min(n, self.max_wall_s * 1e3 / max(w, 1e-3))))
         spans = [self.region(step, K, streams)[0] for _ in range(n)]
         spans = self.allmax(spans)
         return float(np.median(spans)), n, spans
+
+    def sustained(self, calls, fn, streams, seconds, est_ms_per_step):
+        """>= `seconds` of back-to-back steps on the streams' round-robin schedule between ONE event pair
+        (recorded on streams[0]; the other streams are joined into it at the end).  `calls[i]` = the ctypes
+        arguments of step i (cycled).  -> (GPU ms per step, steps, host seconds spent enqueueing)."""
+        torch = self.torch
+        n = int(max(len(calls), seconds * 1e3 / max(est_ms_per_step, 1e-6)))
+        n -= n % len(streams)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        joins = [torch.cuda.Event() for _ in streams[1:]]
+        self.barrier()
+        torch.cuda.synchronize()
+        start = torch.cuda.Event()
+        start.record(streams[0])
+        for s_ in streams[1:]:
+            s_.wait_event(start)
+        e0.record(streams[0])
+        m = len(calls)
+        t0 = time.perf_counter()
+        bad = 0
+        burst = min(n, 512)                    # the queue is empty here: these enqueues show the host's own cost per launch
+        for i in range(burst):
+            bad |= fn(*calls[i % m])
+        t_burst = time.perf_counter() - t0
+        for i in range(burst, n):
+            bad |= fn(*calls[i % m])
+        t_host = time.perf_counter() - t0
+        for s_, ev in zip(streams[1:], joins):
+            ev.record(s_)
+            streams[0].wait_event(ev)
+        e1.record(streams[0])
+        torch.cuda.synchronize()
+        self.barrier()
+        if bad:
+            raise RuntimeError("gvl_reconstruct failed inside the sustained leg")
+        ms = self.allmax([e0.elapsed_time(e1)])[0]
+        return ms / n, n, t_host, t_burst / burst
 
 
 def main() -> None:
@@ -214,13 +272,17 @@ def main() -> None:
     ap.add_argument("--haps", action="store_true", help="also materialise haplotype bytes (h=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-only", action="store_true", help="time the CPU oracle only (cfg1 plumbing case); no GPU")
-    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--cpu-budget", type=float, default=8.0)
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the launches of the timed region rotate over")
     ap.add_argument("--many", type=int, default=1,
                     help="batches per launch in the timed region (gvl_reconstruct_many; a step is still ONE batch)")
-    ap.add_argument("--min-region-ms", type=float, default=20.0)
-    ap.add_argument("--max-regions", type=int, default=400)
+    ap.add_argument("--min-region-ms", type=float, default=1000.0,
+                    help="GPU time to sample per timed leg (repeated K-step regions)")
+    ap.add_argument("--max-regions", type=int, default=20000)
+    ap.add_argument("--max-leg-s", type=float, default=8.0, help="host time one timed leg may take")
+    ap.add_argument("--sustained-s", type=float, default=3.0,
+                    help="length of the sustained leg (back-to-back cold batches, one event pair); 0 = skip")
     ap.add_argument("--strong", action="store_true", help="N > 1: split ONE batch across the ranks (strong scaling)")
     ap.add_argument("--gather", action="store_true", help="N > 1: also time the RCCL all-gather of the one-hot shards")
     ap.add_argument("--no-hot", action="store_true", help="skip the extra cache-hot kernel timing")
@@ -340,7 +402,12 @@ def main() -> None:
     def step_hot(i: int) -> None:
         dev.launch(batches[0], slots[i % n_slots][1], stream)
 
-    tm = Timer(torch, dist, backend, streams, args.min_region_ms, args.max_regions)
+    k_all = K                                  # windows per step over all ranks
+    if dist is not None:
+        t = torch.tensor([K], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        k_all = int(t.item())
+    tm = Timer(torch, dist, backend, streams, args.min_region_ms, args.max_regions, args.max_leg_s)
     steps = args.steps
     if G > 1:
         step_pipelined = ManyStepper()
@@ -375,6 +442,28 @@ def main() -> None:
     hot_ms = None
     if not args.no_hot:
         hot_ms = tm.measure(step_hot, steps, [stream])[0] / steps
+    # ---- sustained: seconds of back-to-back cold batches, the timed region's schedule, ONE event pair ----
+    sustained = None
+    if args.sustained_s > 0:
+        import ctypes as C
+        import math
+
+        period = math.lcm(n_rot, n_slots, len(streams))
+        period = min(period, 4096 - 4096 % len(streams))
+        sp = [C.c_void_p(s_.cuda_stream) for s_ in streams]
+        calls = [(C.byref(dev.c), C.byref(batches[j % n_rot].c), C.byref(slots[j % n_slots][1]), sp[j % len(streams)])
+                 for j in range(period)]
+        clk0 = gpu_clocks(dev_index)
+        sus_ms, sus_n, sus_host, sus_launch = tm.sustained(calls, dev.lib.gvl_reconstruct, streams, args.sustained_s, region_ms / steps)
+        clk1 = gpu_clocks(dev_index)
+        sustained = {"ms_per_step": sus_ms, "steps": sus_n, "seconds": sus_ms * sus_n * 1e-3,
+                     "windows_per_s": k_all / (sus_ms * 1e-3),
+                     "vs_median_region": sus_ms / (region_ms / steps),
+                     "host_enqueue_s": sus_host, "host_us_per_launch_unthrottled": sus_launch * 1e6,
+                     "host_bound": bool(sus_launch * 1e3 > 0.9 * sus_ms),
+                     "how": "back-to-back gvl_reconstruct launches, step i on stream i % streams, rotating cold batches, "
+                            "one HIP event pair around all of them (no gate kernel, no synchronisation in between)",
+                     "clocks_before": clk0, "clocks_after": clk1}
     # ---- single-batch latency, host wall clock: launch -> synchronize --------
     lat = []
     for i in range(50):
@@ -402,12 +491,8 @@ def main() -> None:
         assert g.shape[1:] == oh.shape[1:] and g.shape[0] >= K
         gather_ms = tm.allmax([float(np.median(ts)) * 1e3])[0]
 
-    k_all = K
-    if dist is not None:
-        t = torch.tensor([K], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t)
-        k_all = int(t.item())
-
+    lean = (dev.ref4 is not None and dev.slot_rec is not None and not args.haps and L <= 2048 and L % 4 == 0
+            and (int(os.environ.get("GVL_DBG", "0")) & ~(2 | 4 | 32768)) == 0)
     if rank == 0:
         ms_per_step = region_ms / steps
         abytes = algorithmic_bytes_per_window(L, mean_v, args.haps, True) * K
@@ -443,6 +528,10 @@ def main() -> None:
                                                           else "rows sharded over the ranks, one full batch per rank per step"),
                 "streams": len(streams), "batches_per_launch": G, "batches_in_flight": len(streams) * G,
                 "dataset_build_s": round(t_gen, 2),
+                "layouts": {"slot_rec": dev.slot_rec is not None, "geno_rec": dev.geno_rec is not None, "ref4": dev.ref4 is not None,
+                            "note": None if dev.slot_rec is not None else
+                            "slot_rec NOT built (128 B x genotype slots exceeds a quarter of the free HBM): rows find their records through the CSR"},
+                "kernel_path": "lean" if lean else "all-purpose",
             },
             "timing": {
                 "how": "median of repeated K-step regions, each between barrier+synchronize; GPU time of a region from "
@@ -455,7 +544,8 @@ def main() -> None:
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "frac_of_copy_ceiling": achieved / HBM_COPY_GBS,
-                "kernel": "reconstruct_kernel<OH_LC, haps=%s, annot=false>" % ("true" if args.haps else "false"),
+                "kernel": ("recon_lean_kernel (nibble-packed reference; rows it cannot express run the all-purpose body inside the same launch)"
+                           if lean else "reconstruct_kernel<OH_LC, haps=%s, annot=false>" % ("true" if args.haps else "false")),
                 "kernel_ms": kern_ms,
                 "kernel_ms_how": "HIP events around K back-to-back launches on one stream (rotating batches), median region",
                 "kernel_ms_hot": hot_ms, "hot_frac": None if hot_ms is None else abytes / (hot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -465,6 +555,9 @@ def main() -> None:
                 "single_batch_wall_ms": single_ms,
             },
         }
+        if sustained is not None:
+            res["sustained"] = sustained
+            res["sustained_ms_per_step"] = sustained["ms_per_step"]
         if gather_ms is not None:
             res["gather_ms"] = gather_ms
             res["gather_bytes_per_rank"] = K * L * 4
