@@ -3469,6 +3469,7 @@ int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
 //  8192  painter always paints an LDS image (no start-bitmap lookup for non-overlapping candidates)
 // 16384  no lean kernel (the all-purpose kernel over every row, as before round 3)
 // 32768  the lean kernel hands EVERY row to its solo general path (per-wave scans from the byte reference)
+// 65536  the lean kernel re-reads the runs of a row with indels from memory (never re-aligns the speculative window in LDS)
 // and 1 / 2 / 4 = timing ablations (no variants / no stores / no loads).
 int g_debug_override = -1;
 int debug_flags() {
@@ -3726,7 +3727,7 @@ static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_o
     if (bt->output_length <= 0 || bt->output_length > LEAN_MAX_TRIPS * TRIP || (bt->output_length & 3)) return false;
     if (bt->batch * bt->ploidy <= 0 || bt->batch * bt->ploidy > 0x7FFFFFFFll / (4 * LEAN_MAX_TRIPS * TRIP)) return false;
     if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;     // u32 positions in the kernel
-    return (debug_flags() & ~(2 | 4 | 32768)) == 0;
+    return (debug_flags() & ~(2 | 4 | 32768 | 65536)) == 0;
 }
 
 static int launch_lean(const ReconArgs &RA, void *stream) {
