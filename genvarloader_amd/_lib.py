@@ -51,6 +51,7 @@ SYMBOLS = (
     "gvl_loader_slot_bytes",
     "gvl_loader_table_bytes",
     "gvl_loader_create",
+    "gvl_loader_set_epoch",
     "gvl_loader_start_epoch",
     "gvl_loader_next",
     "gvl_loader_destroy",

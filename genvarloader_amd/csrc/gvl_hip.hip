@@ -4274,7 +4274,9 @@ struct gvl_loader {
     i64 submitted, consumed;      // submitted: GROUPS handed to the GPU; consumed: BATCHES handed to the caller
     i64 released_groups;          // groups whose release has been recorded on the consumer's stream
     int G, n_sets;
-    u64 counter;                  // epochs started (keys the random draws together with cfg.seed)
+    u64 counter;                  // the running epoch's number + 1 (keys the random draws together with cfg.seed)
+    bool epoch_set;               // gvl_loader_set_epoch named the next epoch (else: epochs started so far)
+    u64 next_epoch;
     // epoch table (the caller's memory, like the slots): request arrays of every query of the epoch
     int *e_regions; i64 *e_goi; int *e_shifts; u8 *e_to_rc;
     struct LoaderSync *sync;      // non-NULL: a producer thread submits the groups (cfg.threaded)
@@ -4408,6 +4410,13 @@ int gvl_loader_destroy(gvl_loader *ld) {
     return GVL_OK;
 }
 
+int gvl_loader_set_epoch(gvl_loader *ld, uint64_t epoch) {
+    if (!ld) return fail(GVL_ERR_INVALID, "%s", "gvl_loader_set_epoch: NULL loader");
+    ld->next_epoch = epoch;
+    ld->epoch_set = true;
+    return GVL_OK;
+}
+
 int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int32_t drop_last, void *table, void *stream) {
     if (!ld || n < 0 || (n > 0 && (!order || !table)) || ((uintptr_t)table & 255))
         return fail(GVL_ERR_INVALID, "%s", "gvl_loader_start_epoch: bad arguments (table: gvl_loader_table_bytes() bytes, 256-byte aligned)");
@@ -4444,7 +4453,8 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
     ld->n_batches = drop_last ? n / bs : (n + bs - 1) / bs;
     ld->n_groups = (ld->n_batches + ld->G - 1) / ld->G;
     ld->submitted = ld->consumed = ld->released_groups = 0;
-    ++ld->counter;
+    if (ld->epoch_set) { ld->counter = ld->next_epoch + 1; ld->epoch_set = false; }
+    else ++ld->counter;
     const i64 n_used = drop_last ? ld->n_batches * bs : n;
     if (n_used > 0) {
         const int rc = gvl_prepare_request(&ld->st, order, n_used, c.full_regions, c.n_regions, c.n_samples, c.ploidy, c.jitter,

@@ -126,12 +126,26 @@ class DeviceHapsDataset:
             m = self._max_row_len = max(longest + max(grow, 0), 1)
         return m
 
-    def _loader_seed(self) -> int:
-        """A seed per loader (splitmix64 of seed and the loaders created so far)."""
+    def _loader_seed(self, draw_stream: int | None = None) -> int:
+        """The seed of a loader's random draws: splitmix64 of the dataset seed and the loader's draw stream --
+        by default the number of loaders created from this dataset so far (a new loader does not replay the
+        previous one's draws; the k-th loader of every rank's process gets the same stream), or the caller's."""
         from .sharding import splitmix64
 
-        self._loaders += 1
-        return splitmix64((self.seed + self._loaders) & 0xFFFFFFFFFFFFFFFF)
+        if draw_stream is None:
+            self._loaders += 1
+            draw_stream = self._loaders
+        return splitmix64((self.seed + int(draw_stream)) & 0xFFFFFFFFFFFFFFFF)
+
+    def _draw_key(self) -> tuple[int, int]:
+        """(seed, counter) of the next request's random draws: a draw is hash(seed, counter, dataset index).
+        Stand-alone requests tick the dataset's own counter; a loader pins (its seed, epoch + 1) for the epoch
+        (``_draw_override``), so that an index draws the same whatever batch, batch size or rank delivers it."""
+        ov = getattr(self, "_draw_override", None)
+        if ov is not None:
+            return ov
+        self._counter += 1
+        return self.seed, self._counter
 
     @property
     def shape(self):
@@ -157,13 +171,13 @@ class DeviceHapsDataset:
         goi = torch.empty((b, P), dtype=torch.int64, device=d)
         to_rc = torch.empty(b * P, dtype=torch.uint8, device=d)
         shifts = torch.empty((b, P), dtype=torch.int32, device=d)
-        self._counter += 1
+        d_seed, d_counter = self._draw_key()
         with torch.cuda.device(d):
             _lib.check(self.dev.lib.gvl_prepare_request(
                 C.byref(self.dev.c), _ptr(idx), C.c_int64(b), _ptr(self.full_regions), C.c_int64(self.n_regions),
                 C.c_int64(self.n_samples), C.c_int64(P), C.c_int64(self.jitter), C.c_int32(int(self.rc_neg)),
-                C.c_int32(int(self.deterministic)), C.c_int64(max(self.output_length, 0)), C.c_uint64(self.seed),
-                C.c_uint64(self._counter), _ptr(regions), _ptr(goi), _ptr(to_rc), _ptr(shifts), _stream_ptr()))
+                C.c_int32(int(self.deterministic)), C.c_int64(max(self.output_length, 0)), C.c_uint64(d_seed),
+                C.c_uint64(d_counter), _ptr(regions), _ptr(goi), _ptr(to_rc), _ptr(shifts), _stream_ptr()))
         return idx, regions, shifts, goi, (to_rc if self.rc_neg else None)
 
     def __getitem__(self, idx) -> Batch:
@@ -210,15 +224,15 @@ class DeviceHapsDataset:
         arena = torch.empty(offs[-1], dtype=torch.uint8, device=d)
         base = arena.data_ptr()
         p_oh, p_hp, p_reg, p_goi, p_sh, p_rc, p_oo = (base + o for o in offs[:-1])
-        self._counter += 1
+        d_seed, d_counter = self._draw_key()
         lib = self.dev.lib
         stream = C.c_void_p(torch.cuda.current_stream(d).cuda_stream)
         with torch.cuda.device(d):
             _lib.check(lib.gvl_prepare_request(
                 C.byref(self.dev.c), C.c_void_p(idx.data_ptr()), C.c_int64(b), C.c_void_p(self.full_regions.data_ptr()),
                 C.c_int64(self.n_regions), C.c_int64(self.n_samples), C.c_int64(P), C.c_int64(self.jitter),
-                C.c_int32(int(self.rc_neg)), C.c_int32(int(self.deterministic)), C.c_int64(L), C.c_uint64(self.seed),
-                C.c_uint64(self._counter), C.c_void_p(p_reg), C.c_void_p(p_goi), C.c_void_p(p_rc), C.c_void_p(p_sh),
+                C.c_int32(int(self.rc_neg)), C.c_int32(int(self.deterministic)), C.c_int64(L), C.c_uint64(d_seed),
+                C.c_uint64(d_counter), C.c_void_p(p_reg), C.c_void_p(p_goi), C.c_void_p(p_rc), C.c_void_p(p_sh),
                 stream))
             bt = GvlBatch(regions=p_reg, regions_stride=4, shifts=p_sh, geno_offset_idx=p_goi, batch=b, ploidy=P,
                           keep=None, keep_offsets=None, to_rc=p_rc if self.rc_neg else None, output_length=L,
@@ -246,7 +260,7 @@ class DeviceHapsDataset:
     def to_dataloader(self, batch_size: int = 1, shuffle: bool = False, sampler=None, drop_last: bool = False,
                       generator: torch.Generator | None = None, in_flight: int = 3, rank: int = 0,
                       world_size: int = 1, seed: int = 0, threaded: bool = False, group: int | None = None,
-                      python_loop: bool = False) -> "DeviceLoader":
+                      python_loop: bool = False, draw_stream: int | None = None) -> "DeviceLoader":
         """``Dataset.to_dataloader`` (``_impl.py:1963-2072``) for device consumers.  With
         ``world_size > 1`` the epoch is sharded across ranks like ``DistributedSampler``
         (:func:`genvarloader_amd.sharding.epoch_order`): same permutation on every rank, disjoint
@@ -254,9 +268,15 @@ class DeviceHapsDataset:
         event between two kernels of a stream costs the GPU a few microseconds of idle queue) and
         ``in_flight`` such groups are submitted ahead; ``group=None`` takes the largest of 16, 8, 4, 2, 1
         whose ring of ``(in_flight + 1) * group`` output slots stays under 4 GiB.  ``threaded=True``: a producer thread inside the library
-        submits them (launches overlap the consumer's own host work per batch)."""
+        submits them (launches overlap the consumer's own host work per batch).
+
+        Random draws (jitter, shifts; ``_query.py:160-187``, ``_haps.py:720-730``): the draw of dataset index *i*
+        in epoch *e* (``set_epoch``; epochs count from 0 otherwise) is a function of (dataset seed, ``draw_stream``,
+        *e*, *i*) only -- the same whatever rank, batch, batch size or submit loop delivers the index, different
+        between epochs and between draw streams.  ``draw_stream=None``: the number of loaders created from this
+        dataset so far (the k-th loader of every rank's process draws alike; a new loader does not replay)."""
         return DeviceLoader(self, batch_size, shuffle, sampler, drop_last, generator, in_flight, rank, world_size,
-                            seed, threaded, group, python_loop=python_loop)
+                            seed, threaded, group, python_loop=python_loop, draw_stream=draw_stream)
 
 
 @dataclass
@@ -381,7 +401,8 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
         else:
             from .sharding import splitmix64
 
-            seed = splitmix64(self.seed ^ splitmix64(self._counter + 1))
+            ov = getattr(self, "_draw_override", None)
+            seed = splitmix64(self.seed ^ splitmix64(self._counter + 1)) if ov is None else splitmix64(ov[0] ^ splitmix64(ov[1]))
         base = super().__getitem__(idx)
         dev, d = self.dev, self.dev.device
         b, P, L = int(base.idx.numel()), self.ploidy, self.output_length
@@ -567,7 +588,8 @@ class DeviceLoader:
 
     def __init__(self, ds: DeviceHapsDataset, batch_size=1, shuffle=False, sampler=None, drop_last=False,
                  generator=None, in_flight=2, rank=0, world_size=1, seed=0, threaded=False, group=None,
-                 python_loop=False):
+                 python_loop=False, draw_stream=None):
+        self.draw_seed = ds._loader_seed(draw_stream)      # (seed of this loader's jitter / shift draws)
         self.threaded = bool(threaded)
         self.group = None if group is None else max(1, min(16, int(group)))
         self.python_loop = bool(python_loop)
@@ -601,7 +623,7 @@ class DeviceLoader:
         cfg = GvlLoaderConfig(
             full_regions=ds.full_regions.data_ptr(), n_regions=ds.n_regions, n_samples=ds.n_samples, ploidy=ds.ploidy,
             batch_size=self.batch_size, output_length=ds.output_length, jitter=ds.jitter, rc_neg=int(ds.rc_neg),
-            deterministic=int(ds.deterministic), seed=ds._loader_seed(), want_haps=int(ds.haps), want_onehot=int(ds.onehot),
+            deterministic=int(ds.deterministic), seed=self.draw_seed, want_haps=int(ds.haps), want_onehot=int(ds.onehot),
             onehot_layout=_lib.GVL_ONEHOT_LC if ds.layout == "lc" else _lib.GVL_ONEHOT_CL, in_flight=self.in_flight,
             n_slots=n_slots, slot_arenas=None, threaded=int(self.threaded), group=self.group,
             want_annot=int(ds.annotate), max_row_len=ds.max_row_len() if ds.ragged else 0)
@@ -733,6 +755,7 @@ class DeviceLoader:
                 order = epoch_order(len(ds), shuffle=self.shuffle, seed=self.seed, epoch=self.epoch, rank=self.rank,
                                     world=self.world_size, drop_last=self.drop_last and self.world_size > 1,
                                     device=d, generator=g)
+            _lib.check(lib.gvl_loader_set_epoch(handle, C.c_uint64(self.epoch & 0xFFFFFFFFFFFFFFFF)))
             self.epoch += 1
             n = int(order.numel())
             tab, ev = self._epoch_table(n)
@@ -816,6 +839,7 @@ class DeviceLoader:
         if self.streams is None:
             self.streams = [torch.cuda.Stream(device=self.ds.dev.device) for _ in range(self.in_flight)]
         pending: deque = deque()
+        draw = (self.draw_seed, (self.epoch + 1) & 0xFFFFFFFFFFFFFFFF)      # what the native loop keys this epoch's draws by
         it = iter(self._index_batches())
         k = 0
 
@@ -829,7 +853,11 @@ class DeviceLoader:
             k += 1
             st.wait_stream(torch.cuda.current_stream(self.ds.dev.device))
             with torch.cuda.stream(st):
-                batch = self.ds[idx]
+                self.ds._draw_override = draw
+                try:
+                    batch = self.ds[idx]
+                finally:
+                    self.ds._draw_override = None
                 ev = torch.cuda.Event()
                 ev.record(st)
             pending.append((batch, ev))

@@ -475,9 +475,14 @@ int gvl_loader_create(const gvl_static *st, const gvl_loader_config *cfg, gvl_lo
  * must stay alive until the epoch ends).  `stream` is the stream `order` was produced on.  The
  * request arrays of the WHOLE epoch are prepared here, with one launch of the prep kernel
  * (gvl_prepare_request over all n indices) into `table`; random draws are keyed by
- * (cfg.seed, epochs started so far, dataset index). */
+ * (cfg.seed, epoch number, dataset index) -- see gvl_loader_set_epoch. */
 int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int32_t drop_last,
                            void *table, void *stream);
+/* Name the epoch the next gvl_loader_start_epoch begins (like DistributedSampler.set_epoch).  The jitter /
+ * shift draw of dataset index i is a function of (cfg.seed, epoch, i) only -- not of the rank, the batch the
+ * index lands in or the batch size -- so every rank passes the same number and an N-GPU epoch draws what the
+ * 1-GPU epoch draws; a resumed run names the epoch it resumes.  Without this call epochs count from 0. */
+int gvl_loader_set_epoch(gvl_loader *ld, uint64_t epoch);
 /* Bytes of the epoch table for n queries and the offsets of its GVL_LOADER_TABLE_PARTS parts (regions i32
  * (n, 4), geno_offset_idx i64 (n, ploidy), shifts i32 (n, ploidy), to_rc u8 (n * ploidy), per-batch track
  * seeds u64 (ceil(n / batch_size))).  The table is the

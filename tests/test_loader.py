@@ -541,3 +541,86 @@ def test_native_ragged_rows_longer_than_the_slot_bound_are_reported(oracle):
         assert int(batch.sizes[1]) <= true_bound
     torch.cuda.synchronize()
     assert lib.gvl_async_error(1) == 0
+
+
+@pytest.mark.gpu
+def test_loader_draws_depend_on_seed_epoch_and_index_only():
+    """The jitter / shift draw of dataset index i in epoch e (``_query.py:160-187``, ``_haps.py:720-730``) is the
+    same whatever rank (world_size 1, 2, 8), batch size or submit loop (native ring, producer thread, Python
+    loop) delivers the index -- what makes an 8-way sharded epoch equal to the 1-GPU epoch -- and differs
+    between epochs and between draw streams."""
+    from genvarloader_amd import HapsDevice
+    from genvarloader_amd.loader import DeviceHapsDataset
+
+    R, S, P, L = 6, 9, 2, 256
+    st, full_regions, go, gv = _grid_dataset(21, R, S, P, L + 64, indel_frac=0.6, slack=0)
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+    ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, jitter=8, deterministic=False, seed=5, onehot=True, haps=False)
+
+    def draws(epoch, world=1, bs=7, stream=1, **kw):
+        got = {}
+        for rank in range(world):
+            dl = ds.to_dataloader(batch_size=bs, shuffle=True, rank=rank, world_size=world, seed=3, draw_stream=stream, **kw)
+            dl.set_epoch(epoch)
+            for b in dl:
+                idx, reg, sh = b.idx.cpu().numpy(), b.regions.cpu().numpy(), b.shifts.cpu().numpy()
+                for i, q in enumerate(idx.tolist()):
+                    row = (int(reg[i, 1]), int(reg[i, 2]), tuple(int(x) for x in sh[i]))
+                    assert got.setdefault(q, row) == row        # (an index padded into two ranks' shares draws alike)
+        assert set(got) == set(range(R * S))
+        return got
+
+    ref = draws(4)
+    assert len({v[0] - int(full_regions[q // S, 1]) for q, v in ref.items()}) > 3        # jitter is on
+    assert any(any(v[2]) for v in ref.values())                                            # ... and so are the shifts
+    for kw in (dict(world=2), dict(world=8, bs=2), dict(bs=3), dict(bs=16), dict(threaded=True), dict(python_loop=True),
+               dict(world=2, bs=5, python_loop=True), dict(group=2, bs=4)):
+        assert draws(4, **kw) == ref, kw
+    assert draws(4) == ref                       # the same loader configuration again: reproducible
+    other_epoch, other_stream = draws(5), draws(4, stream=2)
+    assert sum(other_epoch[q] != ref[q] for q in ref) > len(ref) // 2
+    assert sum(other_stream[q] != ref[q] for q in ref) > len(ref) // 2
+    a, b = ds.to_dataloader(batch_size=7), ds.to_dataloader(batch_size=7)        # default: a stream per loader
+    assert a.draw_seed != b.draw_seed
+
+
+@pytest.mark.gpu
+def test_loader_onehot_only_goes_through_the_lean_kernel(oracle):
+    """One-hot only (the benchmark's output): the ring's batches run recon_lean_kernel; bit-exact against the
+    oracle incl. reverse-complemented rows, and identical to the all-purpose kernel (GVL_DBG 16384)."""
+    from genvarloader_amd import HapsDevice, _lib
+    from genvarloader_amd.loader import DeviceHapsDataset
+
+    R, S, P, L = 8, 11, 2, 512
+    st, full_regions, go, gv = _grid_dataset(22, R, S, P, L, indel_frac=0.4)
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+    assert dev.ref4 is not None and dev.slot_rec is not None
+    ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, onehot=True, haps=False)
+    lib = _lib.load()
+    outs = {}
+    try:
+        for flags in (0, 16384):
+            lib.gvl_set_debug_flags(flags)
+            got = {}
+            for b in ds.to_dataloader(batch_size=9, shuffle=True, seed=1):
+                oh = b.onehot.cpu().numpy()
+                for i, q in enumerate(b.idx.cpu().numpy().tolist()):
+                    got[q] = oh[i].copy()
+            outs[flags] = got
+    finally:
+        lib.gvl_set_debug_flags(-1)
+    idx = np.arange(R * S)
+    r_idx, s_idx = np.unravel_index(idx, (R, S))
+    goi = np.ravel_multi_index((r_idx[:, None], s_idx[:, None], np.arange(P)), (R, S, P))
+    _, _, exp_oh = oracle.reconstruct_haplotypes_fused(
+        full_regions[r_idx], np.zeros_like(goi, dtype=np.int32), goi, go, gv, st.v_starts, st.ilens, st.alt_alleles,
+        st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, L, None, None, np.repeat(full_regions[r_idx, 3] == -1, P), False,
+        onehot=True)
+    exp_oh = exp_oh.reshape(R * S, P, L, 4)
+    for q in idx.tolist():
+        np.testing.assert_array_equal(outs[0][q], exp_oh[q])
+        np.testing.assert_array_equal(outs[16384][q], exp_oh[q])
