@@ -3422,20 +3422,21 @@ int check_launch(const char *what) {
 
 // Errors a kernel finds out about (asynchronous, like a sticky HIP error): one host-mapped word the
 // device writes and gvl_async_error() reads.
+// (the loader's producer thread and the caller's thread can both make the first call: once, and the pointer
+// is published before either of them launches with it)
 int *g_async_err = nullptr;
+std::once_flag g_async_once;
 int *async_err_word() {
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    std::call_once(g_async_once, [] {
         void *p = nullptr;
         if (hipHostMalloc(&p, sizeof(int), hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && p) {
             *(volatile int *)p = 0;
-            g_async_err = (int *)p;
+            __atomic_store_n(&g_async_err, (int *)p, __ATOMIC_RELEASE);
         } else {
             (void)hipGetLastError();
         }
-    }
-    return g_async_err;
+    });
+    return __atomic_load_n(&g_async_err, __ATOMIC_ACQUIRE);
 }
 
 int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
@@ -3490,12 +3491,15 @@ double now_ms() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_se
 struct TraceSite { const char *tag; double sum_ms; long n; };
 TraceSite g_sites[16];
 int g_nsites = 0;
+std::mutex g_sites_mu;          // (the producer thread and the caller both report under GVL_TRACE=2)
 void trace_add(const char *tag, double dt) {
+    std::lock_guard<std::mutex> lk(g_sites_mu);
     for (int i = 0; i < g_nsites; ++i) if (g_sites[i].tag == tag) { g_sites[i].sum_ms += dt; ++g_sites[i].n; return; }
     if (g_nsites < 16) g_sites[g_nsites++] = TraceSite{tag, dt, 1};
 }
 void trace_report() {
     if (trace_level() < 2) return;
+    std::lock_guard<std::mutex> lk(g_sites_mu);
     for (int i = 0; i < g_nsites; ++i)
         fprintf(stderr, "[gvl trace] %-24s %8ld calls  %7.2f us each\n", g_sites[i].tag, g_sites[i].n,
                 1e3 * g_sites[i].sum_ms / (double)g_sites[i].n);
@@ -3522,7 +3526,7 @@ void gvl_diag_set_stamps(void *buf) { g_stamps = (u64 *)buf; }
 const char *gvl_last_error(void) { return g_err; }
 
 int gvl_async_error(int clear) {
-    int *w = g_async_err;
+    int *w = __atomic_load_n(&g_async_err, __ATOMIC_ACQUIRE);
     if (!w) return GVL_OK;
     const int e = *(volatile int *)w;
     if (clear) *(volatile int *)w = 0;
@@ -4433,6 +4437,16 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
     const bool abandoned = ld->submitted * ld->G < ld->n_batches || ld->consumed < ld->n_batches;
     if (abandoned)   // an abandoned epoch's batches still read their table and fill their slots: let them drain
         for (int i = 0; i < c.in_flight; ++i) (void)hipStreamSynchronize(ld->streams[i]);
+    // groups that were handed to the consumer but never released (the epoch ended or was abandoned before the
+    // next gvl_loader_next): their release is recorded HERE, on `stream` -- the consumer's stream by contract --
+    // so that the new epoch's submits wait for whatever the consumer still has queued on those slots
+    if (ld->consumed > 0 && ld->n_sets > 0) {
+        const i64 g_last = (ld->consumed - 1) / ld->G;
+        for (i64 g = ld->released_groups; g <= g_last; ++g)
+            if (hipEventRecord(ld->released[g % ld->n_sets], s) != hipSuccess)
+                return fail(GVL_ERR_HIP, "%s", "gvl_loader_start_epoch: hipEventRecord failed");
+        ld->released_groups = g_last + 1;
+    }
     // the previous epoch's last batches were handed to the consumer: the new table contents must not
     // overtake whatever is still queued on them
     for (int i = 0; i < ld->n_sets; ++i)

@@ -73,13 +73,13 @@ class Batch:
 class DeviceHapsDataset:
     """(regions x samples) grid over a :class:`HapsDevice`.
 
-    ``output_length >= 1``: fixed-length rows (crop / pad), the native batch loop.  ``output_length
-    = -1``: RAGGED rows like the reference's default output (``_haps.py:794-811``: row length = region
-    length + the haplotype's length delta): batches carry flat ``haps`` / ``onehot`` plus
-    ``out_offsets`` and come from the Python submit loop (one host read of the batch's total size
-    per batch, which the exactly-sized allocation forces).  ``annotate=True`` adds the variant-index /
-    reference-position annotations (``reconstruct_annotated_haplotypes_fused``), also through the
-    Python loop.
+    ``output_length >= 1``: fixed-length rows (crop / pad).  ``output_length = -1``: RAGGED rows like the
+    reference's default output (``_haps.py:794-811``: row length = region length + the haplotype's length
+    delta): batches carry flat ``haps`` / ``onehot`` plus ``out_offsets``.  ``annotate=True`` adds the
+    variant-index / reference-position annotations (``reconstruct_annotated_haplotypes_fused``).  All of
+    them ride the native batch loop (ragged rows in ring slots of ``max_row_len()`` bases per row, sized on
+    the device); a custom sampler or ``python_loop=True`` submits from Python instead (ragged: one host read
+    of the batch's total size per batch, which the exactly-sized allocation forces).
 
     ``dev``'s genotype offsets must be laid out like the reference's sparse genotypes: slot
     ``ravel_multi_index((region, sample, ploid), (R, S, P))`` (``_haps.py:757-768``)."""
@@ -781,6 +781,9 @@ class DeviceLoader:
                 if rc:
                     _lib.check(rc)
                 if out.slot < 0:
+                    # errors only a kernel can see (a ragged row longer than the slot bound): the flag is sticky and
+                    # process-global, so polling it here reports anything the batches consumed so far have raised
+                    _lib.check_async()
                     return
                 key = (out.slot, out.batch)
                 batch = ring.get(key)

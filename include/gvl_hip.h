@@ -81,7 +81,8 @@ typedef struct gvl_grec {
 typedef struct gvl_srec {
     int32_t pos;       /* v_starts[v]                                              */
     int32_t ilen;      /* ilens[v]                                                 */
-    uint32_t alen_inl; /* (min(alen, 2^24 - 1) << 8) | first ALT byte              */
+    uint32_t alen_inl; /* (alen << 8) | first ALT byte; alen < 2^24 - 1 (a longer allele marks its slot
+                          GVL_SREC_OVERFLOW: the row then reads the CSR)           */
     uint32_t a0;       /* alt_offsets[v] (the table is only built when alt_len < 2^32) */
 } gvl_srec;
 
@@ -164,7 +165,9 @@ int gvl_abi_version(void);
  * debug_flags() in gvl_hip.hip); flags < 0 returns to the environment's value. */
 int gvl_set_debug_flags(int flags);
 const char *gvl_last_error(void);
-/* Errors only the device can find are reported asynchronously, like a sticky HIP error: after the
+/* (The flag behind gvl_async_error is PROCESS-global: it says that some launch of this process met the
+ * condition, not which one.)
+ * Errors only the device can find are reported asynchronously, like a sticky HIP error: after the
  * stream has been synchronised, gvl_async_error() returns GVL_ERR_INVALID (message in
  * gvl_last_error()) if any launch since the last clear met a row longer than its batch's
  * `max_row_len` hint (such a row is left partly unwritten; the reference writes every byte,
@@ -472,7 +475,9 @@ int64_t gvl_loader_slot_bytes(const gvl_loader_config *cfg, int64_t *part_offset
 /* `st` is copied; the device arrays it points to must outlive the loader. */
 int gvl_loader_create(const gvl_static *st, const gvl_loader_config *cfg, gvl_loader **out);
 /* Begin an epoch over `order` (device i64[n] dataset indices, already shuffled by the caller;
- * must stay alive until the epoch ends).  `stream` is the stream `order` was produced on.  The
+ * must stay alive until the epoch ends).  `stream` is the stream `order` was produced on AND the stream the
+ * consumer reads its batches on (the one passed to gvl_loader_next): batches of the previous epoch that are
+ * still held by the consumer are released on it, and the new epoch's table is ordered behind it.  The
  * request arrays of the WHOLE epoch are prepared here, with one launch of the prep kernel
  * (gvl_prepare_request over all n indices) into `table`; random draws are keyed by
  * (cfg.seed, epoch number, dataset index) -- see gvl_loader_set_epoch. */

@@ -531,10 +531,14 @@ def test_native_ragged_rows_longer_than_the_slot_bound_are_reported(oracle):
     ds._max_row_len = 200                        # every region is 300 long
     lib = _lib.load()
     lib.gvl_async_error(1)
-    for batch in ds.to_dataloader(batch_size=5, shuffle=False):
-        assert int(batch.sizes[1]) == 200 and int(batch.sizes[0]) == 200 * batch.idx.numel() * P
+    n_seen = 0
+    with pytest.raises(ValueError, match="max_row_len"):       # the loader polls the flag when the epoch ends
+        for batch in ds.to_dataloader(batch_size=5, shuffle=False):
+            assert int(batch.sizes[1]) == 200 and int(batch.sizes[0]) == 200 * batch.idx.numel() * P
+            n_seen += 1
+    assert n_seen == -(-R * S // 5)                               # ... after every batch was delivered
     torch.cuda.synchronize()
-    assert lib.gvl_async_error(1) != 0
+    assert lib.gvl_async_error(1) == 0                            # (the poll cleared it)
     ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=-1, onehot=False, haps=True)
     assert ds.max_row_len() == true_bound >= L
     for batch in ds.to_dataloader(batch_size=5, shuffle=False):
