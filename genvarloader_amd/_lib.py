@@ -114,7 +114,7 @@ class GvlLoaderConfig(C.Structure):
 
 
 LOADER_SLOT_PARTS = 12       # GVL_LOADER_SLOT_PARTS
-LOADER_TABLE_PARTS = 5       # GVL_LOADER_TABLE_PARTS
+LOADER_TABLE_PARTS = 7       # GVL_LOADER_TABLE_PARTS
 
 
 class GvlLoaderBatch(C.Structure):

@@ -2365,6 +2365,60 @@ __global__ __launch_bounds__(256) void track_lengths_kernel(const DiffArgs A, co
     }
 }
 
+// The same for every query of an EPOCH (gvl_loader_start_epoch: the jittered regions and the length deltas of
+// every query are known there), laid out per batch: batch j's (bs + 1) scan slots at lengths[j * (bs + 1) ..],
+// slot 0 = 0; track_scan_batches_kernel then turns each batch's slots into its scratch-track offsets.  A batch
+// of the epoch then costs no sizing launch at all (they were 19 us of cfg4's 143 us step).
+__global__ __launch_bounds__(256) void track_lengths_epoch_kernel(const DiffArgs A, const int *regions, i64 regions_stride, i64 n,
+                                                                   i64 bs, i64 out_len, i64 *lengths, i64 *out_offsets) {
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 K = bs * A.ploidy;
+    for (i64 k = t; k <= K; k += (i64)gridDim.x * blockDim.x) out_offsets[k] = k * out_len;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const i64 q = t >> 6;                                    // one wave per query
+    if (q >= n) return;
+    const int *reg = regions + q * regions_stride;
+    const i64 qs = rfl(reg[1]), qe = rfl(reg[2]);
+    i64 mn = 0;
+    for (int p = 0; p < A.ploidy; ++p) {
+        const i64 d = (i64)(int)row_diff_wave(A, rfl64(A.geno_offset_idx[q * A.ploidy + p]), false, 0, true, qs, qe, lane);
+        mn = d < mn ? d : mn;
+    }
+    if (lane == 0) {
+        const i64 j = q / bs, i = q - j * bs;
+        lengths[j * (bs + 1) + i + 1] = (qe - qs) - mn;
+        if (i == 0) lengths[j * (bs + 1)] = 0;
+    }
+}
+// one workgroup per batch: inclusive scan of its (bs + 1) slots in place (slot 0 is 0, so slot i = offset of query i)
+__global__ __launch_bounds__(256) void track_scan_batches_kernel(i64 *lengths, i64 n, i64 bs) {
+    __shared__ i64 wsum[4];
+    __shared__ i64 carry_s;
+    const i64 j = blockIdx.x;
+    const i64 cnt = (n - j * bs < bs ? n - j * bs : bs) + 1;
+    i64 *a = lengths + j * (bs + 1);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (i64 base = 0; base < cnt; base += 256) {
+        const i64 i = base + tid;
+        i64 sc = i < cnt ? a[i] : 0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const i64 y = __shfl_up(sc, o, 64);
+            if (lane >= o) sc += y;
+        }
+        if (lane == 63) wsum[wv] = sc;
+        __syncthreads();
+        i64 pre = carry_s;
+        for (int w = 0; w < wv; ++w) pre += wsum[w];
+        if (i < cnt) a[i] = sc + pre;
+        __syncthreads();
+        if (tid == 255) carry_s = sc + pre;
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------
 // choose_exonic_variants (src/genotypes/mod.rs:127-176): keep[v] = the variant lies entirely
 // inside its query's [start, end).  Offsets first (counts -> the scan above), then the mask.
@@ -3470,6 +3524,7 @@ int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
 //  8192  painter always paints an LDS image (no start-bitmap lookup for non-overlapping candidates)
 // 16384  no lean kernel (the all-purpose kernel over every row, as before round 3)
 // 32768  the lean kernel hands EVERY row to its solo general path (per-wave scans from the byte reference)
+// 131072 the native loop sizes the scratch tracks per batch (not once per epoch)
 // 65536  the lean kernel re-reads the runs of a row with indels from memory (never re-aligns the speculative window in LDS)
 // and 1 / 2 / 4 = timing ablations (no variants / no stores / no loads).
 int g_debug_override = -1;
@@ -4134,7 +4189,8 @@ int64_t gvl_tracks_scratch_bytes(int64_t batch, int64_t ploidy, int64_t scratch_
 
 static int tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const int64_t *offset_idxs, const gvl_track_set *tracks,
                              int32_t n_tracks, const double *params, int64_t strategy_id, uint64_t base_seed, const u64 *seed_ptr,
-                             float *out, int64_t out_track_stride, void *scratch, int64_t scratch_stride, void *stream);
+                             float *out, int64_t out_track_stride, void *scratch, int64_t scratch_stride, void *stream,
+                             const i64 *pre_track_offsets = nullptr, const i64 *pre_out_offsets = nullptr);
 int gvl_tracks_batch(const gvl_static *st, const gvl_batch *bt, const int64_t *offset_idxs, const gvl_track_set *tracks,
                      int32_t n_tracks, const double *params, int64_t strategy_id, uint64_t base_seed, float *out,
                      int64_t out_track_stride, void *scratch, int64_t scratch_stride, void *stream) {
@@ -4143,7 +4199,8 @@ int gvl_tracks_batch(const gvl_static *st, const gvl_batch *bt, const int64_t *o
 }
 static int tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const int64_t *offset_idxs, const gvl_track_set *tracks,
                              int32_t n_tracks, const double *params, int64_t strategy_id, uint64_t base_seed, const u64 *seed_ptr,
-                             float *out, int64_t out_track_stride, void *scratch, int64_t scratch_stride, void *stream) {
+                             float *out, int64_t out_track_stride, void *scratch, int64_t scratch_stride, void *stream,
+                             const i64 *pre_track_offsets, const i64 *pre_out_offsets) {
     if (!st || !bt || n_tracks < 0) return fail(GVL_ERR_INVALID, "%s", "gvl_tracks_batch: bad arguments");
     if (bt->batch < 0 || bt->ploidy <= 0 || bt->output_length < 0)
         return fail(GVL_ERR_INVALID, "%s", "gvl_tracks_batch: needs batch >= 0, ploidy > 0 and a fixed output_length");
@@ -4162,12 +4219,16 @@ static int tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const in
     i64 *out_offsets = (i64 *)(base + part[1]);
     PaintTodo *todo = (PaintTodo *)(base + part[2]);
     float *scr = (float *)(base + part[3]);
-    // 1. scratch-track lengths -> offsets (the reference sizes the scratch track per query, _reconstruct.py:191)
+    // 1. scratch-track lengths -> offsets (the reference sizes the scratch track per query, _reconstruct.py:191);
+    // the native loop has them for every batch of the epoch already (gvl_loader_start_epoch)
     DiffArgs D;
     int rc = fill_diff_args(D, st, bt, "gvl_tracks_batch");
     if (rc) return rc;
     D.keep = nullptr; D.keep_offsets = nullptr;
-    {
+    if (pre_track_offsets && pre_out_offsets) {
+        track_offsets = const_cast<i64 *>(pre_track_offsets);
+        out_offsets = const_cast<i64 *>(pre_out_offsets);
+    } else {
         const i64 grid = (B * WAVE + 255) / 256;            // one wave per query (covers the K + 1 offsets too)
         track_lengths_kernel<<<dim3((unsigned)grid), dim3(256), 0, s>>>(D, bt->regions, (i64)bt->regions_stride, B, L, track_offsets, out_offsets);
         rc = check_launch("gvl_tracks_batch(lengths)");
@@ -4278,6 +4339,7 @@ struct gvl_loader {
     i64 submitted, consumed;      // submitted: GROUPS handed to the GPU; consumed: BATCHES handed to the caller
     i64 released_groups;          // groups whose release has been recorded on the consumer's stream
     int G, n_sets;
+    i64 *e_track_offsets, *e_out_offsets;   // tracks: every batch's scratch-track offsets ((bs + 1) per batch) and the k * L output offsets
     u64 counter;                  // the running epoch's number + 1 (keys the random draws together with cfg.seed)
     bool epoch_set;               // gvl_loader_set_epoch named the next epoch (else: epochs started so far)
     u64 next_epoch;
@@ -4324,7 +4386,10 @@ int64_t gvl_loader_slot_bytes(const gvl_loader_config *cfg, int64_t *part_offset
 int64_t gvl_loader_table_bytes(const gvl_loader_config *cfg, int64_t n, int64_t *part_offsets) {
     if (!cfg || cfg->ploidy <= 0 || cfg->batch_size <= 0 || n < 0) return -1;
     const i64 P = cfg->ploidy;
-    const i64 sizes[GVL_LOADER_TABLE_PARTS] = {16 * n, 8 * n * P, 4 * n * P, n * P, 8 * ((n + cfg->batch_size - 1) / cfg->batch_size)};
+    const i64 nb = (n + cfg->batch_size - 1) / cfg->batch_size;
+    const bool tr = cfg->n_tracks > 0;
+    const i64 sizes[GVL_LOADER_TABLE_PARTS] = {16 * n, 8 * n * P, 4 * n * P, n * P, 8 * nb,
+                                               tr ? 8 * (n + nb) : 0, tr ? 8 * (cfg->batch_size * P + 1) : 0};
     i64 off = 0;
     for (int i = 0; i < GVL_LOADER_TABLE_PARTS; ++i) {
         if (part_offsets) part_offsets[i] = off;
@@ -4461,6 +4526,8 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
         ld->e_shifts = (int *)(base + po[2]);
         ld->e_to_rc = base + po[3];
         ld->e_seeds = (u64 *)(base + po[4]);
+        ld->e_track_offsets = (i64 *)(base + po[5]);
+        ld->e_out_offsets = (i64 *)(base + po[6]);
     }
     const i64 bs = c.batch_size;
     ld->order = order; ld->n_order = n;
@@ -4481,6 +4548,26 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
                                                                           c.seed, ld->counter, ld->e_seeds);
             const int rc2 = check_launch("gvl_loader_start_epoch(seeds)");
             if (rc2) return rc2;
+        }
+        if (c.n_tracks > 0) {
+            // the scratch-track sizing of every batch of the epoch: lengths (one wave per query), then one scan per batch
+            gvl_batch eb;
+            memset(&eb, 0, sizeof(eb));
+            eb.regions = ld->e_regions; eb.regions_stride = 4; eb.shifts = ld->e_shifts; eb.geno_offset_idx = (const int64_t *)ld->e_goi;
+            eb.batch = n_used; eb.ploidy = c.ploidy; eb.output_length = c.output_length;
+            DiffArgs D;
+            int rc3 = fill_diff_args(D, &ld->st, &eb, "gvl_loader_start_epoch");
+            if (rc3) return rc3;
+            D.keep = nullptr; D.keep_offsets = nullptr;
+            const i64 grid = (n_used * WAVE + 255) / 256;
+            if (grid > 0x7FFFFFFFll) return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_loader_start_epoch: too many queries for the track sizing");
+            track_lengths_epoch_kernel<<<dim3((unsigned)grid), dim3(256), 0, s>>>(D, ld->e_regions, 4, n_used, bs, c.output_length,
+                                                                                   ld->e_track_offsets, ld->e_out_offsets);
+            rc3 = check_launch("gvl_loader_start_epoch(track lengths)");
+            if (rc3) return rc3;
+            track_scan_batches_kernel<<<dim3((unsigned)ld->n_batches), dim3(256), 0, s>>>(ld->e_track_offsets, n_used, bs);
+            rc3 = check_launch("gvl_loader_start_epoch(track offsets)");
+            if (rc3) return rc3;
         }
     }
     if (hipEventRecord(ld->epoch_ready, s) != hipSuccess)
@@ -4566,7 +4653,9 @@ static int loader_submit(gvl_loader *ld, i64 g) {
             u8 *base = (u8 *)ld->arenas[o.slot];
             (void)traced("launch tracks", [&] {
                 rc = tracks_batch_impl(&ld->st, &bts[m], (const int64_t *)o.idx, ld->tracks, c.n_tracks, par, c.strategy_id, c.track_seed,
-                                       (const u64 *)o.track_seed, o.tracks, K * c.output_length, base + ld->part[10], c.scratch_stride, s);
+                                       (const u64 *)o.track_seed, o.tracks, K * c.output_length, base + ld->part[10], c.scratch_stride, s,
+                                       (debug_flags() & 131072) ? nullptr : ld->e_track_offsets + j * (c.batch_size + 1),
+                                       (debug_flags() & 131072) ? nullptr : ld->e_out_offsets);
                 return hipSuccess;
             });
             if (rc) return rc;

@@ -35,7 +35,14 @@ def _dev(x, dtype: torch.dtype, device) -> torch.Tensor | None:
         a = np.ascontiguousarray(x)
         if a.dtype == np.bool_:
             a = a.view(np.uint8)
-        t = torch.from_numpy(a)
+        if a.flags.writeable:
+            t = torch.from_numpy(a)
+        else:       # a read-only memmap (what the reference hands over): it is only ever copied to the device
+            import warnings
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", UserWarning)
+                t = torch.from_numpy(a)
     if t.dtype == torch.bool:
         t = t.view(torch.uint8) if t.is_contiguous() else t.contiguous().view(torch.uint8)
     if t.dtype != dtype:

@@ -46,26 +46,48 @@ _STATIC_CACHE: "OrderedDict[tuple, HapsDevice]" = OrderedDict()
 _STATIC_CACHE_MAX = 4
 
 
-def _key(a):
-    """Cache key of a per-dataset host array: address, shape, dtype AND a content fingerprint, so
-    that an in-place edit of a cached array is a miss (re-upload) and not silently ignored.  The
-    fingerprint is exact below 1 MiB and a strided sample of 4096 elements (plus both ends) above --
-    the arrays are per-dataset constants by contract (``_HapsFfiStatic``, _haps.py:233-247), this
-    only guards against accidents; ``clear_static_cache()`` forces a re-upload."""
+_FP_CACHE: dict = {}       # id(array) -> (weakref, key): fingerprints of READ-ONLY arrays, taken once per object
+
+
+def _fingerprint(a: np.ndarray) -> int:
     import zlib
 
-    a = np.asarray(a)
     flat = a.reshape(-1)
     if flat.size == 0:
-        fp = 0
-    elif a.nbytes <= (1 << 20):
-        fp = zlib.adler32(np.ascontiguousarray(flat).view(np.uint8))
-    else:
-        step = max(1, flat.size // 4096)
-        fp = zlib.adler32(np.ascontiguousarray(flat[::step]).view(np.uint8))
-        fp = zlib.adler32(np.ascontiguousarray(flat[:64]).view(np.uint8), fp)
-        fp = zlib.adler32(np.ascontiguousarray(flat[-64:]).view(np.uint8), fp)
-    return (a.__array_interface__["data"][0], a.shape, a.dtype.str, fp)
+        return 0
+    if a.nbytes <= (1 << 20):
+        return zlib.adler32(np.ascontiguousarray(flat).view(np.uint8))
+    step = max(1, flat.size // 512)
+    fp = zlib.adler32(np.ascontiguousarray(flat[::step]).view(np.uint8))
+    fp = zlib.adler32(np.ascontiguousarray(flat[:64]).view(np.uint8), fp)
+    return zlib.adler32(np.ascontiguousarray(flat[-64:]).view(np.uint8), fp)
+
+
+def _key(a):
+    """Cache key of a per-dataset host array: address, shape, dtype AND a content fingerprint, so
+    that an in-place edit of a cached array is a miss (re-upload) and not silently ignored.
+
+    A READ-ONLY array -- what the reference hands over: ``np.memmap(..., mode="r")`` of the dataset's files,
+    ``_haps.py:435-460`` -- cannot be edited through that object: it is fingerprinted ONCE (remembered per
+    object, by id + weakref), so a call does not touch a genome-scale memmap at all.  A writable array is
+    fingerprinted on every call: exactly below 1 MiB, a strided sample of 512 elements (plus both ends)
+    above -- the arrays are per-dataset constants by contract (``_HapsFfiStatic``, _haps.py:233-247), this
+    only guards against accidents; ``clear_static_cache()`` forces a re-upload."""
+    import weakref
+
+    a = np.asarray(a)
+    if not a.flags.writeable:
+        hit = _FP_CACHE.get(id(a))
+        if hit is not None and hit[0]() is a:
+            return hit[1]
+        key = (a.__array_interface__["data"][0], a.shape, a.dtype.str, _fingerprint(a))
+        try:
+            i = id(a)
+            _FP_CACHE[i] = (weakref.ref(a, lambda _r, i=i: _FP_CACHE.pop(i, None)), key)
+        except TypeError:
+            pass
+        return key
+    return (a.__array_interface__["data"][0], a.shape, a.dtype.str, _fingerprint(a))
 
 
 def _req(a, dt, name, ndim=None):

@@ -128,5 +128,9 @@ def test_loader_slot_and_table_layout(lib):
     po = (C.c_int64 * _lib.LOADER_TABLE_PARTS)()
     lib.gvl_loader_table_bytes.restype = C.c_int64
     nb = int(lib.gvl_loader_table_bytes(C.byref(cfg), C.c_int64(100), po))
-    assert [int(x) for x in po] == [0, up(1600), up(1600) + up(1600), up(1600) + up(1600) + up(800), up(1600) + up(1600) + up(800) + 256]
-    assert nb == int(po[4]) + up(8 * 13)
+    assert [int(x) for x in po][:5] == [0, up(1600), up(1600) + up(1600), up(1600) + up(1600) + up(800), up(1600) + up(1600) + up(800) + 256]
+    assert nb == int(po[4]) + up(8 * 13) and int(po[5]) == int(po[6]) == nb          # no tracks: the two sizing parts are empty
+    cfg_t = _lib.GvlLoaderConfig(ploidy=2, batch_size=8, n_tracks=1)
+    nb_t = int(lib.gvl_loader_table_bytes(C.byref(cfg_t), C.c_int64(100), po))
+    # with tracks: every batch's (batch_size + 1) scratch-track offsets + the batch_size * ploidy + 1 row offsets
+    assert int(po[6]) - int(po[5]) == up(8 * (100 + 13)) and nb_t - int(po[6]) == up(8 * 17)

@@ -7,6 +7,9 @@ import genvarloader_amd.ffi as ffi
 
 st, bt = synth.make_config("cfg3")
 K, L = bt.n_windows, bt.output_length
+if "--readonly" in sys.argv:      # what the reference passes: read-only memmaps -> fingerprinted once per object
+    for a in (bt.geno_offsets, bt.geno_v_idxs, st.v_starts, st.ilens, st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets):
+        a.flags.writeable = False
 args = (bt.regions, bt.shifts, bt.geno_offset_idx, bt.geno_offsets, bt.geno_v_idxs, st.v_starts, st.ilens, st.alt_alleles,
         st.alt_offsets, st.ref, st.ref_offsets, np.uint8(st.pad_char), np.int64(L), None, None, bt.to_rc, True)
 for name, fn, nbytes in (("reconstruct_haplotypes_fused (u8 haplotypes to host)", lambda: ffi.reconstruct_haplotypes_fused(*args), K * L),
