@@ -492,7 +492,7 @@ def main() -> None:
         gather_ms = tm.allmax([float(np.median(ts)) * 1e3])[0]
 
     lean = (dev.ref4 is not None and dev.slot_rec is not None and not args.haps and L <= 2048 and L % 4 == 0
-            and (int(os.environ.get("GVL_DBG", "0")) & ~(2 | 4 | 32768 | 65536)) == 0)
+            and (int(os.environ.get("GVL_DBG", "0")) & ~(2 | 4 | 32768 | 65536 | 262144 | 524288)) == 0)
     if rank == 0:
         ms_per_step = region_ms / steps
         abytes = algorithmic_bytes_per_window(L, mean_v, args.haps, True) * K

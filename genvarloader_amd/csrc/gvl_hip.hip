@@ -3525,6 +3525,8 @@ int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
 // 16384  no lean kernel (the all-purpose kernel over every row, as before round 3)
 // 32768  the lean kernel hands EVERY row to its solo general path (per-wave scans from the byte reference)
 // 131072 the native loop sizes the scratch tracks per batch (not once per epoch)
+// 262144 / 524288  timing ablations of the lean kernel (WRONG output for rows with indels): no re-alignment / allele
+//        bytes (phases A and B as for a SNP-only row); no scan plan either
 // 65536  the lean kernel re-reads the runs of a row with indels from memory (never re-aligns the speculative window in LDS)
 // and 1 / 2 / 4 = timing ablations (no variants / no stores / no loads).
 int g_debug_override = -1;
@@ -3786,7 +3788,7 @@ static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_o
     if (bt->output_length <= 0 || bt->output_length > LEAN_MAX_TRIPS * TRIP || (bt->output_length & 3)) return false;
     if (bt->batch * bt->ploidy <= 0 || bt->batch * bt->ploidy > 0x7FFFFFFFll / (4 * LEAN_MAX_TRIPS * TRIP)) return false;
     if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;     // u32 positions in the kernel
-    return (debug_flags() & ~(2 | 4 | 32768 | 65536)) == 0;
+    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288)) == 0;
 }
 
 static int launch_lean(const ReconArgs &RA, void *stream) {
@@ -3794,7 +3796,7 @@ static int launch_lean(const ReconArgs &RA, void *stream) {
     memset(&A, 0, sizeof(A));
     A.ref4 = RA.ref4; A.ref_offsets = RA.ref_offsets; A.srec = RA.srec;
     A.regions = RA.regions; A.shifts = RA.shifts; A.geno_offset_idx = RA.geno_offset_idx; A.to_rc = RA.to_rc;
-    A.onehot = RA.onehot; A.out_offsets_w = RA.out_offsets_w; A.alt_alleles = RA.alt_alleles;
+    A.onehot = RA.onehot; A.out_offsets_w = RA.out_offsets_w; A.alt_alleles = RA.alt_alleles; A.stamps = RA.stamps;
     A.go_starts = RA.go_starts; A.go_stops = RA.go_stops; A.grec = RA.grec; A.alt_offsets = RA.alt_offsets;
     A.n_geno_offsets = RA.n_geno_offsets;
     A.n_rows = (int)RA.n_rows; A.n_contigs = RA.n_contigs; A.regions_stride = (int)RA.regions_stride;

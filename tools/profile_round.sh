@@ -13,23 +13,24 @@ cd $R
 [ -x $R/tools/kbench.bin ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 $R/tools/kbench.hip -o $R/tools/kbench.bin
 b() { local name=$1; shift; timeout 900 python3 bench.py "$@" > $T/bench_$name.json 2> $T/bench_$name.err || echo "bench $name FAILED" | tee -a $T/status.txt; }
 b default
-for i in 1 2 3; do b k20_$i --steps 20 --warmup 5 --no-cpu-baseline; b k2000_$i --steps 2000 --warmup 50 --no-cpu-baseline; done
-b hot_small --scale small --rotate 1 --no-cpu-baseline
-b cfg2 --workload cfg2 --no-cpu-baseline
-b cfg3_haps --haps --no-cpu-baseline
+for i in 1 2 3; do b k20_$i --steps 20 --warmup 5 --no-cpu-baseline; b k2000_$i --steps 2000 --warmup 50 --no-cpu-baseline --sustained-s 0; done
+GVL_DBG=16384 b nolean --no-cpu-baseline --sustained-s 0
+b hot_small --scale small --rotate 1 --no-cpu-baseline --sustained-s 0
+b cfg2 --workload cfg2 --no-cpu-baseline --sustained-s 0
+b cfg3_haps --haps --no-cpu-baseline --sustained-s 0
 b cfg4 --workload cfg4 --steps 20 --warmup 3
 b cfg1_cpu --workload cfg1 --cpu-only
 timeout 300 $R/tools/kbench.bin > $T/kbench.txt 2>&1
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats_default -- python3 $R/bench.py --no-cpu-baseline > $T/stats_default.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats_1stream -- python3 $R/bench.py --no-cpu-baseline --streams 1 --no-hot > $T/stats_1stream.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats_1stream_hot -- python3 $R/bench.py --no-cpu-baseline --streams 1 --no-hot --scale small --rotate 1 > $T/stats_1stream_hot.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats_default -- python3 $R/bench.py --no-cpu-baseline --sustained-s 0 --min-region-ms 100 > $T/stats_default.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats_1stream -- python3 $R/bench.py --no-cpu-baseline --streams 1 --no-hot --sustained-s 0 --min-region-ms 100 > $T/stats_1stream.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats_1stream_hot -- python3 $R/bench.py --no-cpu-baseline --streams 1 --no-hot --sustained-s 0 --min-region-ms 100 --scale small --rotate 1 > $T/stats_1stream_hot.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $T/pmc_cold_$c -- python3 $R/bench.py --no-cpu-baseline --no-hot --streams 1 --steps 30 --warmup 5 --min-region-ms 1 > $T/pmc_cold_$c.log 2>&1
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $T/pmc_hot_$c -- python3 $R/bench.py --no-cpu-baseline --no-hot --streams 1 --steps 30 --warmup 5 --min-region-ms 1 --scale small --rotate 1 > $T/pmc_hot_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $T/pmc_cold_$c -- python3 $R/bench.py --no-cpu-baseline --no-hot --streams 1 --steps 30 --warmup 5 --min-region-ms 1 --sustained-s 0 > $T/pmc_cold_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $T/pmc_hot_$c -- python3 $R/bench.py --no-cpu-baseline --no-hot --streams 1 --steps 30 --warmup 5 --min-region-ms 1 --sustained-s 0 --scale small --rotate 1 > $T/pmc_hot_$c.log 2>&1
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $T/pmc_kbench_$c -- $R/tools/kbench.bin > $T/pmc_kbench_$c.log 2>&1
 done
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAVES --output-format csv -d $T/pmc_cold_SQ -- python3 $R/bench.py --no-cpu-baseline --no-hot --streams 1 --steps 30 --warmup 5 --min-region-ms 1 > $T/pmc_cold_SQ.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAVES --output-format csv -d $T/pmc_cold_SQ -- python3 $R/bench.py --no-cpu-baseline --no-hot --streams 1 --steps 30 --warmup 5 --min-region-ms 1 --sustained-s 0 > $T/pmc_cold_SQ.log 2>&1
 for d in stats_default stats_1stream stats_1stream_hot; do echo "== $d"; head -3 $(find $T/$d -name "*kernel_stats.csv" | head -1) | cut -c1-220; done
 python3 - $T <<'PY'
 import csv, sys, glob, collections, json
@@ -41,7 +42,7 @@ for tag in ("pmc_cold_FETCH_SIZE", "pmc_cold_WRITE_SIZE", "pmc_hot_FETCH_SIZE", 
     for r in csv.DictReader(open(f[0])):
         acc[(r["Kernel_Name"][:60], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in acc.items():
-        if "reconstruct" in k or "k_" in k:
+        if "reconstruct" in k or "recon_lean" in k or "k_" in k:
             print(f"{tag:24s} {k:60s} {c:18s} n={len(v):4d} mean={sum(v)/len(v):14.1f}")
 for f in sorted(glob.glob(f"{T}/bench_*.json")):
     try:
