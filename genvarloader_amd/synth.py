@@ -204,12 +204,15 @@ def make_batch(
     lookback: int = 40,
     edge_frac: float = 0.0,
     permute_csr: bool = False,
+    contig_start_frac: float = 0.0,
 ) -> SynthBatch:
     """``n_queries`` regions of ``length + 2*slack`` bp, ``ploidy`` haplotypes each.
 
     ``edge_frac`` of the regions are pushed over a contig edge (negative start /
     end past the contig) to exercise the padding branches.  ``output_length``
-    defaults to ``length`` (fixed-length crop); pass ``-1`` for ragged."""
+    defaults to ``length`` (fixed-length crop); pass ``-1`` for ragged.  ``contig_start_frac`` of the
+    regions begin within 8 bases of their contig's first base (an insertion there is longer than the
+    reference in front of it)."""
     B, P = int(n_queries), int(ploidy)
     n_contigs = len(st.ref_offsets) - 1
     clens = np.diff(st.ref_offsets)
@@ -223,6 +226,9 @@ def make_batch(
         off = rng.integers(1, max(2, span // 2), B)
         start = np.where(edge & left, -off, start)
         start = np.where(edge & ~left, clens[contig] - span + off, start)
+    if contig_start_frac > 0:       # windows that begin within a few bases of their contig's first base
+        near = rng.random(B) < contig_start_frac
+        start = np.where(near, rng.integers(0, 8, B), start)
     end = start + span
     strand = np.where(rng.random(B) < rc_frac, -1, 1)
     regions = np.stack([contig, start, end, strand], axis=1).astype(np.int32)

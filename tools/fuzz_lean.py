@@ -31,7 +31,8 @@ def one_case(rng):
     q = int(rng.integers(1, 40))
     bt = synth.make_batch(rng, st, q, ploidy, L, slack=int(rng.choice([0, 8, 40])), rc_frac=float(rng.choice([0.0, 0.5, 1.0])),
                           random_shifts=False, lookback=int(rng.choice([0, 40, 300, 3200])),
-                          edge_frac=float(rng.choice([0.0, 0.0, 0.3, 1.0])), permute_csr=bool(rng.random() < 0.5))
+                          edge_frac=float(rng.choice([0.0, 0.0, 0.3, 1.0])), permute_csr=bool(rng.random() < 0.5),
+                          contig_start_frac=float(rng.choice([0.0, 0.0, 0.5])))
     if rng.random() < 0.6:
         hi = int(rng.choice([1, 5, 40, 400, 3000]))
         bt.shifts = rng.integers(0, hi + 1, bt.shifts.shape).astype(np.int32)
