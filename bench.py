@@ -503,7 +503,8 @@ def main() -> None:
         if tf.exists():
             try:
                 traffic = json.loads(tf.read_text()).get(
-                    f"{args.workload}{'+haps' if args.haps else ''}@{args.scale}" + ("" if n_rot > 1 else "@hot"))
+                    f"{args.workload}{'+haps' if args.haps else ''}@{args.scale}" + ("" if n_rot > 1 else "@hot")
+                    + ("" if lean or args.workload != "cfg3" or args.haps else "@allpurpose"))
             except Exception:
                 traffic = None
         sizes = ds.nbytes()

@@ -55,4 +55,7 @@ for c in (0, 1, 2, 3):
         for i in (11, 12, 13, 14):
             print(f"      {sub[i]:25s} +{np.median(r[:, i] - r[:, prev]):8.0f} ticks"); prev = i
     if c != 3:
-        print(f"   whole wave                   {np.median(r[:, 7] - r[:, 0]):8.0f} ticks;  start after the launch's first wave: median {np.median((r[:, 10] - min(x[:, 10][x[:, 10] > 0].min() for x in acc)) * 10):.0f} ns (100 MHz clock)")
+        print(f"   whole wave                   {np.median(r[:, 7] - r[:, 0]):8.0f} ticks")
+    if c == 3:
+        print("   why (1 window/shape, 2 slot overflow beyond 64 or no inline records, 3 odd record, 4 / 6 trailing pad, 5 no fixed point):",
+              dict(zip(*[x.tolist() for x in np.unique(r[:, 9].astype(int), return_counts=True)])))
