@@ -315,10 +315,12 @@ static void job_drain(pool_job *job)
     }
 }
 
-static void *pool_worker(void *unused)
+static void *pool_worker(void *born_at)
 {
-    (void)unused;
-    uint64_t seen = 0;
+    /* the job generation when this worker was created (gvlo_pool_resize holds the mutex while it creates
+     * workers, so no job can be posted in between): a worker born into a pool that has already run jobs must
+     * not mistake the old generation count for a new job -- g_pool.job is NULL then */
+    uint64_t seen = (uint64_t)(uintptr_t)born_at;
     pthread_mutex_lock(&g_pool.mu);
     for (;;) {
         while (!g_pool.stop && g_pool.generation == seen) pthread_cond_wait(&g_pool.cv_work, &g_pool.mu);
@@ -358,7 +360,7 @@ GVLO_EXPORT int gvlo_pool_resize(int n_threads)
             g_pool.th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)want);
             int started = 0;
             for (int t = 0; g_pool.th && t < want; t++)
-                if (pthread_create(&g_pool.th[started], NULL, pool_worker, NULL) == 0) started++;
+                if (pthread_create(&g_pool.th[started], NULL, pool_worker, (void *)(uintptr_t)g_pool.generation) == 0) started++;
             g_pool.n_workers = started;
         }
     }
