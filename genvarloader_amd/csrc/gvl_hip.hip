@@ -3155,7 +3155,8 @@ struct PaintIndex { const i64 *offsets; const int *base; const int *lo; const in
 __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
     const i64 *offset_idxs, const int *starts, i64 starts_stride, i64 n_queries, const int *itv_starts,
     const int *itv_ends, const float *itv_values, const i64 *itv_offsets, const int *pmax, float *out,
-    const i64 *out_offsets, int chunk_len, int n_chunks, PaintTodo *chunk_todo, const PaintIndex X, const int force_image) {
+    const i64 *out_offsets, int chunk_len, int n_chunks, PaintTodo *chunk_todo, const PaintIndex X, const int force_image,
+    int *complete_err) {      // non-NULL: the caller vouched that no chunk needs the leftovers launch (gvl_track_set.tile_complete)
     __shared__ PaintTile tiles[4];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = rfl((int)(threadIdx.x >> 6));
@@ -3241,7 +3242,7 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
     }
     const i64 n_c64 = hi_c - lo_c;
     PaintTodo *todo = chunk_todo + q * n_chunks + chunk;
-    if (n_c64 > PAINT_TILE) { if (lane == 0) todo->flag = 1; return; }         // the per-value path takes it
+    if (n_c64 > PAINT_TILE) { if (lane == 0) { todo->flag = 1; if (complete_err) *complete_err = 2; } return; }   // the per-value path takes it
     if (lane == 0) todo->flag = 0;
     const int n_c = (int)n_c64;
     const int clen = (int)(j1 - j0);
@@ -3340,7 +3341,7 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     // overlapping candidates or equal starts: the leftovers kernel paints this chunk into an LDS image
-    if (lane == 0) { todo->flag = 2; todo->n_c = n_c; todo->lo_c = lo_c; }
+    if (lane == 0) { todo->flag = 2; todo->n_c = n_c; todo->lo_c = lo_c; if (complete_err) *complete_err = 2; }
 }
 
 // bucket counts of every list (written at counts[i + 1] for the scan) and the list's base position
@@ -3588,6 +3589,7 @@ int gvl_async_error(int clear) {
     const int e = *(volatile int *)w;
     if (clear) *(volatile int *)w = 0;
     if (e == 1) return fail(GVL_ERR_INVALID, "%s", "a launch found a row longer than its batch's max_row_len hint: that row was left partly unwritten");
+    if (e == 2) return fail(GVL_ERR_INVALID, "%s", "an interval set marked tile_complete has a chunk with overlapping intervals, equal starts or more than 256 candidates: that chunk was left unpainted");
     return e ? fail(GVL_ERR_INVALID, "%s", "asynchronous device-side error") : GVL_OK;
 }
 
@@ -4064,14 +4066,20 @@ int gvl_intervals_bucket_fill(const int32_t *itv_starts, const int32_t *itv_pmax
 static int paint_launch(const int64_t *offset_idxs, const int32_t *starts, int64_t starts_stride, int64_t n_queries,
                         const int32_t *itv_starts, const int32_t *itv_ends, const float *itv_values,
                         const int64_t *itv_offsets, const int32_t *itv_pmax_ends, float *out, const int64_t *out_offsets,
-                        int64_t max_row_len, PaintTodo *todo, hipStream_t s, const PaintIndex X = PaintIndex{nullptr, nullptr, nullptr, nullptr}) {
+                        int64_t max_row_len, PaintTodo *todo, hipStream_t s, const PaintIndex X = PaintIndex{nullptr, nullptr, nullptr, nullptr},
+                        bool tile_complete = false) {
     const int chunk_len = 2048;
     const i64 n_chunks = (max_row_len + chunk_len - 1) / chunk_len;
     if (todo) {
+        // tile_complete: the interval set's owner vouches that the tiled kernel finishes every chunk (no overlaps, no equal
+        // starts, at most 256 candidates in any two adjacent index buckets), so the leftovers launch -- 5.8 us that find
+        // nothing -- is skipped; a chunk that needs it after all is reported through gvl_async_error, never silently wrong
+        const bool complete = tile_complete && X.offsets && !(debug_flags() & (8192 | 1024));
         intervals_to_tracks_tiled_kernel<<<dim3((unsigned)((n_chunks + 3) / 4), (unsigned)n_queries), dim3(256), 0, s>>>(
             (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
             (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, (int)n_chunks, todo, X,
-            (debug_flags() & 8192) ? 1 : 0);
+            (debug_flags() & 8192) ? 1 : 0, complete ? async_err_word() : nullptr);
+        if (complete) return check_launch("gvl_intervals_to_tracks");
         intervals_to_tracks_kernel<<<dim3((unsigned)((n_chunks * n_queries + 255) / 256)), dim3(256), 0, s>>>(
             (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
             (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, todo, n_chunks);
@@ -4253,7 +4261,7 @@ static int tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const in
             X = PaintIndex{(const i64 *)T.bkt_offsets, T.bkt_base, T.bkt_lo, T.bkt_hi};
         rc = paint_launch(offset_idxs, bt->regions + 1, bt->regions_stride, B, T.itv_starts, T.itv_ends, T.itv_values, T.itv_offsets,
                           T.itv_pmax_ends, scr, (const int64_t *)track_offsets, scratch_stride,
-                          paint_can_tile(T.itv_pmax_ends, scratch_stride) ? todo : nullptr, s, X);
+                          paint_can_tile(T.itv_pmax_ends, scratch_stride) ? todo : nullptr, s, X, T.tile_complete != 0);
         if (rc) return rc;
         rc = realign_tracks_impl(st, &rb, scr, (const int64_t *)track_offsets, params, strategy_id, base_seed, seed_ptr,
                                  out + (i64)t * out_track_stride, stream);

@@ -372,18 +372,50 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
             pm = _device.intervals_prefix_max(b, io, d) if int(b.numel()) else None
             self._itv.append((a, b, v, io, pm))
             self._bkt.append(_device.intervals_bucket_index(a, pm, io, d) if pm is not None else None)
+        # Does the tiled painter finish every chunk of this interval set on its own?  (BigWig-like tracks do: no overlaps,
+        # distinct starts, never more than 256 intervals in two adjacent 2048-position buckets.)  Checked once, here; the
+        # painter then skips its second launch (gvl_track_set.tile_complete) and reports a chunk that proves the claim wrong.
+        self._tile_complete = [self._tiles_complete(a, b, io, bk) for (a, b, v, io, pm), bk in zip(self._itv, self._bkt)]
         from ._lib import GvlTrackSet
 
         self._track_sets = (GvlTrackSet * max(len(self._itv), 1))(*[
             GvlTrackSet(itv_starts=a.data_ptr(), itv_ends=b.data_ptr(), itv_values=v.data_ptr(), itv_offsets=io.data_ptr(),
                         n_intervals=int(a.numel()), itv_pmax_ends=None if pm is None else pm.data_ptr(),
                         bkt_offsets=None if bk is None else bk[0].data_ptr(), bkt_base=None if bk is None else bk[1].data_ptr(),
-                        bkt_lo=None if bk is None else bk[2].data_ptr(), bkt_hi=None if bk is None else bk[3].data_ptr())
-            for (a, b, v, io, pm), bk in zip(self._itv, self._bkt)])
+                        bkt_lo=None if bk is None else bk[2].data_ptr(), bkt_hi=None if bk is None else bk[3].data_ptr(),
+                        tile_complete=int(tc))
+            for (a, b, v, io, pm), bk, tc in zip(self._itv, self._bkt, self._tile_complete)])
         reg = self.full_regions
         max_len = int((reg[:, 2] - reg[:, 1]).max().item()) if self.n_regions else 0
         # scratch track per query: len - min(diff, 0) <= 2 * len (a window cannot lose more than itself)
         self._stride = 2 * max(max_len + 2 * self.jitter, 1)
+
+    @staticmethod
+    def _tiles_complete(a, b, io, bk) -> bool:
+        """No two intervals of a list overlap or share a start, and no two adjacent buckets of the painter's index hold more
+        than 256 intervals (one host read, once per interval set)."""
+        n = int(a.numel())
+        if bk is None or n == 0:
+            return False
+        bo, _, lo, hi = bk
+        if n > 1:
+            nxt_is_list_start = torch.zeros(n, dtype=torch.bool, device=a.device)
+            starts = io[1:-1]
+            nxt_is_list_start[starts[starts < n]] = True          # interval i begins a list
+            adj = ~nxt_is_list_start[1:]                           # pairs (i, i + 1) inside one list
+            bad = adj & ((a[1:] <= a[:-1]) | (a[1:] < b[:-1]))
+            if bool(bad.any().item()):
+                return False
+        nb = int(lo.numel()) if int(bo[-1].item()) > 0 else 0
+        if nb == 0:
+            return True
+        g = torch.arange(nb, device=a.device)
+        last_of_list = torch.zeros(nb, dtype=torch.bool, device=a.device)
+        ends = bo[1:] - 1
+        last_of_list[ends[(ends >= 0) & (ends < nb)]] = True
+        nxt = torch.where(last_of_list, g, (g + 1).clamp(max=nb - 1))
+        cnt = hi[:nb].to(torch.int64)[nxt] - lo[:nb].to(torch.int64)
+        return bool((cnt.max() <= 256).item())
 
     def __getitem__(self, idx) -> TrackBatch:
         import ctypes as C

@@ -343,6 +343,11 @@ typedef struct gvl_track_set {
     const int32_t *bkt_base;      /* n_lists     */
     const int32_t *bkt_lo;        /* n_buckets   */
     const int32_t *bkt_hi;        /* n_buckets   */
+    int32_t tile_complete;        /* != 0: the caller vouches (checked once per interval set, see
+                                     DeviceHapsTracksDataset) that inside every list starts strictly increase, no interval
+                                     begins before its predecessor ends, and no two adjacent index buckets hold more than 256
+                                     intervals.  The painter then needs no second ("leftovers") launch; a chunk that would
+                                     have needed it is reported by gvl_async_error().  Needs the bucket index. */
 } gvl_track_set;
 
 /* Coarse per-list index for the painter (once per interval set, next to gvl_intervals_prefix_max):

@@ -45,7 +45,8 @@ def test_ctypes_structs_match_c_layout(tmp_path):
     from genvarloader_amd import _lib
 
     structs = {"gvl_static": _lib.GvlStatic, "gvl_batch": _lib.GvlBatch, "gvl_out": _lib.GvlOut,
-               "gvl_loader_config": _lib.GvlLoaderConfig, "gvl_loader_batch": _lib.GvlLoaderBatch}
+               "gvl_loader_config": _lib.GvlLoaderConfig, "gvl_loader_batch": _lib.GvlLoaderBatch,
+               "gvl_track_set": _lib.GvlTrackSet}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

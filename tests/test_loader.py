@@ -354,6 +354,7 @@ def test_haps_tracks_dataset_matches_oracle(oracle, dbg):
                                                  for pl in loops]:
         ds = DeviceHapsTracksDataset(dev, full_regions, S, P, tracks=tracks, strategy_id=strategy, param=param,
                                      base_seed=pinned, output_length=L, onehot=False, haps=True)
+        assert all(ds._tile_complete)        # BigWig-like lists: the painter needs no leftovers launch (and skips it when dbg == 0)
         seen = 0
         for batch in ds.to_dataloader(batch_size=7, shuffle=True, generator=torch.Generator().manual_seed(1),
                                       python_loop=python_loop, threaded=(strategy == 4 and not python_loop)):
@@ -628,3 +629,48 @@ def test_loader_onehot_only_goes_through_the_lean_kernel(oracle):
     for q in idx.tolist():
         np.testing.assert_array_equal(outs[0][q], exp_oh[q])
         np.testing.assert_array_equal(outs[16384][q], exp_oh[q])
+
+
+@pytest.mark.gpu
+def test_tracks_tile_complete_claim_is_checked():
+    """gvl_track_set.tile_complete lets the painter skip its second launch.  The dataset only sets it for interval sets
+    that qualify (no overlaps, distinct starts, <= 256 intervals per two adjacent buckets); a WRONG claim is reported
+    through gvl_async_error, not silently painted wrong."""
+    from genvarloader_amd import HapsDevice, _lib
+    from genvarloader_amd.loader import DeviceHapsTracksDataset
+
+    R, S, P, L = 3, 4, 2, 600
+    st, full_regions, go, gv = _grid_dataset(43, R, S, P, L, indel_frac=0.3, slack=30)
+    rng = np.random.default_rng(6)
+
+    def lists(overlap):
+        starts, ends, vals, offs = [], [], [], [0]
+        for r in range(R):
+            for s_ in range(S):
+                pos = int(full_regions[r, 1]) - 20
+                while pos < int(full_regions[r, 2]) + 20:
+                    w = int(rng.integers(5, 40))
+                    starts.append(pos); ends.append(pos + w + (15 if overlap else 0)); vals.append(float(rng.random()))
+                    pos += w
+                offs.append(len(starts))
+        return {"t": (np.array(starts, np.int32), np.array(ends, np.int32), np.array(vals, np.float32), np.array(offs, np.int64))}
+
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+    lib = _lib.load()
+    lib.gvl_async_error(1)
+    good = DeviceHapsTracksDataset(dev, full_regions, S, P, tracks=lists(False), output_length=L, onehot=False, haps=True)
+    bad = DeviceHapsTracksDataset(dev, full_regions, S, P, tracks=lists(True), output_length=L, onehot=False, haps=True)
+    assert good._tile_complete == [True] and bad._tile_complete == [False]
+    for _ in good.to_dataloader(batch_size=5):
+        pass
+    for _ in bad.to_dataloader(batch_size=5):      # overlapping intervals, honestly declared: painted by the leftovers launch
+        pass
+    torch.cuda.synchronize()
+    assert lib.gvl_async_error(1) == 0
+    bad._track_sets[0].tile_complete = 1           # a wrong claim
+    with pytest.raises(ValueError, match="tile_complete"):
+        for _ in bad.to_dataloader(batch_size=5):
+            torch.cuda.synchronize()
+    lib.gvl_async_error(1)
