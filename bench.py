@@ -81,7 +81,7 @@ def cpu_baseline(st, bt, budget_s: float = 12.0, thread_counts=None) -> dict:
         lib, march = None, "x86-64-v3"
     nproc = oracle.default_threads()
     if thread_counts is None:
-        thread_counts = sorted({1, 8, 32, nproc} & set(range(1, nproc + 1)) | {1, nproc})
+        thread_counts = sorted({1, 8, 32, 64, 128, nproc} & set(range(1, nproc + 1)) | {1, nproc})
     K, L = bt.n_windows, bt.output_length
     out = np.empty(K * L, np.uint8)
     oh = np.empty((K * L, 4), np.uint8)

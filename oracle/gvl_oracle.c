@@ -323,6 +323,16 @@ static void *pool_worker(void *born_at)
     uint64_t seen = (uint64_t)(uintptr_t)born_at;
     pthread_mutex_lock(&g_pool.mu);
     for (;;) {
+        /* like rayon's workers: look for the next job for a while before going to sleep (a condition-variable wake
+         * costs tens of microseconds; batches arrive back to back) */
+        if (!g_pool.stop && g_pool.generation == seen) {
+            pthread_mutex_unlock(&g_pool.mu);
+            for (int spin = 0; spin < 20000; spin++) {
+                if (__atomic_load_n(&g_pool.generation, __ATOMIC_ACQUIRE) != seen || __atomic_load_n(&g_pool.stop, __ATOMIC_ACQUIRE)) break;
+                __builtin_ia32_pause();
+            }
+            pthread_mutex_lock(&g_pool.mu);
+        }
         while (!g_pool.stop && g_pool.generation == seen) pthread_cond_wait(&g_pool.cv_work, &g_pool.mu);
         if (g_pool.stop) break;
         seen = g_pool.generation;
@@ -386,6 +396,7 @@ static void run_rows(const void *args, void (*fn)(const void *, int64_t),
     pthread_cond_broadcast(&g_pool.cv_work);
     pthread_mutex_unlock(&g_pool.mu);
     job_drain(&job);
+    for (int spin = 0; spin < 20000 && __atomic_load_n(&g_pool.pending, __ATOMIC_ACQUIRE) > 0; spin++) __builtin_ia32_pause();
     pthread_mutex_lock(&g_pool.mu);
     while (g_pool.pending > 0) pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
     g_pool.job = NULL;
