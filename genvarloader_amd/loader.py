@@ -260,7 +260,7 @@ class DeviceHapsDataset:
     def to_dataloader(self, batch_size: int = 1, shuffle: bool = False, sampler=None, drop_last: bool = False,
                       generator: torch.Generator | None = None, in_flight: int = 3, rank: int = 0,
                       world_size: int = 1, seed: int = 0, threaded: bool = False, group: int | None = None,
-                      python_loop: bool = False, draw_stream: int | None = None) -> "DeviceLoader":
+                      python_loop: bool = False, draw_stream: int | None = None, pad_to: int | None = None) -> "DeviceLoader":
         """``Dataset.to_dataloader`` (``_impl.py:1963-2072``) for device consumers.  With
         ``world_size > 1`` the epoch is sharded across ranks like ``DistributedSampler``
         (:func:`genvarloader_amd.sharding.epoch_order`): same permutation on every rank, disjoint
@@ -274,9 +274,13 @@ class DeviceHapsDataset:
         in epoch *e* (``set_epoch``; epochs count from 0 otherwise) is a function of (dataset seed, ``draw_stream``,
         *e*, *i*) only -- the same whatever rank, batch, batch size or submit loop delivers the index, different
         between epochs and between draw streams.  ``draw_stream=None``: the number of loaders created from this
-        dataset so far (the k-th loader of every rank's process draws alike; a new loader does not replay)."""
+        dataset so far (the k-th loader of every rank's process draws alike; a new loader does not replay).
+
+        ``pad_to``: wrap the epoch order around to that many indices (``DistributedSampler``'s padding) -- for ranks whose
+        datasets differ in size (sample-sharded genotypes, :func:`genvarloader_amd.sharding.shard_genotypes_by_sample`) and
+        must run the same number of batches."""
         return DeviceLoader(self, batch_size, shuffle, sampler, drop_last, generator, in_flight, rank, world_size,
-                            seed, threaded, group, python_loop=python_loop, draw_stream=draw_stream)
+                            seed, threaded, group, python_loop=python_loop, draw_stream=draw_stream, pad_to=pad_to)
 
 
 @dataclass
@@ -620,7 +624,8 @@ class DeviceLoader:
 
     def __init__(self, ds: DeviceHapsDataset, batch_size=1, shuffle=False, sampler=None, drop_last=False,
                  generator=None, in_flight=2, rank=0, world_size=1, seed=0, threaded=False, group=None,
-                 python_loop=False, draw_stream=None):
+                 python_loop=False, draw_stream=None, pad_to=None):
+        self.pad_to = None if pad_to is None else int(pad_to)
         self.draw_seed = ds._loader_seed(draw_stream)      # (seed of this loader's jitter / shift draws)
         self.threaded = bool(threaded)
         self.group = None if group is None else max(1, min(16, int(group)))
@@ -787,6 +792,7 @@ class DeviceLoader:
                 order = epoch_order(len(ds), shuffle=self.shuffle, seed=self.seed, epoch=self.epoch, rank=self.rank,
                                     world=self.world_size, drop_last=self.drop_last and self.world_size > 1,
                                     device=d, generator=g)
+            order = self._padded(order)
             _lib.check(lib.gvl_loader_set_epoch(handle, C.c_uint64(self.epoch & 0xFFFFFFFFFFFFFFFF)))
             self.epoch += 1
             n = int(order.numel())
@@ -844,13 +850,22 @@ class DeviceLoader:
         # no sampler: this rank's share of a fresh permutation, every epoch (seed + epoch)
         order = epoch_order(len(self.ds), shuffle=self.shuffle, seed=self.seed, epoch=self.epoch, rank=self.rank,
                             world=self.world_size, drop_last=self.drop_last and self.world_size > 1,
-                            device="cpu", generator=self.generator).numpy()       # host indices: no sync per batch
+                            device="cpu", generator=self.generator)
+        order = self._padded(order).numpy()                                             # host indices: no sync per batch
         self.epoch += 1
         bs, n = self.batch_size, int(order.size)
         for s in range(0, n, bs):
             if self.drop_last and s + bs > n:
                 break
             yield order[s:s + bs]
+
+    def _padded(self, order):
+        """``pad_to``: the order wrapped around to that length (never shortened)."""
+        n = int(order.numel())
+        if self.pad_to is None or n == 0 or n >= self.pad_to:
+            return order
+        reps = -(-self.pad_to // n)
+        return torch.cat([order] * reps)[: self.pad_to].contiguous()
 
     def __len__(self):
         if self.sampler is not None:
@@ -861,6 +876,8 @@ class DeviceLoader:
         n = len(self.ds)
         if self.world_size > 1:                     # DistributedSampler: equal shares
             n = n // self.world_size if self.drop_last else -(-n // self.world_size)
+        if self.pad_to is not None and 0 < n < self.pad_to:
+            n = self.pad_to
         return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
 
     def set_epoch(self, epoch: int) -> None:

@@ -8,6 +8,12 @@ reference window, stay together and ``(b, P, L)`` reshapes hold), runs the kerne
 block, and no collective is on the data path.  The per-dataset arrays (reference, variant
 table, genotype CSR) are replicated on every GPU.
 
+When the genotype CSR is too large to replicate ("shard or replicate genotype CSR by sample range depending
+on size vs 288 GB HBM; with sample-sharded CSR route each query to the GPU owning its sample"), ``shard_genotypes_by_sample``
+cuts it by SAMPLE range instead: rank ``r`` keeps the slots of samples ``[s0, s1)`` for every region, compacted, and its
+dataset is the ``(regions x owned samples)`` grid -- ``owner_of`` / ``global_index`` / ``local_index`` do the routing.  The
+reference, variant table and regions stay replicated (they do not grow with the cohort).
+
 ``all_gather_rows`` is the optional final gather for a single consumer (RCCL over xGMI when
 the process group backend is ``nccl``; ``gloo`` in the CPU tests): fixed-length rows gather
 as equal-size blocks (padded to the largest shard), ragged rows gather lengths first.
@@ -33,6 +39,66 @@ def shard_bounds(n_queries: int, world: int, rank: int) -> tuple[int, int]:
     base, rem = divmod(int(n_queries), int(world))
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_genotypes_by_sample(geno_offsets, geno_v_idxs, n_regions: int, n_samples: int, ploidy: int, world: int, rank: int):
+    """This rank's share of a sparse-genotype CSR sharded by SAMPLE range.
+
+    ``geno_offsets``: ``(2, R*S*P)`` starts / stops (or ``(R*S*P + 1,)``), slot =
+    ``ravel_multi_index((region, sample, ploid), (R, S, P))`` (``_haps.py:757-768``); ``geno_v_idxs`` int32.  numpy arrays or
+    torch tensors (any device; the result lives where the input does).
+    -> ``(local_offsets (2, R*S_loc*P) int64, local_v_idxs int32, (s0, s1))``: the slots of samples ``[s0, s1)`` in
+    ``(R, S_loc, P)`` order over a compacted copy of their entries -- what a ``HapsDevice`` + ``DeviceHapsDataset(n_samples =
+    s1 - s0)`` of that rank take.  Memory per rank: 1 / world of the entries (+ the same share of the derived layouts)."""
+    import torch
+
+    as_np = not isinstance(geno_offsets, torch.Tensor)
+    go = torch.as_tensor(np.asarray(geno_offsets) if as_np else geno_offsets).to(torch.int64)
+    gv = torch.as_tensor(np.asarray(geno_v_idxs) if not isinstance(geno_v_idxs, torch.Tensor) else geno_v_idxs)
+    gv = gv.to(device=go.device, dtype=torch.int32)
+    R, S, P = int(n_regions), int(n_samples), int(ploidy)
+    if go.dim() == 1:
+        go = torch.stack([go[:-1], go[1:]])
+    if tuple(go.shape) != (2, R * S * P):
+        raise ValueError("geno_offsets must cover regions x samples x ploidy slots")
+    s0, s1 = shard_bounds(S, world, rank)
+    sl = s1 - s0
+    starts = go[0].view(R, S, P)[:, s0:s1, :].reshape(-1)
+    stops = go[1].view(R, S, P)[:, s0:s1, :].reshape(-1)
+    n = (stops - starts).clamp_min(0)
+    off = torch.zeros(n.numel() + 1, dtype=torch.int64, device=go.device)
+    torch.cumsum(n, 0, out=off[1:])
+    total = int(off[-1].item()) if n.numel() else 0
+    row_of = torch.repeat_interleave(torch.arange(n.numel(), device=go.device), n)
+    src = starts[row_of] + (torch.arange(total, device=go.device) - off[row_of])
+    lv = gv[src] if total else gv[:0]
+    lo = torch.stack([off[:-1], off[1:]]).contiguous()
+    assert lo.shape[1] == R * sl * P
+    if as_np:
+        return lo.cpu().numpy(), lv.cpu().numpy(), (s0, s1)
+    return lo, lv.contiguous(), (s0, s1)
+
+
+def global_index(local_idx, n_samples: int, s0: int, s1: int):
+    """Dataset index over the (regions x owned samples) grid of a sample shard -> index over the full (regions x samples) grid."""
+    sl = int(s1) - int(s0)
+    return (local_idx // sl) * int(n_samples) + int(s0) + (local_idx % sl)
+
+
+def local_index(global_idx, n_samples: int, s0: int, s1: int):
+    """Inverse of :func:`global_index` (for indices whose sample this shard owns)."""
+    sl = int(s1) - int(s0)
+    return (global_idx // int(n_samples)) * sl + (global_idx % int(n_samples)) - int(s0)
+
+
+def owner_of(global_idx, n_samples: int, world: int):
+    """The rank that owns a dataset index's sample under :func:`shard_genotypes_by_sample` (works on ints, numpy arrays, tensors)."""
+    base, rem = divmod(int(n_samples), int(world))
+    s = global_idx % int(n_samples)
+    cut = rem * (base + 1)                     # the first `rem` ranks own base + 1 samples
+    if base == 0:
+        return s
+    return (s < cut) * (s // (base + 1)) + (s >= cut) * (rem + (s - cut) // base)
 
 
 def shard_batch(rank: int, world: int, regions, shifts, geno_offset_idx, to_rc=None, keep=None,

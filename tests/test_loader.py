@@ -674,3 +674,47 @@ def test_tracks_tile_complete_claim_is_checked():
         for _ in bad.to_dataloader(batch_size=5):
             torch.cuda.synchronize()
     lib.gvl_async_error(1)
+
+
+@pytest.mark.gpu
+def test_sample_sharded_genotypes_give_the_replicated_dataset(oracle):
+    """SURVEY 8(e), the alternative to replicas: each rank holds the genotype CSR of ITS samples only
+    (sharding.shard_genotypes_by_sample) and iterates the (regions x owned samples) grid; mapped back to the full grid its
+    batches are bit-identical to the replicated dataset's, every index is served by exactly one rank, and `pad_to` lets
+    ranks with fewer samples run the same number of batches."""
+    from genvarloader_amd import HapsDevice, sharding
+    from genvarloader_amd.loader import DeviceHapsDataset
+
+    R, S, P, L = 4, 7, 2, 512
+    st, full_regions, go, gv = _grid_dataset(31, R, S, P, L, indel_frac=0.4)
+    kw = dict(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens, alt_alleles=st.alt_alleles,
+              alt_offsets=st.alt_offsets, pad_char=st.pad_char)
+    full = DeviceHapsDataset(HapsDevice(geno_offsets=go, geno_v_idxs=gv, **kw), full_regions, S, P, output_length=L,
+                             onehot=True, haps=False)
+    ref = {}
+    for b in full.to_dataloader(batch_size=9):
+        oh = b.onehot.cpu().numpy()
+        for i, q in enumerate(b.idx.cpu().numpy().tolist()):
+            ref[q] = oh[i].copy()
+    world = 3
+    n_max = R * -(-S // world)
+    served = np.zeros(R * S, np.int32)
+    for rank in range(world):
+        lo, lv, (s0, s1) = sharding.shard_genotypes_by_sample(go, gv, R, S, P, world, rank)
+        assert lv.size < gv.size
+        ds = DeviceHapsDataset(HapsDevice(geno_offsets=lo, geno_v_idxs=lv, **kw), full_regions, s1 - s0, P, output_length=L,
+                               onehot=True, haps=False)
+        dl = ds.to_dataloader(batch_size=5, shuffle=True, seed=2, pad_to=n_max)
+        assert len(dl) == -(-n_max // 5)
+        n_seen, mine = 0, set()
+        for b in dl:
+            gidx = sharding.global_index(b.idx, S, s0, s1).cpu().numpy()
+            assert (sharding.owner_of(gidx, S, world) == rank).all()
+            oh = b.onehot.cpu().numpy()
+            for i, q in enumerate(gidx.tolist()):
+                np.testing.assert_array_equal(oh[i], ref[q])
+                mine.add(q)
+            n_seen += len(gidx)
+        assert n_seen == n_max and len(mine) == R * (s1 - s0)
+        served[list(mine)] += 1
+    assert (served == 1).all()

@@ -149,3 +149,40 @@ def test_epoch_order_matches_distributed_sampler_semantics():
     assert torch.equal(epoch_order(n, shuffle=True, generator=g1), torch.randperm(n, generator=g2))
     with pytest.raises(ValueError):
         epoch_order(n, shuffle=False, rank=2, world=2)
+
+
+def test_shard_genotypes_by_sample_partitions_the_csr():
+    """the genotype CSR cut by sample range -- every (region, sample, ploid) slot lands on exactly one rank
+    with its variant list intact, and the index helpers route between the full grid and a rank's own grid."""
+    rng = np.random.default_rng(3)
+    R, S, P = 5, 11, 2
+    n = rng.integers(0, 7, R * S * P)
+    off = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+    gv = rng.integers(0, 1000, int(off[-1])).astype(np.int32)
+    go = np.stack([off[:-1], off[1:]])
+    for world in (1, 2, 3, 8, 16):
+        seen = np.zeros(R * S, np.int32)
+        total_entries = 0
+        for rank in range(world):
+            lo, lv, (s0, s1) = sharding.shard_genotypes_by_sample(go, gv, R, S, P, world, rank)
+            sl = s1 - s0
+            assert lo.shape == (2, R * sl * P) and lo.dtype == np.int64 and lv.dtype == np.int32
+            total_entries += lv.size
+            assert (lo[0, 1:] == lo[1, :-1]).all() and (lo.size == 0 or lo[0, 0] == 0)       # compacted, back to back
+            loc = np.arange(R * sl)
+            glob = sharding.global_index(loc, S, s0, s1)
+            np.testing.assert_array_equal(sharding.local_index(glob, S, s0, s1), loc)
+            np.testing.assert_array_equal(sharding.owner_of(glob, S, world), rank)
+            seen[glob] += 1
+            for q_loc, q in zip(loc, glob):
+                for p in range(P):
+                    a = lv[lo[0, q_loc * P + p]:lo[1, q_loc * P + p]]
+                    b = gv[go[0, q * P + p]:go[1, q * P + p]]
+                    np.testing.assert_array_equal(a, b)
+        assert (seen == 1).all() and total_entries == gv.size
+    import torch
+
+    lo_t, lv_t, rng_t = sharding.shard_genotypes_by_sample(torch.from_numpy(go), torch.from_numpy(gv), R, S, P, 3, 1)
+    lo_n, lv_n, rng_n = sharding.shard_genotypes_by_sample(go, gv, R, S, P, 3, 1)
+    assert rng_t == rng_n and torch.equal(lo_t, torch.from_numpy(lo_n)) and torch.equal(lv_t, torch.from_numpy(lv_n))
+    np.testing.assert_array_equal(sharding.shard_genotypes_by_sample(off, gv, R, S, P, 3, 1)[0], lo_n)    # (n + 1,) offsets too
