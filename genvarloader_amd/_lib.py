@@ -96,6 +96,7 @@ class GvlTrackSet(C.Structure):
         ("itv_starts", _vp), ("itv_ends", _vp), ("itv_values", _vp), ("itv_offsets", _vp),
         ("n_intervals", _i64), ("itv_pmax_ends", _vp),
         ("bkt_offsets", _vp), ("bkt_base", _vp), ("bkt_lo", _vp), ("bkt_hi", _vp), ("tile_complete", C.c_int32),
+        ("has_fill", C.c_int32), ("fill_strategy", C.c_int32), ("fill_param", C.c_double), ("list_div", _i64),
     ]
 
 

@@ -3096,14 +3096,14 @@ __device__ __forceinline__ void paint_values(const i64 j_begin, const i64 j_end,
 __global__ __launch_bounds__(256) void intervals_to_tracks_kernel(
     const i64 *offset_idxs, const int *starts, i64 starts_stride, i64 n_queries, const int *itv_starts,
     const int *itv_ends, const float *itv_values, const i64 *itv_offsets, const int *pmax, float *out,
-    const i64 *out_offsets, int chunk_len, const PaintTodo *chunk_todo, i64 n_chunks) {
+    const i64 *out_offsets, int chunk_len, const PaintTodo *chunk_todo, i64 n_chunks, i64 list_div) {
     __shared__ PaintImage image;
     __shared__ int flags[256];
     if (!chunk_todo) {
         const i64 q = blockIdx.y;
         if (q >= n_queries) return;
         const i64 o0 = out_offsets[q];
-        const i64 idx = offset_idxs[q];
+        const i64 idx = offset_idxs[q] / list_div;
         paint_values((i64)blockIdx.x * blockDim.x + threadIdx.x, out_offsets[q + 1] - o0, (i64)gridDim.x * blockDim.x, itv_offsets[idx],
                      itv_offsets[idx + 1], starts[q * starts_stride], itv_starts, itv_ends, itv_values, pmax, out + o0);
         return;
@@ -3121,7 +3121,7 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_kernel(
         const PaintTodo td = chunk_todo[rec];
         const i64 o0 = out_offsets[q];
         const i64 length = out_offsets[q + 1] - o0;
-        const i64 idx = offset_idxs[q];
+        const i64 idx = offset_idxs[q] / list_div;
         const i64 qs = starts[q * starts_stride];
         const i64 c0 = chunk * chunk_len;
         const i64 c1 = c0 + chunk_len < length ? c0 + chunk_len : length;
@@ -3156,7 +3156,7 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
     const i64 *offset_idxs, const int *starts, i64 starts_stride, i64 n_queries, const int *itv_starts,
     const int *itv_ends, const float *itv_values, const i64 *itv_offsets, const int *pmax, float *out,
     const i64 *out_offsets, int chunk_len, int n_chunks, PaintTodo *chunk_todo, const PaintIndex X, const int force_image,
-    int *complete_err) {      // non-NULL: the caller vouched that no chunk needs the leftovers launch (gvl_track_set.tile_complete)
+    int *complete_err, const i64 list_div) {      // non-NULL: the caller vouched that no chunk needs the leftovers launch (gvl_track_set.tile_complete)
     __shared__ PaintTile tiles[4];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = rfl((int)(threadIdx.x >> 6));
@@ -3166,7 +3166,7 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
     const i64 chunk = (i64)blockIdx.x * 4 + wave;
     const i64 o0 = rfl64(out_offsets[q]);
     const i64 length = rfl64(out_offsets[q + 1]) - o0;
-    const i64 idx = rfl64(offset_idxs[q]);
+    const i64 idx = rfl64(offset_idxs[q]) / list_div;
     const i64 s0 = rfl64(itv_offsets[idx]), e0 = rfl64(itv_offsets[idx + 1]);
     const i64 qs = rfl(starts[q * starts_stride]);
     // the first round of both searches probes the same 64 strided entries of the query's list for
@@ -3788,7 +3788,7 @@ static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_o
     if (out->annot_v_idxs || out->annot_ref_pos || out->onehot_layout != GVL_ONEHOT_LC) return false;
     if (bt->out_offsets || bt->keep || bt->keep_offsets) return false;
     if (bt->output_length <= 0 || bt->output_length > LEAN_MAX_TRIPS * TRIP || (bt->output_length & 3)) return false;
-    if (bt->batch * bt->ploidy <= 0 || bt->batch * bt->ploidy > 0x7FFFFFFFll / (4 * LEAN_MAX_TRIPS * TRIP)) return false;
+    if (bt->batch * bt->ploidy <= 0 || bt->batch * bt->ploidy > 0x7FFFFFF0ll) return false;     // (row indices are ints in the kernel)
     if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;     // u32 positions in the kernel
     return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288)) == 0;
 }
@@ -4067,7 +4067,8 @@ static int paint_launch(const int64_t *offset_idxs, const int32_t *starts, int64
                         const int32_t *itv_starts, const int32_t *itv_ends, const float *itv_values,
                         const int64_t *itv_offsets, const int32_t *itv_pmax_ends, float *out, const int64_t *out_offsets,
                         int64_t max_row_len, PaintTodo *todo, hipStream_t s, const PaintIndex X = PaintIndex{nullptr, nullptr, nullptr, nullptr},
-                        bool tile_complete = false) {
+                        bool tile_complete = false, i64 list_div = 1) {
+    if (list_div < 1) list_div = 1;
     const int chunk_len = 2048;
     const i64 n_chunks = (max_row_len + chunk_len - 1) / chunk_len;
     if (todo) {
@@ -4078,17 +4079,17 @@ static int paint_launch(const int64_t *offset_idxs, const int32_t *starts, int64
         intervals_to_tracks_tiled_kernel<<<dim3((unsigned)((n_chunks + 3) / 4), (unsigned)n_queries), dim3(256), 0, s>>>(
             (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
             (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, (int)n_chunks, todo, X,
-            (debug_flags() & 8192) ? 1 : 0, complete ? async_err_word() : nullptr);
+            (debug_flags() & 8192) ? 1 : 0, complete ? async_err_word() : nullptr, list_div);
         if (complete) return check_launch("gvl_intervals_to_tracks");
         intervals_to_tracks_kernel<<<dim3((unsigned)((n_chunks * n_queries + 255) / 256)), dim3(256), 0, s>>>(
             (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
-            (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, todo, n_chunks);
+            (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, todo, n_chunks, list_div);
     } else {
         i64 gx = (max_row_len + 255) / 256;
         if (gx > 1024) gx = 1024;
         intervals_to_tracks_kernel<<<dim3((unsigned)gx, (unsigned)n_queries), dim3(256), 0, s>>>(
             (const i64 *)offset_idxs, starts, (i64)starts_stride, (i64)n_queries, itv_starts, itv_ends, itv_values,
-            (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, nullptr, (i64)0);
+            (const i64 *)itv_offsets, itv_pmax_ends, out, (const i64 *)out_offsets, chunk_len, nullptr, (i64)0, list_div);
     }
     return check_launch("gvl_intervals_to_tracks");
 }
@@ -4261,9 +4262,13 @@ static int tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const in
             X = PaintIndex{(const i64 *)T.bkt_offsets, T.bkt_base, T.bkt_lo, T.bkt_hi};
         rc = paint_launch(offset_idxs, bt->regions + 1, bt->regions_stride, B, T.itv_starts, T.itv_ends, T.itv_values, T.itv_offsets,
                           T.itv_pmax_ends, scr, (const int64_t *)track_offsets, scratch_stride,
-                          paint_can_tile(T.itv_pmax_ends, scratch_stride) ? todo : nullptr, s, X, T.tile_complete != 0);
+                          paint_can_tile(T.itv_pmax_ends, scratch_stride) ? todo : nullptr, s, X, T.tile_complete != 0,
+                          T.list_div > 1 ? T.list_div : 1);
         if (rc) return rc;
-        rc = realign_tracks_impl(st, &rb, scr, (const int64_t *)track_offsets, params, strategy_id, base_seed, seed_ptr,
+        // the track's own insertion fill (_reconstruct.py:204-208 lowers one per track) or the call's
+        const double t_par[1] = {T.has_fill ? T.fill_param : params[0]};
+        const int64_t t_strategy = T.has_fill ? (int64_t)T.fill_strategy : strategy_id;
+        rc = realign_tracks_impl(st, &rb, scr, (const int64_t *)track_offsets, T.has_fill ? t_par : params, t_strategy, base_seed, seed_ptr,
                                  out + (i64)t * out_track_stride, stream);
         if (rc) return rc;
     }

@@ -342,7 +342,12 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
 
     ``tracks``: ``{name: (itv_starts i32, itv_ends i32, itv_values f32, itv_offsets i64)}`` with one
     interval list per (region, sample), list index ``region * n_samples + sample`` -- the
-    reference's per-track interval store (``RaggedIntervals``, ``_dataset/_tracks.py``).  Per
+    reference's per-track interval store (``RaggedIntervals``, ``_dataset/_tracks.py``).  A track may
+    instead be a dict ``{starts, ends, values, offsets, fill=(strategy_id, param) | None, region_level=False}``:
+    ``fill`` is the track's OWN insertion fill (the reference lowers one per track, ``_reconstruct.py:204-208``;
+    ``None`` = the dataset's ``strategy_id`` / ``param``), ``region_level=True`` a track with one interval list per
+    REGION, shared by its samples (``TrackType`` other than ``SAMPLE``: the reference indexes it by ``r_idx``,
+    ``_reconstruct.py:231-236``).  Per
     batch and track: paint the query's intervals into a scratch track of the reference's length
     ``len - min_p(min(diff, 0))`` (``_reconstruct.py:191``; computed on the device), then realign it to every
     haplotype with the insertion-fill strategy (``intervals_and_realign_track_fused``,
@@ -365,14 +370,23 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
         self.track_names = list(tracks)
         self._itv, self._bkt = [], []
         n_lists = self.n_regions * self.n_samples
+        self._track_opts = []
         for name in self.track_names:
-            a, b, v, io = tracks[name]
+            spec = tracks[name]
+            fill, region_level = None, False
+            if isinstance(spec, dict):      # a track with its own insertion fill and / or region-level lists
+                fill, region_level = spec.get("fill"), bool(spec.get("region_level", False))
+                a, b, v, io = spec["starts"], spec["ends"], spec["values"], spec["offsets"]
+            else:
+                a, b, v, io = spec
+            n_lists = self.n_regions if region_level else self.n_regions * self.n_samples
+            self._track_opts.append((None if fill is None else (int(fill[0]), float(fill[1])), region_level))
             a = torch.as_tensor(np.ascontiguousarray(a, np.int32)).to(d)
             b = torch.as_tensor(np.ascontiguousarray(b, np.int32)).to(d)
             v = torch.as_tensor(np.ascontiguousarray(v, np.float32)).to(d)
             io = torch.as_tensor(np.ascontiguousarray(io, np.int64)).to(d)
             if int(io.numel()) != n_lists + 1:
-                raise ValueError(f"track {name!r}: itv_offsets must have regions x samples + 1 entries")
+                raise ValueError(f"track {name!r}: itv_offsets must have " + ("regions" if region_level else "regions x samples") + " + 1 entries")
             pm = _device.intervals_prefix_max(b, io, d) if int(b.numel()) else None
             self._itv.append((a, b, v, io, pm))
             self._bkt.append(_device.intervals_bucket_index(a, pm, io, d) if pm is not None else None)
@@ -387,8 +401,9 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
                         n_intervals=int(a.numel()), itv_pmax_ends=None if pm is None else pm.data_ptr(),
                         bkt_offsets=None if bk is None else bk[0].data_ptr(), bkt_base=None if bk is None else bk[1].data_ptr(),
                         bkt_lo=None if bk is None else bk[2].data_ptr(), bkt_hi=None if bk is None else bk[3].data_ptr(),
-                        tile_complete=int(tc))
-            for (a, b, v, io, pm), bk, tc in zip(self._itv, self._bkt, self._tile_complete)])
+                        tile_complete=int(tc), has_fill=int(fill is not None), fill_strategy=0 if fill is None else fill[0],
+                        fill_param=0.0 if fill is None else fill[1], list_div=self.n_samples if region_level else 1)
+            for (a, b, v, io, pm), bk, tc, (fill, region_level) in zip(self._itv, self._bkt, self._tile_complete, self._track_opts)])
         reg = self.full_regions
         max_len = int((reg[:, 2] - reg[:, 1]).max().item()) if self.n_regions else 0
         # scratch track per query: len - min(diff, 0) <= 2 * len (a window cannot lose more than itself)

@@ -348,6 +348,14 @@ typedef struct gvl_track_set {
                                      begins before its predecessor ends, and no two adjacent index buckets hold more than 256
                                      intervals.  The painter then needs no second ("leftovers") launch; a chunk that would
                                      have needed it is reported by gvl_async_error().  Needs the bucket index. */
+    int32_t has_fill;             /* != 0: this track's own insertion fill (the reference lowers one per track,
+                                     _reconstruct.py:204-208): fill_strategy / fill_param replace the call's strategy_id /
+                                     params for this track.  0: the call's */
+    int32_t fill_strategy;        /* GVL_FILL_* */
+    double fill_param;
+    int64_t list_div;             /* > 1: a REGION-level track (TrackType other than SAMPLE, _reconstruct.py:231-236): the
+                                     list of a query is offset_idxs[q] / list_div (= dataset index / n_samples = r_idx)
+                                     instead of offset_idxs[q].  0 / 1: per (region, sample) lists */
 } gvl_track_set;
 
 /* Coarse per-list index for the painter (once per interval set, next to gvl_intervals_prefix_max):

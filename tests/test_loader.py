@@ -718,3 +718,62 @@ def test_sample_sharded_genotypes_give_the_replicated_dataset(oracle):
         assert n_seen == n_max and len(mine) == R * (s1 - s0)
         served[list(mine)] += 1
     assert (served == 1).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("python_loop", [False, True], ids=["native-ring", "python-loop"])
+def test_tracks_with_their_own_fill_and_region_level_lists(oracle, python_loop):
+    """The reference lowers ONE insertion fill per track and indexes region-level (non-SAMPLE) tracks by r_idx
+    (_reconstruct.py:204-236): a dataset with a per-sample Repeat5p track, a per-sample Constant-fill track and a
+    region-level Interpolate track, each against the oracle with its own strategy / parameter / list index."""
+    from genvarloader_amd import HapsDevice
+    from genvarloader_amd.loader import DeviceHapsTracksDataset
+
+    R, S, P, L = 4, 5, 2, 640
+    st, full_regions, go, gv = _grid_dataset(47, R, S, P, L, indel_frac=0.5, slack=20)
+    rng = np.random.default_rng(9)
+
+    def lists(n_lists, per_list_region):
+        starts, ends, vals, offs = [], [], [], [0]
+        for i in range(n_lists):
+            r = per_list_region(i)
+            pos = int(full_regions[r, 1]) - int(rng.integers(0, 50))
+            while pos < int(full_regions[r, 2]) + 30:
+                w, gap = int(rng.geometric(1 / 15)), int(rng.integers(0, 5))
+                starts.append(pos + gap); ends.append(pos + gap + w); vals.append(float(rng.random() * 3)); pos += gap + w
+            offs.append(len(starts))
+        return np.array(starts, np.int32), np.array(ends, np.int32), np.array(vals, np.float32), np.array(offs, np.int64)
+
+    cov, atac, cons = lists(R * S, lambda i: i // S), lists(R * S, lambda i: i // S), lists(R, lambda i: i)
+    tracks = {"cov": cov,                                                                              # the dataset's fill
+              "atac": dict(starts=atac[0], ends=atac[1], values=atac[2], offsets=atac[3], fill=(2, 7.5)),          # Constant 7.5
+              "cons": dict(starts=cons[0], ends=cons[1], values=cons[2], offsets=cons[3], fill=(4, 3.0), region_level=True)}
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+    ds = DeviceHapsTracksDataset(dev, full_regions, S, P, tracks=tracks, strategy_id=0, param=0.0, base_seed=3,
+                                 output_length=L, onehot=False, haps=True)
+    spec = {"cov": (cov, 0, 0.0, False), "atac": (atac, 2, 7.5, False), "cons": (cons, 4, 3.0, True)}
+    seen = 0
+    for batch in ds.to_dataloader(batch_size=6, shuffle=True, seed=1, python_loop=python_loop):
+        idx = batch.idx.cpu().numpy()
+        r_idx, s_idx = np.unravel_index(idx, (R, S))
+        regions = full_regions[r_idx]
+        goi = np.ravel_multi_index((r_idx[:, None], s_idx[:, None], np.arange(P)), (R, S, P))
+        to_rc = np.repeat(regions[:, 3] == -1, P)
+        shifts = np.zeros_like(goi, dtype=np.int32)
+        diffs = oracle.get_diffs_sparse(goi, gv, go, st.ilens, None, None, regions[:, 1], regions[:, 2], st.v_starts)
+        tlen = (regions[:, 2] - regions[:, 1]).astype(np.int64) - np.minimum(diffs.min(axis=1), 0)
+        track_offsets = np.concatenate([[0], np.cumsum(tlen)]).astype(np.int64)
+        out_offsets = np.arange(len(idx) * P + 1, dtype=np.int64) * L
+        for t, name in enumerate(("cov", "atac", "cons")):
+            (a, e, v, io), strategy, param, by_region = spec[name]
+            exp = np.zeros(len(idx) * P * L, np.float32)
+            oracle.intervals_and_realign_track_fused(
+                exp, out_offsets, regions, shifts, goi, gv, go, st.v_starts, st.ilens,
+                (r_idx if by_region else idx).astype(np.int64), a, e, v, io, track_offsets, np.array([param]), strategy, 3,
+                None, None, to_rc)
+            got = batch.tracks[:, t].contiguous().cpu().numpy().ravel()
+            np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32), err_msg=name)
+        seen += len(idx)
+    assert seen == R * S
