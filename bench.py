@@ -491,7 +491,7 @@ def main() -> None:
         assert g.shape[1:] == oh.shape[1:] and g.shape[0] >= K
         gather_ms = tm.allmax([float(np.median(ts)) * 1e3])[0]
 
-    lean = (dev.ref4 is not None and dev.slot_rec is not None and not args.haps and L <= 2048 and L % 4 == 0
+    lean = (dev.ref4 is not None and dev.slot_rec is not None and L <= 2048 and L % 4 == 0
             and (int(os.environ.get("GVL_DBG", "0")) & ~(2 | 4 | 32768 | 65536 | 262144 | 524288)) == 0)
     if rank == 0:
         ms_per_step = region_ms / steps
@@ -504,7 +504,7 @@ def main() -> None:
             try:
                 traffic = json.loads(tf.read_text()).get(
                     f"{args.workload}{'+haps' if args.haps else ''}@{args.scale}" + ("" if n_rot > 1 else "@hot")
-                    + ("" if lean or args.workload != "cfg3" or args.haps else "@allpurpose"))
+                    + ("" if lean or args.workload != "cfg3" else "@allpurpose"))
             except Exception:
                 traffic = None
         sizes = ds.nbytes()
@@ -545,7 +545,7 @@ def main() -> None:
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "frac_of_copy_ceiling": achieved / HBM_COPY_GBS,
-                "kernel": ("recon_lean_kernel (nibble-packed reference; rows it cannot express run the all-purpose body inside the same launch)"
+                "kernel": ("recon_lean_kernel<onehot, haps=%s> (nibble-packed reference; rows it cannot express run the all-purpose body inside the same launch)" % ("true" if args.haps else "false")
                            if lean else "reconstruct_kernel<OH_LC, haps=%s, annot=false>" % ("true" if args.haps else "false")),
                 "kernel_ms": kern_ms,
                 "kernel_ms_how": "HIP events around K back-to-back launches on one stream (rotating batches), median region",

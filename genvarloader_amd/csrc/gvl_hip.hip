@@ -3780,12 +3780,12 @@ static int launch_recon(const ReconArgs &A, int chunks, int variant, void *strea
     return check_launch("gvl_reconstruct");
 }
 
-// Can this batch take the lean kernel?  One-hot only, row-major, fixed-length rows of one chunk, no keep
+// Can this batch take the lean kernel?  Row-major one-hot and / or haplotype bytes, fixed-length rows of one chunk, no keep
 // mask, no annotations, both derived layouts present -- and no path-forcing debug flag (those exist to
 // walk the all-purpose kernel).
 static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_out *out) {
-    if (!st->ref4 || !st->slot_rec || !out->onehot || out->haps) return false;
-    if (out->annot_v_idxs || out->annot_ref_pos || out->onehot_layout != GVL_ONEHOT_LC) return false;
+    if (!st->ref4 || !st->slot_rec || (!out->onehot && !out->haps)) return false;
+    if (out->annot_v_idxs || out->annot_ref_pos || (out->onehot && out->onehot_layout != GVL_ONEHOT_LC)) return false;
     if (bt->out_offsets || bt->keep || bt->keep_offsets) return false;
     if (bt->output_length <= 0 || bt->output_length > LEAN_MAX_TRIPS * TRIP || (bt->output_length & 3)) return false;
     if (bt->batch * bt->ploidy <= 0 || bt->batch * bt->ploidy > 0x7FFFFFF0ll) return false;     // (row indices are ints in the kernel)
@@ -3798,13 +3798,15 @@ static int launch_lean(const ReconArgs &RA, void *stream) {
     memset(&A, 0, sizeof(A));
     A.ref4 = RA.ref4; A.ref_offsets = RA.ref_offsets; A.srec = RA.srec;
     A.regions = RA.regions; A.shifts = RA.shifts; A.geno_offset_idx = RA.geno_offset_idx; A.to_rc = RA.to_rc;
-    A.onehot = RA.onehot; A.out_offsets_w = RA.out_offsets_w; A.alt_alleles = RA.alt_alleles; A.stamps = RA.stamps;
+    A.onehot = RA.onehot; A.haps = RA.haps; A.out_offsets_w = RA.out_offsets_w; A.alt_alleles = RA.alt_alleles; A.stamps = RA.stamps;
     A.go_starts = RA.go_starts; A.go_stops = RA.go_stops; A.grec = RA.grec; A.alt_offsets = RA.alt_offsets;
     A.n_geno_offsets = RA.n_geno_offsets;
     A.n_rows = (int)RA.n_rows; A.n_contigs = RA.n_contigs; A.regions_stride = (int)RA.regions_stride;
     A.ploidy_shift = RA.ploidy_shift; A.ploidy = RA.ploidy; A.L = (int)RA.fixed_len; A.dbg = RA.dbg;
     const unsigned grid = (unsigned)((A.n_rows + LEAN_WAVES - 1) / LEAN_WAVES);
-    recon_lean_kernel<<<dim3(grid), dim3(LEAN_THREADS), 0, (hipStream_t)stream>>>(A, RA);
+    if (A.onehot && A.haps) recon_lean_kernel<true, true><<<dim3(grid), dim3(LEAN_THREADS), 0, (hipStream_t)stream>>>(A, RA);
+    else if (A.onehot) recon_lean_kernel<true, false><<<dim3(grid), dim3(LEAN_THREADS), 0, (hipStream_t)stream>>>(A, RA);
+    else recon_lean_kernel<false, true><<<dim3(grid), dim3(LEAN_THREADS), 0, (hipStream_t)stream>>>(A, RA);
     return check_launch("gvl_reconstruct (lean)");
 }
 

@@ -1,5 +1,5 @@
-"""Randomised parity sweep of the LEAN kernel (one-hot only, fixed-length rows of at most 2048 bases: what
-gvl_reconstruct sends to recon_lean_kernel) against the oracle's one-hot.  Dense rows, long indels, shifts that
+"""Randomised parity sweep of the LEAN kernel (fixed-length rows of at most 2048 bases, one-hot and / or haplotype bytes:
+what gvl_reconstruct sends to recon_lean_kernel) against the oracle.  Dense rows, long indels, shifts that
 meet indels, windows over contig edges, overflowing slots: every row the lean path hands to its solo general path
 is checked the same way.  python tools/fuzz_lean.py [n_cases] [seed]"""
 import os, sys, time
@@ -41,15 +41,21 @@ def one_case(rng):
     return st, bt
 
 
-def check(st, bt):
+def check(st, bt, want=(True, False)):
+    onehot, haps = want
     dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens, alt_alleles=st.alt_alleles,
                      alt_offsets=st.alt_offsets, geno_offsets=bt.geno_offsets, geno_v_idxs=bt.geno_v_idxs, pad_char=st.pad_char)
     assert dev.ref4 is not None and dev.slot_rec is not None
-    out = dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, bt.output_length, None, None, bt.to_rc, haps=False, onehot=True)
+    out = dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, bt.output_length, None, None, bt.to_rc, haps=haps, onehot=onehot)
     args = (bt.regions, bt.shifts, bt.geno_offset_idx, bt.geno_offsets, bt.geno_v_idxs, st.v_starts, st.ilens, st.alt_alleles,
             st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, bt.output_length, None, None, bt.to_rc, False)
-    _, eo, eoh = oracle.reconstruct_haplotypes_fused(*args, onehot=True)
-    return np.array_equal(out.onehot.cpu().numpy(), eoh) and np.array_equal(out.out_offsets.cpu().numpy(), eo)
+    eh, eo, eoh = oracle.reconstruct_haplotypes_fused(*args, onehot=True)
+    ok = np.array_equal(out.out_offsets.cpu().numpy(), eo)
+    if onehot:
+        ok = ok and np.array_equal(out.onehot.cpu().numpy(), eoh)
+    if haps:
+        ok = ok and np.array_equal(out.haps.cpu().numpy(), eh)
+    return ok
 
 
 if __name__ == "__main__":
@@ -61,9 +67,10 @@ if __name__ == "__main__":
     for ci in range(n_cases):
         rng = np.random.default_rng(seed0 * 100003 + ci)
         st, bt = one_case(rng)
-        if not check(st, bt):
+        want = ((True, False), (True, True), (False, True))[ci % 3]         # one-hot only / one-hot + bytes / bytes only
+        if not check(st, bt, want):
             bad += 1
-            print(f"MISMATCH case {ci} (seed {seed0}): L={bt.output_length} P={bt.meta['P']} q={bt.meta['B']} V/row={bt.mean_variants:.1f} "
+            print(f"MISMATCH case {ci} (seed {seed0}) onehot, haps = {want}: L={bt.output_length} P={bt.meta['P']} q={bt.meta['B']} V/row={bt.mean_variants:.1f} "
                   f"shiftmax={bt.shifts.max()}", flush=True)
     print(f"{n_cases} lean cases, {bad} mismatches, {time.time()-t0:.1f} s")
     sys.exit(1 if bad else 0)
