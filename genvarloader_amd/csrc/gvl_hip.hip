@@ -1006,7 +1006,7 @@ struct SoloLds {
 // has put the row's parameters into solo->ri; no P1, no barrier, no packed plan: the row takes the
 // per-wave scans (or the scalar walk) and streams from the byte reference like any row here.
 template <int OH, bool HAPS, bool ANNOT, bool SOLO>
-__device__ __forceinline__ void recon_body(const ReconArgs &A, ReconShared<ANNOT> *Sp, SoloLds<ANNOT> *solo, Luts &luts, const i64 wg) {
+__device__ __forceinline__ void recon_body(const ReconArgs &A, ReconShared<ANNOT> *Sp, SoloLds<ANNOT> *solo, Luts &luts, const i64 wg, const int chunk) {
     SegMirror *const mirror = SOLO ? nullptr : Sp->mirror;
     Stage<ANNOT> *const stage = SOLO ? nullptr : Sp->stage;
     RowIn *const rin = SOLO ? nullptr : Sp->rin;
@@ -1018,7 +1018,6 @@ __device__ __forceinline__ void recon_body(const ReconArgs &A, ReconShared<ANNOT
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wave = rfl(tid >> 6);
-    const int chunk = blockIdx.y;
     const int lo_clip = chunk * A.chunk_len;
     const bool has_keep = A.keep && A.keep_offsets;
     const bool planned_ok = A.chunk_len <= CHUNK_TRIPS * TRIP && !(A.dbg & 8);
@@ -2096,7 +2095,7 @@ __device__ __forceinline__ void recon_body(const ReconArgs &A, ReconShared<ANNOT
 template <int OH, bool HAPS, bool ANNOT>
 __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void reconstruct_kernel(const ReconArgs A) {
     __shared__ ReconShared<ANNOT> S;
-    recon_body<OH, HAPS, ANNOT, false>(A, &S, nullptr, S.luts, (i64)blockIdx.x);
+    recon_body<OH, HAPS, ANNOT, false>(A, &S, nullptr, S.luts, (i64)blockIdx.x, (int)blockIdx.y);
 }
 
 typedef void (*recon_fn)(const ReconArgs);
@@ -3529,6 +3528,7 @@ int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
 // 262144 / 524288  timing ablations of the lean kernel (WRONG output for rows with indels): no re-alignment / allele
 //        bytes (phases A and B as for a SNP-only row); no scan plan either
 // 65536  the lean kernel re-reads the runs of a row with indels from memory (never re-aligns the speculative window in LDS)
+// 1048576 rows longer than one chunk never take the lean kernel (LONG): the all-purpose kernel as before
 // and 1 / 2 / 4 = timing ablations (no variants / no stores / no loads).
 int g_debug_override = -1;
 int debug_flags() {
@@ -3780,20 +3780,28 @@ static int launch_recon(const ReconArgs &A, int chunks, int variant, void *strea
     return check_launch("gvl_reconstruct");
 }
 
-// Can this batch take the lean kernel?  Row-major one-hot and / or haplotype bytes, fixed-length rows of one chunk, no keep
-// mask, no annotations, both derived layouts present -- and no path-forcing debug flag (those exist to
-// walk the all-purpose kernel).
-static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_out *out) {
-    if (!st->ref4 || !st->slot_rec || (!out->onehot && !out->haps)) return false;
+// Can this batch take the lean kernel?  Row-major one-hot and / or haplotype bytes, fixed-length rows, no keep mask, no
+// annotations, the derived layouts present -- and no path-forcing debug flag (those exist to walk the all-purpose
+// kernel).  Rows of one chunk: one wave per row, variants from the slot lines.  Longer rows (a multiple of 4 bases, cut
+// into 2048-base chunks): one wave per chunk, variants from the CSR's inline records (LONG).
+static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_out *out, int chunks, int chunk_len) {
+    if (!st->ref4 || (!out->onehot && !out->haps)) return false;
     if (out->annot_v_idxs || out->annot_ref_pos || (out->onehot && out->onehot_layout != GVL_ONEHOT_LC)) return false;
     if (bt->out_offsets || bt->keep || bt->keep_offsets) return false;
-    if (bt->output_length <= 0 || bt->output_length > LEAN_MAX_TRIPS * TRIP || (bt->output_length & 3)) return false;
-    if (bt->batch * bt->ploidy <= 0 || bt->batch * bt->ploidy > 0x7FFFFFF0ll) return false;     // (row indices are ints in the kernel)
+    if (bt->output_length <= 0 || (bt->output_length & 3)) return false;
+    const i64 n_rows = bt->batch * bt->ploidy;
+    if (chunks == 1) {
+        if (!st->slot_rec || bt->output_length > LEAN_MAX_TRIPS * TRIP) return false;
+        if (n_rows <= 0 || n_rows > 0x7FFFFFF0ll) return false;     // (row indices are ints in the kernel)
+    } else {
+        if (!st->geno_rec || chunk_len != LEAN_MAX_TRIPS * TRIP || (debug_flags() & 1048576)) return false;
+        if (n_rows <= 0 || n_rows * chunks > 0x7FFFFFF0ll) return false;                  // (wave indices are ints in the kernel)
+    }
     if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;     // u32 positions in the kernel
-    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288)) == 0;
+    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576)) == 0;
 }
 
-static int launch_lean(const ReconArgs &RA, void *stream) {
+static int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
     LeanArgs A;
     memset(&A, 0, sizeof(A));
     A.ref4 = RA.ref4; A.ref_offsets = RA.ref_offsets; A.srec = RA.srec;
@@ -3803,10 +3811,19 @@ static int launch_lean(const ReconArgs &RA, void *stream) {
     A.n_geno_offsets = RA.n_geno_offsets;
     A.n_rows = (int)RA.n_rows; A.n_contigs = RA.n_contigs; A.regions_stride = (int)RA.regions_stride;
     A.ploidy_shift = RA.ploidy_shift; A.ploidy = RA.ploidy; A.L = (int)RA.fixed_len; A.dbg = RA.dbg;
-    const unsigned grid = (unsigned)((A.n_rows + LEAN_WAVES - 1) / LEAN_WAVES);
-    if (A.onehot && A.haps) recon_lean_kernel<true, true><<<dim3(grid), dim3(LEAN_THREADS), 0, (hipStream_t)stream>>>(A, RA);
-    else if (A.onehot) recon_lean_kernel<true, false><<<dim3(grid), dim3(LEAN_THREADS), 0, (hipStream_t)stream>>>(A, RA);
-    else recon_lean_kernel<false, true><<<dim3(grid), dim3(LEAN_THREADS), 0, (hipStream_t)stream>>>(A, RA);
+    A.chunks = chunks;
+    const unsigned grid = (unsigned)(((i64)A.n_rows * chunks + LEAN_WAVES - 1) / LEAN_WAVES);
+    const dim3 g(grid), b(LEAN_THREADS);
+    hipStream_t s = (hipStream_t)stream;
+    if (chunks > 1) {
+        if (A.onehot && A.haps) recon_lean_kernel<true, true, true><<<g, b, 0, s>>>(A, RA);
+        else if (A.onehot) recon_lean_kernel<true, false, true><<<g, b, 0, s>>>(A, RA);
+        else recon_lean_kernel<false, true, true><<<g, b, 0, s>>>(A, RA);
+    } else {
+        if (A.onehot && A.haps) recon_lean_kernel<true, true, false><<<g, b, 0, s>>>(A, RA);
+        else if (A.onehot) recon_lean_kernel<true, false, false><<<g, b, 0, s>>>(A, RA);
+        else recon_lean_kernel<false, true, false><<<g, b, 0, s>>>(A, RA);
+    }
     return check_launch("gvl_reconstruct (lean)");
 }
 
@@ -3815,7 +3832,7 @@ int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *ou
     int chunks = 1, variant = 0;
     const int rc = fill_recon_args(st, bt, out, A, &chunks, &variant);
     if (rc) return rc;
-    if (A.n_rows > 0 && chunks == 1 && lean_eligible(st, bt, out)) return launch_lean(A, stream);
+    if (A.n_rows > 0 && lean_eligible(st, bt, out, chunks, A.chunk_len)) return launch_lean(A, chunks, stream);
     return launch_recon(A, chunks, variant, stream);
 }
 
@@ -3834,8 +3851,8 @@ int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_o
         if (rc) return rc;
     }
     for (int i = 0; i < n; ++i) {
-        const bool lean = A[i].n_rows > 0 && chunks[i] == 1 && lean_eligible(st, &bts[i], &outs[i]);
-        const int rc = lean ? launch_lean(A[i], stream) : launch_recon(A[i], chunks[i], variant[i], stream);
+        const bool lean = A[i].n_rows > 0 && lean_eligible(st, &bts[i], &outs[i], chunks[i], A[i].chunk_len);
+        const int rc = lean ? launch_lean(A[i], chunks[i], stream) : launch_recon(A[i], chunks[i], variant[i], stream);
         if (rc) return rc;
     }
     return GVL_OK;

@@ -42,7 +42,7 @@ def gpu():
 # kernel path: gvl_set_debug_flags removes one way at a time.
 KERNEL_PATHS = {0: "default", 8: "scalar-walk", 64: "csr-inline-records", 80: "csr-vrec-gather", 32: "no-scan-free-plan",
                 128: "no-speculative-reads", 512: "per-wave-scans", 2048: "wave-per-row-diffs",
-                16384: "no-lean-kernel", 32768: "lean-lists-every-row"}
+                16384: "no-lean-kernel", 32768: "lean-lists-every-row", 1048576: "no-lean-long"}
 
 
 @pytest.fixture(params=sorted(KERNEL_PATHS), ids=[KERNEL_PATHS[k] for k in sorted(KERNEL_PATHS)])
@@ -294,12 +294,17 @@ def test_dense_variants_overflow_tables(gpu, oracle):
     check_batch(gpu, oracle, st, bt, annotate=True)
 
 
-def test_long_rows_chunked(gpu, oracle):
-    # Enformer-like rows: several chunks per row, each wave replays the walk to its chunk
+def test_long_rows_chunked(gpu, oracle, kpath):
+    # Enformer-like rows: several chunks per row, each wave replays the walk to its chunk (fixed-length rows of a
+    # multiple of 4 bases: the lean kernel's LONG form; anything else: the all-purpose kernel)
     st, bt = _synth(8, (1 << 20,), 6, 131072, indel_frac=0.15, rc_frac=0.5, random_shifts=True)
     check_batch(gpu, oracle, st, bt)
     st, bt = _synth(9, (1 << 19,), 5, 40_001, indel_frac=0.3, density=1 / 20, rc_frac=0.5, edge_frac=0.4)
     check_batch(gpu, oracle, st, bt, annotate=True)
+    # dense rows over contig edges, chunk borders inside long alleles, a last chunk shorter than the others
+    st, bt = _synth(10, (1 << 18, 50_000), 7, 40_004, indel_frac=0.5, density=1 / 12, rc_frac=0.5, edge_frac=0.4,
+                    random_shifts=True, max_indel=300)
+    check_batch(gpu, oracle, st, bt)
 
 
 def test_keep_mask(gpu, oracle):

@@ -5,7 +5,7 @@ A step = one batch FROM DATASET INDICES through ``DeviceHapsTracksDataset``: req
 fused reconstruct / one-hot kernel, and ``gvl_tracks_batch`` (scratch-track sizing, painting,
 realignment, reversal) -- every input resident in HBM, batches rotate over the dataset.
 ``value`` = windows / s of that whole step; ``roofline`` = the dominant kernel of the step
-(``reconstruct_kernel<OH_LC, haps, !annot>``) timed alone with HIP events over back-to-back launches,
+(``recon_lean_kernel<onehot, haps, long>``; ``GVL_DBG=1048576``: ``reconstruct_kernel<OH_LC, haps, !annot>``) timed alone with HIP events over back-to-back launches,
 ``kernels`` lists the other kernels of the step the same way.  Algorithmic bytes per window
 (SURVEY 8d): L (1 + 1 + 4) + 28 V + 61 for the haplotype half, + 4 L_track read + 4 L written per
 track for the realignment, + 4 L_track written + 12 B per interval for the painting."""
@@ -175,6 +175,10 @@ def main(args) -> None:
     par = (C.c_double * 1)(0.0)
     t_realign = timeit(lambda: _lib.check(lib.gvl_realign_tracks(C.byref(dev.c), C.byref(tbt.c), gdev._ptr(scratch), gdev._ptr(toff), par,
                                                                  C.c_int64(0), C.c_uint64(0), gdev._ptr(tout), gdev._stream_ptr())))
+    dbg = int(os.environ.get("GVL_DBG", "0") or 0)
+    lean_long = dev.ref4 is not None and dev.geno_rec is not None and not (dbg & (16384 | 1048576 | 16))
+    kernel_name = ("recon_lean_kernel<onehot, haps, long> (one wave per 2048-base chunk)" if lean_long
+                   else "reconstruct_kernel<OH_LC, haps=true, annot=false>")
     if rank == 0:
         hap_bytes = (L * 6 + 28.0 * mean_v + 61.0) * K
         realign_bytes = 4.0 * float(toff[-1]) + 4.0 * K * L
@@ -193,7 +197,7 @@ def main(args) -> None:
                        "loop": "native ring (gvl_loader_*)" if loop == "native" else "python submit loop", "parallelism": f"world_size {world}: one batch per rank per step"},
             "timing": {"how": "median of K-step regions between barrier + synchronize, host clock", "regions": len(spans)},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": _traffic("cfg4"), "kernel": "reconstruct_kernel<OH_LC, haps=true, annot=false>", "kernel_ms": t_recon,
+                         "traffic": _traffic("cfg4" if lean_long else "cfg4@allpurpose"), "kernel": kernel_name, "kernel_ms": t_recon,
                          "kernel_ms_how": "HIP events around 30 back-to-back launches on one stream",
                          "algorithmic_bytes_per_launch": hap_bytes,
                          "step_GBps": (hap_bytes + realign_bytes + paint_bytes) / (ms_step * 1e-3) / 1e9},

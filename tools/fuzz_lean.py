@@ -1,7 +1,9 @@
 """Randomised parity sweep of the LEAN kernel (fixed-length rows of at most 2048 bases, one-hot and / or haplotype bytes:
 what gvl_reconstruct sends to recon_lean_kernel) against the oracle.  Dense rows, long indels, shifts that
 meet indels, windows over contig edges, overflowing slots: every row the lean path hands to its solo general path
-is checked the same way.  python tools/fuzz_lean.py [n_cases] [seed]"""
+is checked the same way.  python tools/fuzz_lean.py [n_cases] [seed]
+FUZZ_LONG=1: rows of several 2048-base chunks (the kernel's LONG form: one wave per chunk, the row's walk replayed from
+the CSR records) -- chunk borders inside alleles, behind deletions, rows with hundreds of variants."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,9 +11,14 @@ from genvarloader_amd import HapsDevice, synth
 from oracle import oracle
 
 
+LONG = bool(int(os.environ.get("FUZZ_LONG", "0")))
+
+
 def one_case(rng):
     n_contigs = int(rng.integers(1, 4))
     contigs = tuple(int(x) for x in rng.integers(3_000, 120_000, n_contigs))
+    if LONG:
+        contigs = tuple(int(x) for x in rng.integers(12_000, 200_000, n_contigs))
     indel_frac = float(rng.choice([0.0, 0.1, 0.3, 0.6, 0.9]))
     density = float(rng.choice([1 / 400, 1 / 100, 1 / 30, 1 / 8, 1 / 3]))
     max_indel = int(rng.choice([3, 30, 200, 3000]))
@@ -26,9 +33,11 @@ def one_case(rng):
         st.ref[m] = rng.choice(np.frombuffer(b"RYKMacgtn", np.uint8), int(m.sum()))
     ploidy = int(rng.choice([1, 2, 2, 3]))
     L = int(rng.choice([4, 8, 64, 252, 256, 260, 500, 512, 1000, 1024, 1500, 2044, 2048]))
+    if LONG:
+        L = int(rng.choice([2052, 2056, 4096, 4100, 5000, 6144, 8192, 8196, 10_000, 16_384, 40_000]))
     L = min(L, ((min(contigs) - 200) // 4) * 4) if min(contigs) > 400 else min(L, 64)
     L = max(L, 4)
-    q = int(rng.integers(1, 40))
+    q = int(rng.integers(1, 40)) if not LONG else int(rng.integers(1, 6))
     bt = synth.make_batch(rng, st, q, ploidy, L, slack=int(rng.choice([0, 8, 40])), rc_frac=float(rng.choice([0.0, 0.5, 1.0])),
                           random_shifts=False, lookback=int(rng.choice([0, 40, 300, 3200])),
                           edge_frac=float(rng.choice([0.0, 0.0, 0.3, 1.0])), permute_csr=bool(rng.random() < 0.5),
