@@ -52,12 +52,13 @@ SYMBOLS = (
     "gvl_loader_table_bytes",
     "gvl_loader_create",
     "gvl_loader_set_epoch",
+    "gvl_loader_prefetch_epoch",
     "gvl_loader_start_epoch",
     "gvl_loader_next",
     "gvl_loader_destroy",
 )
 
-ABI_VERSION = 5          # include/gvl_hip.h: GVL_ABI_VERSION
+ABI_VERSION = 6          # include/gvl_hip.h: GVL_ABI_VERSION
 GVL_ONEHOT_LC = 0
 GVL_ONEHOT_CL = 1
 

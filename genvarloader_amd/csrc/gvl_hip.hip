@@ -4380,6 +4380,11 @@ struct gvl_loader {
     // epoch table (the caller's memory, like the slots): request arrays of every query of the epoch
     int *e_regions; i64 *e_goi; int *e_shifts; u8 *e_to_rc;
     struct LoaderSync *sync;      // non-NULL: a producer thread submits the groups (cfg.threaded)
+    // an epoch prepared ahead of its start (gvl_loader_prefetch_epoch): its table is filled, pf_ready recorded behind it
+    hipEvent_t pf_ready;
+    bool pf_valid;
+    const int64_t *pf_order; i64 pf_n; int pf_drop_last; void *pf_table; u64 pf_counter;
+    void *cur_table;              // the running epoch's table
 };
 
 // Producer thread state.  `submitted` / `consumed` / `n_batches` / `order` are only touched under
@@ -4478,6 +4483,7 @@ int gvl_loader_create(const gvl_static *st, const gvl_loader_config *cfg, gvl_lo
         ok = hipEventCreateWithFlags(&ld->done[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&ld->released[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&ld->epoch_ready, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ld->pf_ready, hipEventDisableTiming) == hipSuccess;
     if (!ok) { gvl_loader_destroy(ld); return fail(GVL_ERR_HIP, "%s", "gvl_loader_create: stream / event creation failed"); }
     if (cfg->threaded) {
         LoaderSync *sy = new (std::nothrow) LoaderSync;
@@ -4509,6 +4515,7 @@ int gvl_loader_destroy(gvl_loader *ld) {
         if (ld->released[i]) (void)hipEventDestroy(ld->released[i]);
     }
     if (ld->epoch_ready) (void)hipEventDestroy(ld->epoch_ready);
+    if (ld->pf_ready) (void)hipEventDestroy(ld->pf_ready);
     delete ld;
     return GVL_OK;
 }
@@ -4517,6 +4524,73 @@ int gvl_loader_set_epoch(gvl_loader *ld, uint64_t epoch) {
     if (!ld) return fail(GVL_ERR_INVALID, "%s", "gvl_loader_set_epoch: NULL loader");
     ld->next_epoch = epoch;
     ld->epoch_set = true;
+    return GVL_OK;
+}
+
+// the request arrays of every query of an epoch, the per-batch track seeds and the scratch-track sizing of its batches,
+// into `table` on stream `s`
+static int loader_fill_table(gvl_loader *ld, const int64_t *order, i64 n, int32_t drop_last, void *table, u64 counter, hipStream_t s) {
+    const gvl_loader_config &c = ld->cfg;
+    int64_t po[GVL_LOADER_TABLE_PARTS];
+    gvl_loader_table_bytes(&c, n, po);
+    u8 *base = (u8 *)table;
+    int *t_regions = (int *)(base + po[0]);
+    i64 *t_goi = (i64 *)(base + po[1]);
+    int *t_shifts = (int *)(base + po[2]);
+    u8 *t_to_rc = base + po[3];
+    u64 *t_seeds = (u64 *)(base + po[4]);
+    i64 *t_track_offsets = (i64 *)(base + po[5]);
+    i64 *t_out_offsets = (i64 *)(base + po[6]);
+    const i64 bs = c.batch_size;
+    const i64 n_batches = drop_last ? n / bs : (n + bs - 1) / bs;
+    const i64 n_used = drop_last ? n_batches * bs : n;
+    if (n_used <= 0) return GVL_OK;
+    const int rc = gvl_prepare_request(&ld->st, order, n_used, c.full_regions, c.n_regions, c.n_samples, c.ploidy, c.jitter,
+                                       c.rc_neg, c.deterministic, c.output_length < 0 ? 0 : c.output_length, c.seed, counter,
+                                       t_regions, (int64_t *)t_goi, t_to_rc, t_shifts, s);
+    if (rc) return rc;
+    if (c.n_tracks > 0 && c.track_seed_mode == 1) {
+        const i64 grid = (n_batches * WAVE + 255) / 256;
+        batch_seeds_kernel<<<dim3((unsigned)grid), dim3(256), 0, s>>>((const i64 *)order, n_used, bs, n_batches, c.deterministic,
+                                                                      c.seed, counter, t_seeds);
+        const int rc2 = check_launch("gvl_loader_start_epoch(seeds)");
+        if (rc2) return rc2;
+    }
+    if (c.n_tracks > 0) {
+        // the scratch-track sizing of every batch of the epoch: lengths (one wave per query), then one scan per batch
+        gvl_batch eb;
+        memset(&eb, 0, sizeof(eb));
+        eb.regions = t_regions; eb.regions_stride = 4; eb.shifts = t_shifts; eb.geno_offset_idx = (const int64_t *)t_goi;
+        eb.batch = n_used; eb.ploidy = c.ploidy; eb.output_length = c.output_length;
+        DiffArgs D;
+        int rc3 = fill_diff_args(D, &ld->st, &eb, "gvl_loader_start_epoch");
+        if (rc3) return rc3;
+        D.keep = nullptr; D.keep_offsets = nullptr;
+        const i64 grid = (n_used * WAVE + 255) / 256;
+        if (grid > 0x7FFFFFFFll) return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_loader_start_epoch: too many queries for the track sizing");
+        track_lengths_epoch_kernel<<<dim3((unsigned)grid), dim3(256), 0, s>>>(D, t_regions, 4, n_used, bs, c.output_length,
+                                                                               t_track_offsets, t_out_offsets);
+        rc3 = check_launch("gvl_loader_start_epoch(track lengths)");
+        if (rc3) return rc3;
+        track_scan_batches_kernel<<<dim3((unsigned)n_batches), dim3(256), 0, s>>>(t_track_offsets, n_used, bs);
+        rc3 = check_launch("gvl_loader_start_epoch(track offsets)");
+        if (rc3) return rc3;
+    }
+    return GVL_OK;
+}
+
+int gvl_loader_prefetch_epoch(gvl_loader *ld, uint64_t epoch, const int64_t *order, int64_t n, int32_t drop_last, void *table, void *stream) {
+    if (!ld || n < 0 || (n > 0 && (!order || !table)) || ((uintptr_t)table & 255))
+        return fail(GVL_ERR_INVALID, "%s", "gvl_loader_prefetch_epoch: bad arguments (table: gvl_loader_table_bytes() bytes, 256-byte aligned)");
+    if (n > (1ll << 31)) return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_loader_prefetch_epoch: more than 2^31 queries per epoch (shard the order)");
+    if (table == ld->cur_table) return fail(GVL_ERR_INVALID, "%s", "gvl_loader_prefetch_epoch: `table` is the running epoch's table (alternate between two)");
+    ld->pf_valid = false;
+    const int rc = loader_fill_table(ld, order, n, drop_last, table, epoch + 1, (hipStream_t)stream);
+    if (rc) return rc;
+    if (hipEventRecord(ld->pf_ready, (hipStream_t)stream) != hipSuccess)
+        return fail(GVL_ERR_HIP, "%s", "gvl_loader_prefetch_epoch: hipEventRecord failed");
+    ld->pf_order = order; ld->pf_n = n; ld->pf_drop_last = drop_last; ld->pf_table = table; ld->pf_counter = epoch + 1;
+    ld->pf_valid = true;
     return GVL_OK;
 }
 
@@ -4546,11 +4620,20 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
                 return fail(GVL_ERR_HIP, "%s", "gvl_loader_start_epoch: hipEventRecord failed");
         ld->released_groups = g_last + 1;
     }
-    // the previous epoch's last batches were handed to the consumer: the new table contents must not
-    // overtake whatever is still queued on them
-    for (int i = 0; i < ld->n_sets; ++i)
-        if (ld->set_used[i] && hipStreamWaitEvent(s, ld->done[i], 0) != hipSuccess)
-            return fail(GVL_ERR_HIP, "%s", "gvl_loader_start_epoch: hipStreamWaitEvent failed");
+    u64 counter = ld->counter + 1;
+    if (ld->epoch_set) { counter = ld->next_epoch + 1; ld->epoch_set = false; }
+    // was exactly this epoch prepared ahead (gvl_loader_prefetch_epoch)?  Then its table is filled -- or being filled,
+    // pf_ready says when -- and nothing of the running epoch is touched: no wait for that epoch's last batches
+    const bool prefetched = ld->pf_valid && ld->pf_order == order && ld->pf_n == n && ld->pf_drop_last == drop_last &&
+                            ld->pf_table == table && ld->pf_counter == counter && table != ld->cur_table;
+    ld->pf_valid = false;
+    if (!prefetched) {
+        // the previous epoch's last batches were handed to the consumer: the new table contents must not
+        // overtake whatever is still queued on them
+        for (int i = 0; i < ld->n_sets; ++i)
+            if (ld->set_used[i] && hipStreamWaitEvent(s, ld->done[i], 0) != hipSuccess)
+                return fail(GVL_ERR_HIP, "%s", "gvl_loader_start_epoch: hipStreamWaitEvent failed");
+    }
     {
         int64_t po[GVL_LOADER_TABLE_PARTS];
         gvl_loader_table_bytes(&c, n, po);
@@ -4568,44 +4651,16 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
     ld->n_batches = drop_last ? n / bs : (n + bs - 1) / bs;
     ld->n_groups = (ld->n_batches + ld->G - 1) / ld->G;
     ld->submitted = ld->consumed = ld->released_groups = 0;
-    if (ld->epoch_set) { ld->counter = ld->next_epoch + 1; ld->epoch_set = false; }
-    else ++ld->counter;
-    const i64 n_used = drop_last ? ld->n_batches * bs : n;
-    if (n_used > 0) {
-        const int rc = gvl_prepare_request(&ld->st, order, n_used, c.full_regions, c.n_regions, c.n_samples, c.ploidy, c.jitter,
-                                           c.rc_neg, c.deterministic, c.output_length < 0 ? 0 : c.output_length, c.seed, ld->counter,
-                                           ld->e_regions, (int64_t *)ld->e_goi, ld->e_to_rc, ld->e_shifts, s);
+    ld->counter = counter;
+    ld->cur_table = table;
+    if (prefetched) {
+        hipEvent_t t = ld->epoch_ready; ld->epoch_ready = ld->pf_ready; ld->pf_ready = t;
+    } else {
+        const int rc = loader_fill_table(ld, order, n, drop_last, table, counter, s);
         if (rc) return rc;
-        if (c.n_tracks > 0 && c.track_seed_mode == 1) {
-            const i64 grid = (ld->n_batches * WAVE + 255) / 256;
-            batch_seeds_kernel<<<dim3((unsigned)grid), dim3(256), 0, s>>>((const i64 *)order, n_used, bs, ld->n_batches, c.deterministic,
-                                                                          c.seed, ld->counter, ld->e_seeds);
-            const int rc2 = check_launch("gvl_loader_start_epoch(seeds)");
-            if (rc2) return rc2;
-        }
-        if (c.n_tracks > 0) {
-            // the scratch-track sizing of every batch of the epoch: lengths (one wave per query), then one scan per batch
-            gvl_batch eb;
-            memset(&eb, 0, sizeof(eb));
-            eb.regions = ld->e_regions; eb.regions_stride = 4; eb.shifts = ld->e_shifts; eb.geno_offset_idx = (const int64_t *)ld->e_goi;
-            eb.batch = n_used; eb.ploidy = c.ploidy; eb.output_length = c.output_length;
-            DiffArgs D;
-            int rc3 = fill_diff_args(D, &ld->st, &eb, "gvl_loader_start_epoch");
-            if (rc3) return rc3;
-            D.keep = nullptr; D.keep_offsets = nullptr;
-            const i64 grid = (n_used * WAVE + 255) / 256;
-            if (grid > 0x7FFFFFFFll) return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_loader_start_epoch: too many queries for the track sizing");
-            track_lengths_epoch_kernel<<<dim3((unsigned)grid), dim3(256), 0, s>>>(D, ld->e_regions, 4, n_used, bs, c.output_length,
-                                                                                   ld->e_track_offsets, ld->e_out_offsets);
-            rc3 = check_launch("gvl_loader_start_epoch(track lengths)");
-            if (rc3) return rc3;
-            track_scan_batches_kernel<<<dim3((unsigned)ld->n_batches), dim3(256), 0, s>>>(ld->e_track_offsets, n_used, bs);
-            rc3 = check_launch("gvl_loader_start_epoch(track offsets)");
-            if (rc3) return rc3;
-        }
+        if (hipEventRecord(ld->epoch_ready, s) != hipSuccess)
+            return fail(GVL_ERR_HIP, "%s", "gvl_loader_start_epoch: hipEventRecord failed");
     }
-    if (hipEventRecord(ld->epoch_ready, s) != hipSuccess)
-        return fail(GVL_ERR_HIP, "%s", "gvl_loader_start_epoch: hipEventRecord failed");
     for (int i = 0; i < 16; ++i) ld->stream_synced[i] = false;
     if (ld->sync) {
         ld->sync->active = true;

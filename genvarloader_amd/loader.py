@@ -653,6 +653,9 @@ class DeviceLoader:
         if sampler is not None and self.world_size > 1:
             raise ValueError("a custom sampler does its own sharding: pass world_size=1")
         self.in_flight = max(1, min(16, int(in_flight)))
+        # native loop: an epoch whose order depends on (seed, epoch number) only is prepared while the epoch before it runs
+        # (gvl_loader_prefetch_epoch), so that consecutive epochs leave no gap on the GPU; False: every epoch is prepared at its start
+        self.prefetch_epochs = True
         self._native = None
         self.streams = None
 
@@ -753,9 +756,10 @@ class DeviceLoader:
         nat["views"][key] = v
         return v
 
-    def _epoch_table(self, n: int):
-        """The epoch's request arrays (filled by gvl_loader_start_epoch): one grow-only device buffer,
-        typed views of its four parts, split into per-batch views once per epoch."""
+    def _epoch_table(self, n: int, which: int = 0):
+        """The epoch's request arrays (filled by gvl_loader_start_epoch / gvl_loader_prefetch_epoch): one of two
+        grow-only device buffers (epochs alternate, so that the next epoch's table can be filled while this
+        epoch's batches still read theirs), typed views of its parts."""
         import ctypes as C
 
         nat, ds, d = self._native, self.ds, self.ds.dev.device
@@ -764,9 +768,10 @@ class DeviceLoader:
 
         po = (C.c_int64 * _lib.LOADER_TABLE_PARTS)()
         nbytes = int(lib.gvl_loader_table_bytes(C.byref(nat["cfg"]), C.c_int64(n), po))
-        tab = nat.get("table")
+        tabs = nat.setdefault("tables", [None, None])
+        tab = tabs[which]
         if tab is None or tab.numel() < nbytes:
-            tab = nat["table"] = torch.empty(nbytes + nbytes // 4, dtype=torch.uint8, device=d)
+            tab = tabs[which] = torch.empty(nbytes + nbytes // 4, dtype=torch.uint8, device=d)
         P, bs = ds.ploidy, self.batch_size
 
         def part(i, dtype, shape):
@@ -795,7 +800,21 @@ class DeviceLoader:
         with torch.cuda.device(d):
             cur = torch.cuda.current_stream(d)
             g = self.generator
-            if self.world_size == 1 and self.shuffle and g is not None and g.device.type != "cuda":
+
+            def make_order(epoch):
+                return self._padded(epoch_order(len(ds), shuffle=self.shuffle, seed=self.seed, epoch=epoch, rank=self.rank,
+                                                world=self.world_size, drop_last=self.drop_last and self.world_size > 1,
+                                                device=d, generator=g))
+
+            # an epoch whose order is a pure function of (seed, epoch number) is prepared one epoch ahead
+            # (gvl_loader_prefetch_epoch): what this epoch needs may already be there
+            pure = g is None or not self.shuffle or self.world_size > 1
+            ekey = (self.epoch, self.seed, self.shuffle, self.rank, self.world_size, self.drop_last, self.pad_to, len(ds),
+                   self.batch_size)
+            pf = nat.pop("prefetch", None)
+            if pf is not None and pure and pf[0] == ekey:
+                _, order, which = pf
+            elif self.world_size == 1 and self.shuffle and g is not None and g.device.type != "cuda":
                 # host generator: shuffle into a persistent pinned buffer and copy asynchronously
                 pin = nat.get("pinned")
                 if pin is None or pin.numel() != len(ds):
@@ -803,22 +822,38 @@ class DeviceLoader:
                 torch.randperm(len(ds), generator=g, out=pin)
                 order = torch.empty(len(ds), dtype=torch.int64, device=d)
                 order.copy_(pin, non_blocking=True)
+                order = self._padded(order)
+                which = 1 - nat.get("which", 1)
             else:                                  # shuffle on the device: no H2D of the order
-                order = epoch_order(len(ds), shuffle=self.shuffle, seed=self.seed, epoch=self.epoch, rank=self.rank,
-                                    world=self.world_size, drop_last=self.drop_last and self.world_size > 1,
-                                    device=d, generator=g)
-            order = self._padded(order)
+                order = make_order(self.epoch)
+                which = 1 - nat.get("which", 1)
             _lib.check(lib.gvl_loader_set_epoch(handle, C.c_uint64(self.epoch & 0xFFFFFFFFFFFFFFFF)))
             self.epoch += 1
             n = int(order.numel())
-            tab, ev = self._epoch_table(n)
+            tab, ev = self._epoch_table(n, which)
             ev.order = order
             if ev.seeds is None:
                 ev.seeds = getattr(ds, "base_seed", None)
             _lib.check(lib.gvl_loader_start_epoch(handle, C.c_void_p(order.data_ptr()), C.c_int64(n),
                                                   C.c_int32(int(self.drop_last)), C.c_void_p(tab.data_ptr()),
                                                   C.c_void_p(cur.cuda_stream)))
+            nat["order_prev"] = nat.get("order")       # (the epoch before may still have batches in flight that read theirs)
             nat["order"] = order                       # keep the epoch order alive
+            nat["which"] = which
+            next_epoch = self.epoch
+
+            def prefetch_next():
+                # the NEXT epoch's order and table, queued early in this epoch (right behind its first submits, so
+                # that those are not held up by the host work here): the epoch boundary then costs nothing -- the
+                # next epoch's first batches queue right behind this epoch's last
+                nkey = (next_epoch,) + ekey[1:]
+                norder = make_order(next_epoch)
+                nn = int(norder.numel())
+                ntab, _ = self._epoch_table(nn, 1 - which)
+                _lib.check(lib.gvl_loader_prefetch_epoch(handle, C.c_uint64(next_epoch & 0xFFFFFFFFFFFFFFFF),
+                                                         C.c_void_p(norder.data_ptr()), C.c_int64(nn), C.c_int32(int(self.drop_last)),
+                                                         C.c_void_p(ntab.data_ptr()), C.c_void_p(cur.cuda_stream)))
+                nat["prefetch"] = (nkey, norder, 1 - which)
             nxt, ref_out, bs = lib.gvl_loader_next, C.byref(out), self.batch_size
             nxt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]          # plain ints in, no wrapper objects per call
             # the consumer's CURRENT stream, read every iteration (it may change), through the raw getter
@@ -838,6 +873,8 @@ class DeviceLoader:
                     # process-global, so polling it here reports anything the batches consumed so far have raised
                     _lib.check_async()
                     return
+                if i == 0 and pure and self.prefetch_epochs:
+                    prefetch_next()
                 key = (out.slot, out.batch)
                 batch = ring.get(key)
                 if batch is None:            # one object per (slot, size): its outputs never change, its rows do

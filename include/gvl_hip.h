@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GVL_ABI_VERSION 5
+#define GVL_ABI_VERSION 6
 
 enum {
     GVL_OK = 0,
@@ -496,6 +496,17 @@ int gvl_loader_create(const gvl_static *st, const gvl_loader_config *cfg, gvl_lo
  * (cfg.seed, epoch number, dataset index) -- see gvl_loader_set_epoch. */
 int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int32_t drop_last,
                            void *table, void *stream);
+/* Prepare epoch number `epoch` AHEAD of its start: the same table fill as gvl_loader_start_epoch (same arguments,
+ * same draws), into a table that is NOT the running epoch's, on `stream` -- typically right after the running epoch
+ * was started, when nothing is queued in front of it.  A later gvl_loader_start_epoch with exactly these arguments
+ * for exactly this epoch number (the next in sequence, or the one named by gvl_loader_set_epoch) then finds its table
+ * filled: it launches nothing and -- because nothing of the running epoch is overwritten -- does not wait for that
+ * epoch's last batches, so the first batches of the new epoch are queued behind them without a gap (without it an
+ * epoch boundary costs the table fill + a pipeline refill: ~90 us for BASELINE config 4, 0.25-0.5 ms of a 1.6 ms
+ * config-5 epoch).  Anything else (another order, table, length, epoch) is a normal start; a prepared epoch that is
+ * never started costs its kernels only.  `order` and `table` must stay alive until that epoch has ended. */
+int gvl_loader_prefetch_epoch(gvl_loader *ld, uint64_t epoch, const int64_t *order, int64_t n, int32_t drop_last,
+                              void *table, void *stream);
 /* Name the epoch the next gvl_loader_start_epoch begins (like DistributedSampler.set_epoch).  The jitter /
  * shift draw of dataset index i is a function of (cfg.seed, epoch, i) only -- not of the rank, the batch the
  * index lands in or the batch size -- so every rank passes the same number and an N-GPU epoch draws what the

@@ -777,3 +777,65 @@ def test_tracks_with_their_own_fill_and_region_level_lists(oracle, python_loop):
             np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32), err_msg=name)
         seen += len(idx)
     assert seen == R * S
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("tracks", [False, True], ids=["haps", "haps+tracks"])
+def test_epochs_prepared_ahead_deliver_what_epochs_prepared_at_their_start_do(tracks):
+    """The native loop fills the NEXT epoch's table while the running epoch's batches are in flight
+    (``gvl_loader_prefetch_epoch``).  Chained epochs, a ``set_epoch`` jump (the prepared epoch is not the one that
+    starts: it is dropped), an abandoned epoch and a change of batch size must deliver exactly the batches of a
+    loader that prepares every epoch at its start -- indices, draws, one-hot and tracks."""
+    from genvarloader_amd import HapsDevice
+    from genvarloader_amd.loader import DeviceHapsDataset, DeviceHapsTracksDataset, DeviceLoader
+
+    R, S, P, L = 5, 7, 2, 512
+    st, full_regions, go, gv = _grid_dataset(33, R, S, P, L + 64, indel_frac=0.5, slack=0)
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+    if tracks:
+        rng = np.random.default_rng(3)
+        starts, ends, vals, offs = [], [], [], [0]
+        for r in range(R):
+            for s_ in range(S):
+                n = int(rng.integers(5, 40))
+                s0 = np.sort(rng.integers(int(full_regions[r, 1]) - 50, int(full_regions[r, 2]) + 50, n)).astype(np.int32)
+                starts.append(s0); ends.append(s0 + rng.integers(1, 30, n).astype(np.int32)); vals.append(rng.random(n).astype(np.float32))
+                offs.append(offs[-1] + n)
+        tr = {"t": (np.concatenate(starts), np.concatenate(ends), np.concatenate(vals), np.asarray(offs, np.int64))}
+        ds = DeviceHapsTracksDataset(dev, full_regions, S, P, tracks=tr, output_length=L, jitter=4, deterministic=False, seed=9,
+                                     onehot=True, haps=False)
+    else:
+        ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, jitter=4, deterministic=False, seed=9, onehot=True, haps=False)
+
+    def run(prefetch):
+        dl = DeviceLoader(ds, batch_size=4, shuffle=True, seed=11, in_flight=3, group=1, draw_stream=7)
+        dl.prefetch_epochs = prefetch
+        seen = []
+
+        def epoch(stop_after=None):
+            for i, b in enumerate(dl):
+                item = [b.idx.cpu().numpy().copy(), b.regions.cpu().numpy().copy(), b.shifts.cpu().numpy().copy(),
+                        b.onehot.cpu().numpy().copy()]
+                if tracks:
+                    item.append(b.tracks.cpu().numpy().copy())
+                seen.append(item)
+                if stop_after is not None and i == stop_after:
+                    break
+
+        epoch(); epoch()                      # chained: the second one was prepared ahead
+        dl.set_epoch(7); epoch()              # a jump: what was prepared (epoch 2) is dropped
+        epoch(stop_after=2)                   # abandoned after three batches ...
+        epoch()                               # ... and the one prepared behind it starts all the same
+        dl.set_epoch(3); epoch(); epoch()
+        return seen
+
+    a, b = run(True), run(False)
+    assert len(a) == len(b) and len(a) > 50
+    for x, y in zip(a, b):
+        for u, v in zip(x, y):
+            np.testing.assert_array_equal(u, v)
+    # (and epochs differ from each other: the comparison above is not one batch list seven times)
+    assert not np.array_equal(a[0][0], a[9][0])

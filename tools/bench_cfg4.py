@@ -76,7 +76,7 @@ def main(args) -> None:
         import torch.distributed as dist
 
         dist.init_process_group(backend, **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
-    R, S, P, L = 16, 64, 2, 131072
+    R, S, P, L = int(os.environ.get("GVL_CFG4_R", 16)), int(os.environ.get("GVL_CFG4_S", 64)), 2, 131072
     st, dev, ds, tracks, mean_v = build(f"cuda:{local}", R, S, P, L, seed=20260802 + 4 + 1000 * rank)
     bs = int(os.environ.get("GVL_CFG4_BS", 128))                # queries per batch = 256 windows
     order = np.random.default_rng(1).permutation(R * S)

@@ -39,6 +39,8 @@ for det in (True, False):
                        for c in os.environ["COMBOS"].split(","))
     for in_flight, group, gen, thr in combos:
         dl = ds.to_dataloader(batch_size=bs, shuffle=True, generator=gen, in_flight=in_flight, threaded=thr, group=group)
+        if os.environ.get("NO_PREFETCH"):          # A/B: every epoch prepared at its start (as before gvl_loader_prefetch_epoch)
+            dl.prefetch_epochs = False
         for rep in range(int(os.environ.get("REPS", 4))):                        # first pass warms up
             torch.cuda.synchronize(); t0 = time.perf_counter(); n = 0; t_first = None
             for batch in dl:
@@ -48,6 +50,13 @@ for det in (True, False):
             t_issue = time.perf_counter()
             torch.cuda.synchronize(); t1 = time.perf_counter()
         dt = t1 - t0
+        # epochs chained (no synchronisation between them: what a training loop does)
+        n_chain = int(os.environ.get("CHAIN", 6))
+        torch.cuda.synchronize(); c0 = time.perf_counter()
+        for rep in range(n_chain):
+            for batch in dl:
+                pass
+        torch.cuda.synchronize(); dc = (time.perf_counter() - c0) / n_chain
         print(f"deterministic={det} in_flight={in_flight} group={group} {'cpu-shuffle' if gen is not None else 'dev-shuffle'}{' threaded' if thr else ''}: {n} windows in {dt*1e3:.2f} ms -> {n/dt/1e6:.1f} M windows/s; "
               f"first batch after {1e3*(t_first-t0):.2f} ms, loop {1e6*(t_issue-t_first)/max(1,len(dl)-1):.1f} us/batch host, "
-              f"steady {1e6*(t1-t_first)/max(1,len(dl)-1):.1f} us per {bs*P}-window batch", flush=True)
+              f"steady {1e6*(t1-t_first)/max(1,len(dl)-1):.1f} us per {bs*P}-window batch; {n_chain} epochs chained: {dc*1e3:.2f} ms per epoch = {n/dc/1e6:.1f} M windows/s", flush=True)
