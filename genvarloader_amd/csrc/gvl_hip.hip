@@ -39,6 +39,7 @@
 #include <string.h>
 #include <time.h>
 #include <new>
+#include <type_traits>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -2623,12 +2624,100 @@ __device__ __forceinline__ u64 hash4_dev(u64 a, u64 b, u64 c, u64 d) {   // :48-
     return h;
 }
 
+// ---- where the realignment reads a query's reference-coordinate track from -------------------------------
+// SrcGlobal: a track in memory (gvl_realign_tracks; the scratch track the painter wrote).
+// SrcPainted: the query's INTERVALS -- src/intervals.rs:19-126 evaluated at the positions the realignment asks for,
+// so that the scratch track is neither written nor read (BASELINE config 4: 67 MB each way per batch, and one
+// launch).  Position x of the track = reference position qs + x; its value = that of the last interval (in order)
+// that covers it, 0.0 if none.  The wave keeps a WINDOW of the track as the tiled painter keeps a chunk: the
+// candidate intervals' values / ends and a bitmap of their starts with its popcount prefix -- for a position in
+// the window two LDS reads give the only candidate that can cover it (non-overlapping candidates; a window whose
+// candidates overlap, or more than PAINT_TILE of them, is not used).  Any other position is looked up in the
+// list itself (binary search + walk back under the running maximum of ends, as the per-value painter does):
+// exactness never depends on what the window holds.
+constexpr int PAINT_TILE = 256;
+constexpr int PAINT_CHUNK = 2048;
+constexpr int PAINT_WIN = 4096;                 // window positions (a chunk's 2048 + what its deletions skip + slack)
+struct PaintIndex { const i64 *offsets; const int *base; const int *lo; const int *hi; };
+struct PaintSrcArgs {                           // the interval set of one track (gvl_track_set) for the kernel
+    const i64 *offset_idxs; i64 list_div;
+    const int *itv_starts; const int *itv_ends; const float *itv_values; const i64 *itv_offsets; const int *pmax;
+    PaintIndex X;
+};
+struct PaintWin { u32 bm[PAINT_WIN / 32]; u32 pre[PAINT_WIN / 32]; float cv[PAINT_TILE]; int ce[PAINT_TILE]; };
+
+struct SrcGlobal {
+    const float *track; i64 tlen;
+    __device__ __forceinline__ float at(const i64 x) const { return (x >= 0 && x < tlen) ? track[x] : 0.0f; }
+    // (0 <= x, x + 4 <= tlen)
+    __device__ __forceinline__ void at4(const i64 x, float (&v)[4]) const {
+        const float *src = track + x;
+        v[0] = src[0]; v[1] = src[1]; v[2] = src[2]; v[3] = src[3];
+    }
+};
+struct SrcPainted {
+    const PaintWin *W; i64 x_lo; int wlen; int base; bool win_ok;
+    i64 tlen, qs, s0, e0;
+    const int *itv_starts; const int *itv_ends; const float *itv_values; const int *pmax;
+    __device__ __forceinline__ float in_win(const int r) const {
+        const u32 wd = W->bm[r >> 5];
+        const int ig = base + (int)W->pre[r >> 5] + __builtin_popcount(wd & (0xFFFFFFFFu >> (31 - (r & 31))));
+        return (ig >= 0 && W->ce[ig] > r) ? W->cv[ig] : 0.0f;
+    }
+    __device__ float in_list(const i64 j) const {           // (intervals.rs:19-126 for one position)
+        i64 lo = s0, hi = e0;                                  // first interval with start - qs > j
+        while (lo < hi) {
+            const i64 mid = (lo + hi) >> 1;
+            if ((i64)itv_starts[mid] - qs <= j) lo = mid + 1; else hi = mid;
+        }
+        if (lo > s0 && (i64)pmax[lo - 1] - qs > j)
+            for (i64 c = lo - 1; c >= s0; --c)
+                if ((i64)itv_ends[c] - qs > j) return itv_values[c];
+        return 0.0f;
+    }
+    __device__ __forceinline__ float at(const i64 x) const {
+        if (x < 0 || x >= tlen) return 0.0f;
+        const i64 r = x - x_lo;
+        if (win_ok && r >= 0 && r < wlen) return in_win((int)r);
+        return in_list(x);
+    }
+    __device__ __forceinline__ void at4(const i64 x, float (&v)[4]) const {
+        const i64 r64 = x - x_lo;
+        if (win_ok && r64 >= 0 && r64 + 4 <= wlen) {
+            const int r = (int)r64, bp = r & 31;
+            if (bp <= 28) {                                    // the four positions share a bitmap word
+                const u32 wd = W->bm[r >> 5];
+                const int pre = base + (int)W->pre[r >> 5];
+                const int i0 = pre + __builtin_popcount(wd & (0xFFFFFFFFu >> (31 - bp)));
+                const int i3 = pre + __builtin_popcount(wd & (0xFFFFFFFFu >> (28 - bp)));
+                if (i0 == i3) {
+                    const int e0_ = i0 >= 0 ? W->ce[i0] : 0;
+                    const float c0 = i0 >= 0 ? W->cv[i0] : 0.0f;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) v[g] = e0_ > r + g ? c0 : 0.0f;
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ig = pre + __builtin_popcount(wd & (0xFFFFFFFFu >> (31 - bp - g)));
+                        v[g] = (ig >= 0 && W->ce[ig] > r + g) ? W->cv[ig] : 0.0f;
+                    }
+                }
+                return;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] = at(x + g);
+    }
+};
+
 // One value of an insertion-fill region: src/tracks/mod.rs:87-190, evaluated per position.
 // `i` = offset inside the region, `pp` = output index in the row.
-__device__ float fill_value(const TrackArgs &A, const float *track, i64 tlen, i64 vrp, i64 v_len, i64 i,
+template <class Src>
+__device__ float fill_value(const TrackArgs &A, const Src &S, i64 vrp, i64 v_len, i64 i,
                             i64 pp, u64 query, u64 hap) {
 #pragma clang fp contract(off)
-    auto tr = [&](i64 x) -> float { return (x >= 0 && x < tlen) ? track[x] : 0.0f; };
+    const i64 tlen = S.tlen;
+    auto tr = [&](i64 x) -> float { return S.at(x); };
     if (A.strategy == GVL_FILL_REPEAT_5P) return tr(vrp);
     if (A.strategy == GVL_FILL_REPEAT_5P_NORM) return tr(vrp) / (float)v_len;
     if (A.strategy == GVL_FILL_CONSTANT) return (float)A.param;
@@ -2664,8 +2753,11 @@ __device__ float fill_value(const TrackArgs &A, const float *track, i64 tlen, i6
     return 0.0f;
 }
 
-__global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A) {
+// PAINT: the track comes from the query's intervals (SrcPainted; A.tracks is not read), else from memory.
+template <bool PAINT>
+__global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, const PaintSrcArgs PS) {
     __shared__ TrackMirror mirror[4];
+    __shared__ PaintWin wins[PAINT ? 4 : 1];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = rfl((int)(threadIdx.x >> 6));
     TrackMirror &M = mirror[wave];
@@ -2681,7 +2773,7 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A) 
     const int hi_clip = (L - lo_clip > A.chunk_len) ? lo_clip + A.chunk_len : L;
     const i64 t_s = rfl64(A.track_offsets[query]);
     const i64 tlen = rfl64(A.track_offsets[query + 1]) - t_s;
-    const float *track = A.tracks + t_s;
+    const float *track = PAINT ? nullptr : A.tracks + t_s;
     const i64 q_start = rfl(A.regions[query * A.regions_stride + 1]);
     const i64 shift = rfl(A.shifts[k]);
     const i64 o_idx = rfl64(A.geno_offset_idx[k]);
@@ -2857,6 +2949,91 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A) 
         }
     }
 
+    typename std::conditional<PAINT, SrcPainted, SrcGlobal>::type S;
+    bool have_win = false;
+    if constexpr (PAINT) {
+        const i64 idx = rfl64(PS.offset_idxs[query]) / PS.list_div;
+        S.W = &wins[wave]; S.x_lo = 0; S.wlen = 0; S.base = -1; S.win_ok = false;
+        S.tlen = tlen; S.qs = q_start;
+        S.s0 = rfl64(PS.itv_offsets[idx]); S.e0 = rfl64(PS.itv_offsets[idx + 1]);
+        S.itv_starts = PS.itv_starts; S.itv_ends = PS.itv_ends; S.itv_values = PS.itv_values; S.pmax = PS.pmax;
+    } else {
+        S.track = track; S.tlen = tlen;
+    }
+    // the window of a painted source: from where the chunk's first value comes from on (see SrcPainted)
+    auto build_window = [&](const i64 x_first) {
+        PaintWin &Wn = wins[PAINT ? wave : 0];
+        i64 x_lo = x_first - 64;
+        x_lo = x_lo < 0 ? 0 : x_lo;
+        const i64 wl64 = tlen - x_lo;
+        const int wlen = wl64 > PAINT_WIN ? PAINT_WIN : (wl64 < 0 ? 0 : (int)wl64);
+        const i64 idx = rfl64(PS.offset_idxs[query]) / PS.list_div;
+        const i64 s0 = rfl64(PS.itv_offsets[idx]), e0 = rfl64(PS.itv_offsets[idx + 1]);
+        if (wlen <= 0 || !PS.X.offsets || e0 <= s0) return;
+        const i64 b0 = rfl64(PS.X.offsets[idx]);
+        const i64 nb = rfl64(PS.X.offsets[idx + 1]) - b0;
+        if (nb <= 0) return;
+        const i64 bbase = rfl(PS.X.base[idx]);
+        i64 ba = (q_start + x_lo - bbase) >> 11, bb = (q_start + x_lo + wlen - 1 - bbase) >> 11;
+        ba = ba < 0 ? 0 : (ba > nb - 1 ? nb - 1 : ba);
+        bb = bb < 0 ? 0 : (bb > nb - 1 ? nb - 1 : bb);
+        i64 lo_c = s0 + rfl(PS.X.lo[b0 + ba]);
+        const i64 hi_c = s0 + rfl(PS.X.hi[b0 + bb]);
+        if (lo_c > hi_c) lo_c = hi_c;
+        if (hi_c - lo_c > PAINT_TILE) return;
+        const int n_c = (int)(hi_c - lo_c);
+        Wn.bm[lane] = 0u; Wn.bm[WAVE + lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        bool bad = false;
+        int n_before = 0;
+        int carry_e = (int)0x80000000, carry_s = (int)0x80000000;          // end / start of the candidate in front
+        int c_s[PAINT_TILE / WAVE], c_e[PAINT_TILE / WAVE]; float c_v[PAINT_TILE / WAVE];
+#pragma unroll
+        for (int r_ = 0; r_ < PAINT_TILE / WAVE; ++r_) {
+            const int i = r_ * WAVE + lane;
+            c_s[r_] = 0; c_e[r_] = 0; c_v[r_] = 0.0f;
+            if (i < n_c) { c_s[r_] = PS.itv_starts[lo_c + i]; c_e[r_] = PS.itv_ends[lo_c + i]; c_v[r_] = PS.itv_values[lo_c + i]; }
+        }
+#pragma unroll
+        for (int r_ = 0; r_ < PAINT_TILE / WAVE; ++r_) {
+            const int b = r_ * WAVE;
+            if (b >= n_c) break;
+            const int i = b + lane;
+            int sr = 0x7FFFFFFF, er = 0x7FFFFFFF;
+            if (i < n_c) {
+                i64 s64 = (i64)c_s[r_] - q_start - x_lo, e64 = (i64)c_e[r_] - q_start - x_lo;
+                s64 = s64 < -(1ll << 30) ? -(1ll << 30) : (s64 > (1ll << 30) ? (1ll << 30) : s64);
+                e64 = e64 < -(1ll << 30) ? -(1ll << 30) : (e64 > (1ll << 30) ? (1ll << 30) : e64);
+                sr = (int)s64; er = (int)e64;
+                Wn.ce[i] = er;
+                Wn.cv[i] = c_v[r_];
+            }
+            int pe = __shfl_up(er, 1, WAVE), ps = __shfl_up(sr, 1, WAVE);
+            if (lane == 0) { pe = carry_e; ps = carry_s; }
+            if (i < n_c && (sr < pe || sr == ps)) bad = true;
+            if (i < n_c && sr >= 0 && sr < wlen) atomicOr(&Wn.bm[sr >> 5], 1u << (sr & 31));
+            n_before += __builtin_popcountll(__builtin_amdgcn_ballot_w64(i < n_c && sr < 0));
+            const int last = (n_c - b > WAVE ? WAVE : n_c - b) - 1;
+            carry_e = rdl(er, last); carry_s = rdl(sr, last);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (__builtin_amdgcn_ballot_w64(bad) != 0) return;
+        {   // exclusive popcount prefix over the 128 words: lane owns words 2 lane, 2 lane + 1
+            const int c0 = __builtin_popcount(Wn.bm[2 * lane]), c1 = __builtin_popcount(Wn.bm[2 * lane + 1]);
+            const int incl = wave_scan_inclusive<OpAdd>(c0 + c1);
+            Wn.pre[2 * lane] = (u32)(incl - c0 - c1);
+            Wn.pre[2 * lane + 1] = (u32)(incl - c1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (PAINT) { S.x_lo = x_lo; S.wlen = wlen; S.base = n_before - 1; S.win_ok = !(A.dbg & 2097152); }
+    };
+
     for (;;) {
         while (!walk_done && nseg <= SEG_FLUSH) {
             bool stop = (vi >= n_var) || (out_idx >= hi_clip);
@@ -2930,6 +3107,13 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A) 
 
         const int cov = out_idx < lo_clip ? lo_clip : (out_idx > hi_clip ? hi_clip : out_idx);
         const int limit = walk_done ? hi_clip : (cov & ~3);
+        if (PAINT && !have_win && nseg > 0) {
+            // the first entry that reaches into the chunk says where its first value comes from
+            // (entry 0: the table only holds entries that reach into what is still to be emitted)
+            have_win = true;
+            const i64 pv = (i64)(((u64)(u32)rfl(M.phi[0]) << 32) | (u32)rfl(M.plo[0]));
+            build_window(rfl(M.kind[0]) == T_TRACK ? pv + emit_pos : pv);
+        }
         for (int p0 = emit_pos; p0 < limit; p0 += TRIP) {
             const int p = p0 + GROUP * lane;
             if (p < limit) {
@@ -2945,8 +3129,7 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A) 
                 const i64 pv0 = (i64)(((u64)(u32)M.phi[li] << 32) | (u32)M.plo[li]);
                 if (M.kind[li] == T_TRACK && p + GROUP <= nx && p + GROUP <= limit && pv0 + p >= 0 &&
                     pv0 + p + GROUP <= tlen) {
-                    const float *src = track + pv0 + p;
-                    v4[0] = src[0]; v4[1] = src[1]; v4[2] = src[2]; v4[3] = src[3];
+                    S.at4(pv0 + p, v4);
                 } else {
 #pragma unroll
                     for (int i = 0; i < GROUP; ++i) {
@@ -2956,9 +3139,9 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A) 
                             while (li + 1 < nseg && M.out[li + 1] <= pp) ++li;
                             const int kd = M.kind[li];
                             const i64 pv = (i64)(((u64)(u32)M.phi[li] << 32) | (u32)M.plo[li]);
-                            if (kd == T_TRACK) { const i64 x = pv + pp; v = (x >= 0 && x < tlen) ? track[x] : 0.0f; }
-                            else if (kd == T_REPEAT) { v = (pv >= 0 && pv < tlen) ? track[pv] : 0.0f; }
-                            else if (kd == T_FILL) { v = fill_value(A, track, tlen, pv, (i64)M.vlen[li], (i64)(pp - M.out[li]), (i64)pp, (u64)query, (u64)hap); }
+                            if (kd == T_TRACK) v = S.at(pv + pp);
+                            else if (kd == T_REPEAT) v = S.at(pv);
+                            else if (kd == T_FILL) v = fill_value(A, S, pv, (i64)M.vlen[li], (i64)(pp - M.out[li]), (i64)pp, (u64)query, (u64)hap);
                         }
                         v4[i] = v;
                     }
@@ -2997,8 +3180,6 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A) 
 // interval (in order) that covers the position -- what sequential painting leaves behind.
 // `pmax[c]` = max(ends[list start .. c]): a position no earlier interval reaches is 0.0 without
 // walking back over the whole list (gaps between intervals are the common case).
-constexpr int PAINT_TILE = 256;
-constexpr int PAINT_CHUNK = 2048;
 struct PaintTile { u32 idx[2 * WAVE]; float cv[PAINT_TILE]; int ce[PAINT_TILE]; };     // start bitmap + prefix, candidate values / ends
 struct PaintImage { u32 idx[PAINT_CHUNK]; float cv[PAINT_TILE]; };                      // the leftovers kernel's image of one chunk
 struct PaintTodo { int flag; int n_c; i64 lo_c; };      // per (query, chunk): 0 = done, 1 = per-value kernel, 2 = image (candidates [lo_c, lo_c + n_c))
@@ -3149,7 +3330,6 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_kernel(
 // the bucket's start, hi[] = first interval that starts at or after the bucket's end (both relative
 // to the list's first interval).  One lookup per chunk gives a SUPERSET of the chunk's candidates
 // (intervals outside the chunk clip to nothing), instead of two dependent 64-ary searches.
-struct PaintIndex { const i64 *offsets; const int *base; const int *lo; const int *hi; };
 
 __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
     const i64 *offset_idxs, const int *starts, i64 starts_stride, i64 n_queries, const int *itv_starts,
@@ -3529,6 +3709,8 @@ int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
 //        bytes (phases A and B as for a SNP-only row); no scan plan either
 // 65536  the lean kernel re-reads the runs of a row with indels from memory (never re-aligns the speculative window in LDS)
 // 1048576 rows longer than one chunk never take the lean kernel (LONG): the all-purpose kernel as before
+// 2097152 realignment from intervals never uses its window (every value looked up in the interval list itself)
+// 4194304 tracks are always painted into the scratch track first (no realignment straight from the intervals)
 // and 1 / 2 / 4 = timing ablations (no variants / no stores / no loads).
 int g_debug_override = -1;
 int debug_flags() {
@@ -4160,7 +4342,7 @@ int gvl_intervals_to_tracks(const int64_t *offset_idxs, const int32_t *starts, i
 
 static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const float *tracks,
                                const int64_t *track_offsets, const double *params, int64_t strategy_id,
-                               uint64_t base_seed, const u64 *seed_ptr, float *out, void *stream);
+                               uint64_t base_seed, const u64 *seed_ptr, float *out, void *stream, const PaintSrcArgs *ps = nullptr);
 int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *tracks,
                        const int64_t *track_offsets, const double *params, int64_t strategy_id,
                        uint64_t base_seed, float *out, void *stream) {
@@ -4168,12 +4350,12 @@ int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *t
 }
 static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const float *tracks,
                                const int64_t *track_offsets, const double *params, int64_t strategy_id,
-                               uint64_t base_seed, const u64 *seed_ptr, float *out, void *stream) {
+                               uint64_t base_seed, const u64 *seed_ptr, float *out, void *stream, const PaintSrcArgs *ps) {
     if (!st || !bt) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: NULL struct");
     if (bt->batch < 0 || bt->ploidy <= 0) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: bad batch/ploidy");
     if (bt->batch == 0) return GVL_OK;
     if (!bt->regions || !bt->shifts || !bt->geno_offset_idx || !bt->out_offsets || bt->regions_stride < 3 ||
-        !st->geno_o_starts || !st->geno_o_stops || !tracks || !track_offsets || !out || !params)
+        !st->geno_o_starts || !st->geno_o_stops || (!tracks && !ps) || !track_offsets || !out || !params)
         return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: NULL/invalid array");
     if (st->n_geno > 0 && (!st->geno_v_idxs || !st->v_starts || !st->ilens))
         return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: NULL variant table");
@@ -4195,7 +4377,8 @@ static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const 
     A.dbg = debug_flags();
     if (A.n_rows > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: batch too large");
     const i64 grid = (A.n_rows + 3) / 4;
-    realign_tracks_kernel<<<dim3((unsigned)grid, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream>>>(A);
+    if (ps) realign_tracks_kernel<true><<<dim3((unsigned)grid, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream>>>(A, *ps);
+    else realign_tracks_kernel<false><<<dim3((unsigned)grid, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream>>>(A, PaintSrcArgs());
     return check_launch("gvl_realign_tracks");
 }
 
@@ -4279,14 +4462,26 @@ static int tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const in
         PaintIndex X{nullptr, nullptr, nullptr, nullptr};
         if (T.bkt_offsets && T.bkt_base && T.bkt_lo && T.bkt_hi && !(debug_flags() & 1024))
             X = PaintIndex{(const i64 *)T.bkt_offsets, T.bkt_base, T.bkt_lo, T.bkt_hi};
+        // the track's own insertion fill (_reconstruct.py:204-208 lowers one per track) or the call's
+        const double t_par[1] = {T.has_fill ? T.fill_param : params[0]};
+        const int64_t t_strategy = T.has_fill ? (int64_t)T.fill_strategy : strategy_id;
+        // An interval set whose owner vouches for non-overlapping intervals (tile_complete) and that has its bucket
+        // index is realigned straight from the intervals: the scratch track is neither written nor read (SrcPainted;
+        // a window the claim does not hold for falls back to exact per-position lookups, it is never wrong).
+        const bool fused = T.tile_complete != 0 && X.offsets && T.itv_pmax_ends && !(debug_flags() & 4194304);
+        if (fused) {
+            PaintSrcArgs ps{(const i64 *)offset_idxs, T.list_div > 1 ? T.list_div : 1, T.itv_starts, T.itv_ends, T.itv_values,
+                            (const i64 *)T.itv_offsets, T.itv_pmax_ends, X};
+            rc = realign_tracks_impl(st, &rb, nullptr, (const int64_t *)track_offsets, T.has_fill ? t_par : params, t_strategy, base_seed,
+                                     seed_ptr, out + (i64)t * out_track_stride, stream, &ps);
+            if (rc) return rc;
+            continue;
+        }
         rc = paint_launch(offset_idxs, bt->regions + 1, bt->regions_stride, B, T.itv_starts, T.itv_ends, T.itv_values, T.itv_offsets,
                           T.itv_pmax_ends, scr, (const int64_t *)track_offsets, scratch_stride,
                           paint_can_tile(T.itv_pmax_ends, scratch_stride) ? todo : nullptr, s, X, T.tile_complete != 0,
                           T.list_div > 1 ? T.list_div : 1);
         if (rc) return rc;
-        // the track's own insertion fill (_reconstruct.py:204-208 lowers one per track) or the call's
-        const double t_par[1] = {T.has_fill ? T.fill_param : params[0]};
-        const int64_t t_strategy = T.has_fill ? (int64_t)T.fill_strategy : strategy_id;
         rc = realign_tracks_impl(st, &rb, scr, (const int64_t *)track_offsets, T.has_fill ? t_par : params, t_strategy, base_seed, seed_ptr,
                                  out + (i64)t * out_track_stride, stream);
         if (rc) return rc;

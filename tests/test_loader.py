@@ -322,7 +322,8 @@ def test_threaded_loader_matches_inline_loader_and_survives_abandoned_epochs(ora
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dbg", [0, 1024, 8, 8192], ids=["default", "painter-without-bucket-index", "scalar-walk", "painter-image-path"])
+@pytest.mark.parametrize("dbg", [0, 1024, 8, 8192, 2097152, 4194304],
+                         ids=["default", "painter-without-bucket-index", "scalar-walk", "painter-image-path", "intervals-without-window", "painter-first"])
 def test_haps_tracks_dataset_matches_oracle(oracle, dbg):
     """cfg4's dataset shape at a small size: haplotypes + two realigned tracks per batch from dataset
     indices, against the oracle's fused paint + realign for the same request."""
@@ -389,7 +390,8 @@ def test_haps_tracks_dataset_matches_oracle(oracle, dbg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dbg", [0, 1024, 8192], ids=["bucket-index", "exact-searches", "painter-image-path"])
+@pytest.mark.parametrize("dbg", [0, 1024, 8192, 2097152, 4194304],
+                         ids=["bucket-index", "exact-searches", "painter-image-path", "intervals-without-window", "painter-first"])
 def test_tracks_batch_long_rows_jitter_and_dense_lists(oracle, dbg):
     """gvl_tracks_batch on rows of many 2048-value chunks whose starts are not bucket aligned (jitter),
     with sparse, ordinary and very dense interval lists (a dense list overflows the painter's tile:
@@ -633,9 +635,10 @@ def test_loader_onehot_only_goes_through_the_lean_kernel(oracle):
 
 @pytest.mark.gpu
 def test_tracks_tile_complete_claim_is_checked():
-    """gvl_track_set.tile_complete lets the painter skip its second launch.  The dataset only sets it for interval sets
-    that qualify (no overlaps, distinct starts, <= 256 intervals per two adjacent buckets); a WRONG claim is reported
-    through gvl_async_error, not silently painted wrong."""
+    """gvl_track_set.tile_complete lets the tracks be realigned straight from the intervals (and the painter, where it
+    still runs, skip its second launch).  The dataset only sets it for interval sets that qualify (no overlaps, distinct
+    starts, <= 256 intervals per two adjacent buckets); a WRONG claim is never silently wrong: the realignment falls
+    back to exact per-position lookups, the painter reports it through gvl_async_error."""
     from genvarloader_amd import HapsDevice, _lib
     from genvarloader_amd.loader import DeviceHapsTracksDataset
 
@@ -665,14 +668,25 @@ def test_tracks_tile_complete_claim_is_checked():
     assert good._tile_complete == [True] and bad._tile_complete == [False]
     for _ in good.to_dataloader(batch_size=5):
         pass
-    for _ in bad.to_dataloader(batch_size=5):      # overlapping intervals, honestly declared: painted by the leftovers launch
-        pass
-    torch.cuda.synchronize()
+    honest = [b.tracks.cpu().numpy().copy() for b in bad.to_dataloader(batch_size=5)]      # overlapping intervals, honestly
+    torch.cuda.synchronize()                                                                # declared: the leftovers launch
     assert lib.gvl_async_error(1) == 0
     bad._track_sets[0].tile_complete = 1           # a wrong claim
-    with pytest.raises(ValueError, match="tile_complete"):
-        for _ in bad.to_dataloader(batch_size=5):
-            torch.cuda.synchronize()
+    # ... read by the realignment straight from the intervals: a window whose candidates overlap is not used, every
+    # value is looked up in the list itself -- slower, never wrong
+    claimed = [b.tracks.cpu().numpy().copy() for b in bad.to_dataloader(batch_size=5)]
+    assert lib.gvl_async_error(1) == 0
+    assert len(claimed) == len(honest)
+    for x, y in zip(claimed, honest):
+        np.testing.assert_array_equal(x, y)
+    # ... read by the painter (GVL_DBG 4194304: tracks painted into the scratch track first): reported
+    lib.gvl_set_debug_flags(4194304)
+    try:
+        with pytest.raises(ValueError, match="tile_complete"):
+            for _ in bad.to_dataloader(batch_size=5):
+                torch.cuda.synchronize()
+    finally:
+        lib.gvl_set_debug_flags(-1)
     lib.gvl_async_error(1)
 
 
