@@ -2600,6 +2600,7 @@ __global__ __launch_bounds__(256) void onehot_kernel(const u8 *in, i64 n, u8 *ou
 struct TrackArgs {
     const i64 *go_starts; const i64 *go_stops; const int *geno_v_idxs; const int *v_starts;
     const int *ilens; i64 n_variants;
+    const gvl_grec *grec;       // genotype-inline records (gvl_static.geno_rec; NULL: geno_v_idxs -> v_starts / ilens)
     const int *regions; i64 regions_stride; const int *shifts; const i64 *geno_offset_idx;
     const u8 *keep; const i64 *keep_offsets; const u8 *to_rc; const i64 *out_offsets;
     i64 n_rows; int ploidy; int ploidy_shift; int chunk_len;
@@ -2644,7 +2645,7 @@ struct PaintSrcArgs {                           // the interval set of one track
     const int *itv_starts; const int *itv_ends; const float *itv_values; const i64 *itv_offsets; const int *pmax;
     PaintIndex X;
 };
-struct PaintWin { u32 bm[PAINT_WIN / 32]; u32 pre[PAINT_WIN / 32]; float cv[PAINT_TILE]; int ce[PAINT_TILE]; };
+struct PaintWin { u32 bm[PAINT_WIN / 32 + 2]; u32 pre[PAINT_WIN / 32]; float cv[PAINT_TILE + 1]; int ce[PAINT_TILE + 1]; };   // (+ one zero word behind the bitmap, one slot behind the candidates)
 
 struct SrcGlobal {
     const float *track; i64 tlen;
@@ -2654,6 +2655,7 @@ struct SrcGlobal {
         const float *src = track + x;
         v[0] = src[0]; v[1] = src[1]; v[2] = src[2]; v[3] = src[3];
     }
+    __device__ __forceinline__ void at4i(const int x, float (&v)[4]) const { at4((i64)x, v); }
 };
 struct SrcPainted {
     const PaintWin *W; i64 x_lo; int wlen; int base; bool win_ok;
@@ -2681,32 +2683,44 @@ struct SrcPainted {
         if (win_ok && r >= 0 && r < wlen) return in_win((int)r);
         return in_list(x);
     }
+    // four consecutive positions (0 <= x, x + 4 <= tlen).  Inside the window: the word that holds x's bit and the one
+    // behind it as ONE 64-bit word (no special case for a group that straddles two words); a group with at most
+    // one interval start behind its first position (all but 1-2 bp intervals) is two candidates and a switch point,
+    // read without a branch.
     __device__ __forceinline__ void at4(const i64 x, float (&v)[4]) const {
         const i64 r64 = x - x_lo;
-        if (win_ok && r64 >= 0 && r64 + 4 <= wlen) {
-            const int r = (int)r64, bp = r & 31;
-            if (bp <= 28) {                                    // the four positions share a bitmap word
-                const u32 wd = W->bm[r >> 5];
-                const int pre = base + (int)W->pre[r >> 5];
-                const int i0 = pre + __builtin_popcount(wd & (0xFFFFFFFFu >> (31 - bp)));
-                const int i3 = pre + __builtin_popcount(wd & (0xFFFFFFFFu >> (28 - bp)));
-                if (i0 == i3) {
-                    const int e0_ = i0 >= 0 ? W->ce[i0] : 0;
-                    const float c0 = i0 >= 0 ? W->cv[i0] : 0.0f;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) v[g] = e0_ > r + g ? c0 : 0.0f;
-                } else {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int ig = pre + __builtin_popcount(wd & (0xFFFFFFFFu >> (31 - bp - g)));
-                        v[g] = (ig >= 0 && W->ce[ig] > r + g) ? W->cv[ig] : 0.0f;
-                    }
-                }
-                return;
-            }
-        }
+        if (win_ok && r64 >= 0 && r64 + 4 <= wlen) { win4((int)r64, v); return; }
 #pragma unroll
         for (int g = 0; g < 4; ++g) v[g] = at(x + g);
+    }
+    // (positions below 2^31 - 8: the caller has checked the row's table and track length)
+    __device__ __forceinline__ void at4i(const int x, float (&v)[4]) const {
+        const int r = x - (int)x_lo;
+        if (win_ok && r >= 0 && r + 4 <= wlen) { win4(r, v); return; }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] = at((i64)x + g);
+    }
+    __device__ __forceinline__ void win4(const int r, float (&v)[4]) const {
+        {
+            const int bp = r & 31, wi = r >> 5;
+            const u64 w = ((u64)W->bm[wi + 1] << 32) | W->bm[wi];
+            const int i0 = base + (int)W->pre[wi] + __builtin_popcountll(w & (~0ull >> (63 - bp)));
+            const u32 m3 = (u32)(w >> (bp + 1)) & 7u;         // starts at positions x + 1 .. x + 3
+            if (__builtin_popcount(m3) <= 1) {
+                const int t = m3 ? __builtin_ctz(m3) + 1 : 4;    // positions [t, 4) belong to candidate i0 + 1
+                const int ia = i0 < 0 ? PAINT_TILE : i0;         // (slot PAINT_TILE: "no candidate", end 0x80000000)
+                const int e_a = W->ce[ia], e_b = W->ce[i0 + 1];
+                const float c_a = W->cv[ia], c_b = W->cv[i0 + 1];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) v[g] = g < t ? (e_a > r + g ? c_a : 0.0f) : (e_b > r + g ? c_b : 0.0f);
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ig = base + (int)W->pre[wi] + __builtin_popcountll(w & (~0ull >> (63 - bp - g)));
+                    v[g] = (ig >= 0 && W->ce[ig] > r + g) ? W->cv[ig] : 0.0f;
+                }
+            }
+        }
     }
 };
 
@@ -2834,9 +2848,14 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
             int pos = 0, d = 0;
             bool valid = tb + lane < n_var;
             if (valid) {
-                int v = A.geno_v_idxs[o_s + tb + lane];
-                v = v < 0 ? 0 : ((i64)v >= A.n_variants ? (int)(A.n_variants - 1) : v);
-                pos = A.v_starts[v]; d = A.ilens[v];
+                if (A.grec) {           // position and length delta sit next to the CSR entry: one read, not three
+                    const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.grec + (o_s + tb + lane));
+                    pos = rec.x; d = rec.y;
+                } else {
+                    int v = A.geno_v_idxs[o_s + tb + lane];
+                    v = v < 0 ? 0 : ((i64)v >= A.n_variants ? (int)(A.n_variants - 1) : v);
+                    pos = A.v_starts[v]; d = A.ilens[v];
+                }
                 if (has_keep) valid = A.keep[keep_off + tb + lane] != 0;
             }
             const bool weird = valid && (pos <= -(1 << 30) || pos >= (1 << 30) || d <= -(1 << 30) || d >= (1 << 30));
@@ -2983,6 +3002,8 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
         if (hi_c - lo_c > PAINT_TILE) return;
         const int n_c = (int)(hi_c - lo_c);
         Wn.bm[lane] = 0u; Wn.bm[WAVE + lane] = 0u;
+        if (lane < 2) Wn.bm[2 * WAVE + lane] = 0u;
+        if (lane == 0) { Wn.ce[PAINT_TILE] = (int)0x80000000; Wn.cv[PAINT_TILE] = 0.0f; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -3042,9 +3063,14 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
                     vb = vi;
                     const int j = vb + lane;
                     if (j < n_var) {
-                        int v = A.geno_v_idxs[o_s + j];
-                        v = v < 0 ? 0 : ((i64)v >= A.n_variants ? (int)(A.n_variants - 1) : v);
-                        r_pos = A.v_starts[v]; r_ilen = A.ilens[v];
+                        if (A.grec) {
+                            const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.grec + (o_s + j));
+                            r_pos = rec.x; r_ilen = rec.y;
+                        } else {
+                            int v = A.geno_v_idxs[o_s + j];
+                            v = v < 0 ? 0 : ((i64)v >= A.n_variants ? (int)(A.n_variants - 1) : v);
+                            r_pos = A.v_starts[v]; r_ilen = A.ilens[v];
+                        }
                         r_keep = has_keep ? (int)A.keep[keep_off + j] : 1;
                     }
                 }
@@ -3114,15 +3140,51 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
             const i64 pv = (i64)(((u64)(u32)rfl(M.phi[0]) << 32) | (u32)rfl(M.plo[0]));
             build_window(rfl(M.kind[0]) == T_TRACK ? pv + emit_pos : pv);
         }
+        // a table of at most 4 entries (a chunk with one indel: run | fill | run) keeps its starts on the scalar side
+        const bool small_tab = nseg <= 4;
+        const int so1 = (small_tab && nseg > 1) ? rfl(M.out[1]) : 0x7FFFFFFF;
+        const int so2 = (small_tab && nseg > 2) ? rfl(M.out[2]) : 0x7FFFFFFF;
+        const int so3 = (small_tab && nseg > 3) ? rfl(M.out[3]) : 0x7FFFFFFF;
+        // ... and so do their kinds and deltas when those fit 32 bits (the planned walk's always do): a trip that lies
+        // inside ONE track run -- all of them in a chunk without an indel -- needs no per-lane entry lookup
+        int sk[4], sp[4];
+        bool tab32 = small_tab && tlen < 0x7FFFFF00ll;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            sk[t] = T_ZERO; sp[t] = 0;
+            if (small_tab && t < nseg) {
+                sk[t] = rfl(M.kind[t]); sp[t] = rfl(M.plo[t]);
+                tab32 = tab32 && rfl(M.phi[t]) == (sp[t] >> 31);
+            }
+        }
         for (int p0 = emit_pos; p0 < limit; p0 += TRIP) {
+            if (tab32 && p0 + TRIP <= limit) {
+                const int fli = (p0 >= so1 ? 1 : 0) + (p0 >= so2 ? 1 : 0) + (p0 >= so3 ? 1 : 0);
+                const int fnx = fli == 0 ? so1 : (fli == 1 ? so2 : (fli == 2 ? so3 : 0x7FFFFFFF));
+                const int fk = fli == 0 ? sk[0] : (fli == 1 ? sk[1] : (fli == 2 ? sk[2] : sk[3]));
+                const int fp = fli == 0 ? sp[0] : (fli == 1 ? sp[1] : (fli == 2 ? sp[2] : sp[3]));
+                const i64 xs = (i64)fp + p0;
+                if (fk == T_TRACK && p0 + TRIP <= (fnx < cov ? fnx : cov) && xs >= 0 && xs + TRIP <= tlen) {
+                    float v4[GROUP];
+                    const int p = p0 + GROUP * lane;
+                    S.at4i((int)xs + GROUP * lane, v4);
+                    if (!rc) store_f32x4(out_row + p, v4[0], v4[1], v4[2], v4[3]);
+                    else store_f32x4(out_row + (L - GROUP - p), v4[3], v4[2], v4[1], v4[0]);
+                    continue;
+                }
+            }
             const int p = p0 + GROUP * lane;
             if (p < limit) {
-                // segment holding p (binary search in the LDS mirror; nseg <= 64)
+                // segment holding p (three compares, or a binary search in the LDS mirror; nseg <= 64)
                 int li = 0;
+                if (small_tab) {
+                    li = (p >= so1 ? 1 : 0) + (p >= so2 ? 1 : 0) + (p >= so3 ? 1 : 0);
+                } else {
 #pragma unroll
-                for (int step = 32; step > 0; step >>= 1) {
-                    const int t = li + step;
-                    if (t < nseg && M.out[t] <= p) li = t;
+                    for (int step = 32; step > 0; step >>= 1) {
+                        const int t = li + step;
+                        if (t < nseg && M.out[t] <= p) li = t;
+                    }
                 }
                 const int nx = li + 1 < nseg ? M.out[li + 1] : cov;
                 float v4[GROUP];
@@ -4365,6 +4427,7 @@ static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const 
     memset(&A, 0, sizeof(A));
     A.go_starts = (const i64 *)st->geno_o_starts; A.go_stops = (const i64 *)st->geno_o_stops;
     A.geno_v_idxs = st->geno_v_idxs; A.v_starts = st->v_starts; A.ilens = st->ilens; A.n_variants = st->n_variants;
+    A.grec = (debug_flags() & 16) ? nullptr : st->geno_rec;
     A.regions = bt->regions; A.regions_stride = bt->regions_stride; A.shifts = bt->shifts;
     A.geno_offset_idx = (const i64 *)bt->geno_offset_idx; A.keep = bt->keep; A.keep_offsets = (const i64 *)bt->keep_offsets;
     A.to_rc = bt->to_rc; A.out_offsets = (const i64 *)bt->out_offsets;

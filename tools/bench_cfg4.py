@@ -179,6 +179,18 @@ def main(args) -> None:
     lean_long = dev.ref4 is not None and dev.geno_rec is not None and not (dbg & (16384 | 1048576 | 16))
     kernel_name = ("recon_lean_kernel<onehot, haps, long> (one wave per 2048-base chunk)" if lean_long
                    else "reconstruct_kernel<OH_LC, haps=true, annot=false>")
+    # the track half as the step runs it: gvl_tracks_batch = scratch sizing (two small kernels; once per EPOCH in the native
+    # loop) + per track either the realignment straight from the intervals (tile_complete sets) or paint + realign
+    fused = all(ds._tile_complete) and not (dbg & 4194304)
+    n_scr = int(lib.gvl_tracks_scratch_bytes(C.c_int64(bs), C.c_int64(P), C.c_int64(ds._stride)))
+    arena = torch.empty(((4 * K * L + 255) & ~255) + n_scr, dtype=torch.uint8, device="cuda")
+    from genvarloader_amd._lib import GvlBatch
+    gbt = GvlBatch(regions=reg.data_ptr(), regions_stride=4, shifts=sh.data_ptr(), geno_offset_idx=goi.data_ptr(), batch=bs, ploidy=P,
+                   keep=None, keep_offsets=None, to_rc=None if rc is None else rc.data_ptr(), output_length=L, out_offsets=None, max_row_len=L)
+    t_tracks = timeit(lambda: _lib.check(lib.gvl_tracks_batch(
+        C.byref(dev.c), C.byref(gbt), C.c_void_p(idx0.data_ptr()), ds._track_sets, C.c_int32(1), par, C.c_int64(0), C.c_uint64(0),
+        C.c_void_p(arena.data_ptr()), C.c_int64(K * L), C.c_void_p(arena.data_ptr() + ((4 * K * L + 255) & ~255)), C.c_int64(ds._stride),
+        gdev._stream_ptr())))
     if rank == 0:
         hap_bytes = (L * 6 + 28.0 * mean_v + 61.0) * K
         realign_bytes = 4.0 * float(toff[-1]) + 4.0 * K * L
@@ -206,7 +218,11 @@ def main(args) -> None:
                                           "frac": realign_bytes / (t_realign * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "intervals_to_tracks (tiled + per-value)": {"ms": t_paint, "algorithmic_bytes": paint_bytes,
                                                             "frac": paint_bytes / (t_paint * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                "sum_of_kernels_ms": t_recon + t_realign + t_paint},
+                "gvl_tracks_batch (scratch sizing + " + ("realignment straight from the intervals" if fused else "paint + realign") + ")": {
+                    "ms": t_tracks, "algorithmic_bytes": realign_bytes + (0.0 if fused else paint_bytes),
+                    "frac": (realign_bytes + (0.0 if fused else paint_bytes)) / (t_tracks * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "tracks_path": "realign_tracks_kernel<PAINT> (no scratch track)" if fused else "intervals_to_tracks_tiled_kernel + realign_tracks_kernel",
+                "sum_of_kernels_ms": t_recon + (t_tracks if fused else t_realign + t_paint)},
         }
         print(json.dumps(res), flush=True)
     if dist is not None:

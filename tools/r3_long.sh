@@ -14,7 +14,7 @@ import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); r = d['roofline']
-        print('step us', round(d['ms_per_step']*1e3, 2), 'kernel', r['kernel'], 'us', round(r['kernel_ms']*1e3, 2), 'frac', round(r['frac'], 3), {k: round(v['ms']*1e3, 2) for k, v in d['kernels'].items() if isinstance(v, dict)})
+        print('step us', round(d['ms_per_step']*1e3, 2), 'kernel', r['kernel'], 'us', round(r['kernel_ms']*1e3, 2), 'frac', round(r['frac'], 3), {k[:40]: round(v["ms"]*1e3, 2) for k, v in d["kernels"].items() if isinstance(v, dict)})
     else: print(l.rstrip()[:300])
 " | tee -a $O
 done
