@@ -2645,7 +2645,7 @@ struct PaintSrcArgs {                           // the interval set of one track
     const int *itv_starts; const int *itv_ends; const float *itv_values; const i64 *itv_offsets; const int *pmax;
     PaintIndex X;
 };
-struct PaintWin { u32 bm[PAINT_WIN / 32 + 2]; u32 pre[PAINT_WIN / 32]; float cv[PAINT_TILE + 1]; int ce[PAINT_TILE + 1]; };   // (+ one zero word behind the bitmap, one slot behind the candidates)
+struct PaintWin { u32 bm[PAINT_WIN / 32 + 2]; u32 pre[PAINT_WIN / 32]; float cv[PAINT_TILE + 2]; int ce[PAINT_TILE + 2]; };   // (+ zero words behind the bitmap, slots behind the candidates)
 
 struct SrcGlobal {
     const float *track; i64 tlen;
@@ -2656,27 +2656,47 @@ struct SrcGlobal {
         v[0] = src[0]; v[1] = src[1]; v[2] = src[2]; v[3] = src[3];
     }
     __device__ __forceinline__ void at4i(const int x, float (&v)[4]) const { at4((i64)x, v); }
+    __device__ __forceinline__ void at8i(const int x, float (&v)[8]) const {
+        const float *src = track + x;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) v[g] = src[g];
+    }
 };
+// One position looked up in the query's interval list itself (intervals.rs:19-126 for one position): binary search for the
+// last start at or in front of it, then back under the running maximum of ends.  A real call, and the list's arrays
+// are re-read from the kernel's arguments (`ps_kernarg` = where PaintSrcArgs sits in the kernarg segment): this is
+// the rare path, and inlined it kept eight more pointers alive on the scalar side through the whole emit loop (the
+// kernel spills scalars into vector lanes as it is: every such value costs a v_readlane where it is used).
+typedef const PaintSrcArgs __attribute__((address_space(4))) *PaintSrcArgsK;
+__device__ __noinline__ float paint_list_value(const u64 ps_kernarg, const i64 idx, const i64 qs, const i64 j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const PaintSrcArgsK ps = (PaintSrcArgsK)(u64)rfl64((i64)ps_kernarg);
+    const int *itv_starts = ps->itv_starts, *itv_ends = ps->itv_ends, *pmax = ps->pmax;
+    const float *itv_values = ps->itv_values;
+    const i64 li = rfl64(idx);
+    const i64 s0 = ps->itv_offsets[li], e0 = ps->itv_offsets[li + 1];
+    i64 lo = s0, hi = e0;                                      // first interval with start - qs > j
+    while (lo < hi) {
+        const i64 mid = (lo + hi) >> 1;
+        if ((i64)itv_starts[mid] - qs <= j) lo = mid + 1; else hi = mid;
+    }
+    if (lo > s0 && (i64)pmax[lo - 1] - qs > j)
+        for (i64 c = lo - 1; c >= s0; --c)
+            if ((i64)itv_ends[c] - qs > j) return itv_values[c];
+#endif
+    return 0.0f;
+}
+
 struct SrcPainted {
     const PaintWin *W; i64 x_lo; int wlen; int base; bool win_ok;
-    i64 tlen, qs, s0, e0;
-    const int *itv_starts; const int *itv_ends; const float *itv_values; const int *pmax;
+    i64 tlen, qs, idx;
+    u64 ps_kernarg;
     __device__ __forceinline__ float in_win(const int r) const {
         const u32 wd = W->bm[r >> 5];
         const int ig = base + (int)W->pre[r >> 5] + __builtin_popcount(wd & (0xFFFFFFFFu >> (31 - (r & 31))));
         return (ig >= 0 && W->ce[ig] > r) ? W->cv[ig] : 0.0f;
     }
-    __device__ float in_list(const i64 j) const {           // (intervals.rs:19-126 for one position)
-        i64 lo = s0, hi = e0;                                  // first interval with start - qs > j
-        while (lo < hi) {
-            const i64 mid = (lo + hi) >> 1;
-            if ((i64)itv_starts[mid] - qs <= j) lo = mid + 1; else hi = mid;
-        }
-        if (lo > s0 && (i64)pmax[lo - 1] - qs > j)
-            for (i64 c = lo - 1; c >= s0; --c)
-                if ((i64)itv_ends[c] - qs > j) return itv_values[c];
-        return 0.0f;
-    }
+    __device__ __forceinline__ float in_list(const i64 j) const { return paint_list_value(ps_kernarg, idx, qs, j); }
     __device__ __forceinline__ float at(const i64 x) const {
         if (x < 0 || x >= tlen) return 0.0f;
         const i64 r = x - x_lo;
@@ -2699,6 +2719,40 @@ struct SrcPainted {
         if (win_ok && r >= 0 && r + 4 <= wlen) { win4(r, v); return; }
 #pragma unroll
         for (int g = 0; g < 4; ++g) v[g] = at((i64)x + g);
+    }
+    // eight consecutive positions: up to two interval starts behind the first position = three candidates and two
+    // switch points, still without a branch (intervals of 1-3 bases in a row take the per-position form)
+    __device__ __forceinline__ void at8i(const int x, float (&v)[8]) const {
+        const int r = x - (int)x_lo;
+        if (win_ok && r >= 0 && r + 8 <= wlen) {
+            const int bp = r & 31, wi = r >> 5;
+            const u64 w = ((u64)W->bm[wi + 1] << 32) | W->bm[wi];
+            const int pre = base + (int)W->pre[wi];
+            const int i0 = pre + __builtin_popcountll(w & (~0ull >> (63 - bp)));
+            const u32 m7 = (u32)(w >> (bp + 1)) & 0x7Fu;      // starts at positions x + 1 .. x + 7
+            if (__builtin_popcount(m7) <= 2) {
+                const u32 m7b = m7 & (m7 - 1u);
+                const int t1 = m7 ? __builtin_ctz(m7) + 1 : 8, t2 = m7b ? __builtin_ctz(m7b) + 1 : 8;
+                const int ia = i0 < 0 ? PAINT_TILE : i0;         // (slot PAINT_TILE: "no candidate", end 0x80000000)
+                const int e_a = W->ce[ia], e_b = W->ce[i0 + 1], e_c = W->ce[i0 + 2];
+                const float c_a = W->cv[ia], c_b = W->cv[i0 + 1], c_c = W->cv[i0 + 2];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const int e = g < t1 ? e_a : (g < t2 ? e_b : e_c);
+                    const float c = g < t1 ? c_a : (g < t2 ? c_b : c_c);
+                    v[g] = e > r + g ? c : 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const int ig = pre + __builtin_popcountll(w & (~0ull >> (63 - bp - g)));
+                    v[g] = (ig >= 0 && W->ce[ig] > r + g) ? W->cv[ig] : 0.0f;
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) v[g] = at((i64)x + g);
     }
     __device__ __forceinline__ void win4(const int r, float (&v)[4]) const {
         {
@@ -2973,9 +3027,8 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
     if constexpr (PAINT) {
         const i64 idx = rfl64(PS.offset_idxs[query]) / PS.list_div;
         S.W = &wins[wave]; S.x_lo = 0; S.wlen = 0; S.base = -1; S.win_ok = false;
-        S.tlen = tlen; S.qs = q_start;
-        S.s0 = rfl64(PS.itv_offsets[idx]); S.e0 = rfl64(PS.itv_offsets[idx + 1]);
-        S.itv_starts = PS.itv_starts; S.itv_ends = PS.itv_ends; S.itv_values = PS.itv_values; S.pmax = PS.pmax;
+        S.tlen = tlen; S.qs = q_start; S.idx = idx;
+        S.ps_kernarg = (u64)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(TrackArgs);
     } else {
         S.track = track; S.tlen = tlen;
     }
@@ -3010,29 +3063,43 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
         bool bad = false;
         int n_before = 0;
         int carry_e = (int)0x80000000, carry_s = (int)0x80000000;          // end / start of the candidate in front
+        // (all candidate records are requested before the first one is used: one memory round trip; rounds the
+        // window has no candidates for are skipped as a whole)
         int c_s[PAINT_TILE / WAVE], c_e[PAINT_TILE / WAVE]; float c_v[PAINT_TILE / WAVE];
 #pragma unroll
         for (int r_ = 0; r_ < PAINT_TILE / WAVE; ++r_) {
             const int i = r_ * WAVE + lane;
             c_s[r_] = 0; c_e[r_] = 0; c_v[r_] = 0.0f;
-            if (i < n_c) { c_s[r_] = PS.itv_starts[lo_c + i]; c_e[r_] = PS.itv_ends[lo_c + i]; c_v[r_] = PS.itv_values[lo_c + i]; }
+            if (r_ * WAVE < n_c) {
+                if (i < n_c) { c_s[r_] = PS.itv_starts[lo_c + i]; c_e[r_] = PS.itv_ends[lo_c + i]; c_v[r_] = PS.itv_values[lo_c + i]; }
+            }
         }
+        const i64 qx64 = q_start + x_lo;             // the window's first position on the reference
+        const bool qx_small = qx64 > -(1ll << 30) && qx64 < (1ll << 30);
+        const int qx = (int)qx64;
 #pragma unroll
         for (int r_ = 0; r_ < PAINT_TILE / WAVE; ++r_) {
             const int b = r_ * WAVE;
             if (b >= n_c) break;
             const int i = b + lane;
             int sr = 0x7FFFFFFF, er = 0x7FFFFFFF;
+            // starts / ends relative to the window: 32-bit arithmetic when nothing can overflow it (always, for real
+            // coordinates), else 64-bit and clamped
+            const bool small = qx_small && __builtin_amdgcn_ballot_w64(i < n_c && (c_s[r_] <= -(1 << 30) || c_s[r_] >= (1 << 30) ||
+                                                                                  c_e[r_] <= -(1 << 30) || c_e[r_] >= (1 << 30))) == 0;
             if (i < n_c) {
-                i64 s64 = (i64)c_s[r_] - q_start - x_lo, e64 = (i64)c_e[r_] - q_start - x_lo;
-                s64 = s64 < -(1ll << 30) ? -(1ll << 30) : (s64 > (1ll << 30) ? (1ll << 30) : s64);
-                e64 = e64 < -(1ll << 30) ? -(1ll << 30) : (e64 > (1ll << 30) ? (1ll << 30) : e64);
-                sr = (int)s64; er = (int)e64;
+                if (small) {
+                    sr = c_s[r_] - qx; er = c_e[r_] - qx;
+                } else {
+                    i64 s64 = (i64)c_s[r_] - qx64, e64 = (i64)c_e[r_] - qx64;
+                    s64 = s64 < -(1ll << 30) ? -(1ll << 30) : (s64 > (1ll << 30) ? (1ll << 30) : s64);
+                    e64 = e64 < -(1ll << 30) ? -(1ll << 30) : (e64 > (1ll << 30) ? (1ll << 30) : e64);
+                    sr = (int)s64; er = (int)e64;
+                }
                 Wn.ce[i] = er;
                 Wn.cv[i] = c_v[r_];
             }
-            int pe = __shfl_up(er, 1, WAVE), ps = __shfl_up(sr, 1, WAVE);
-            if (lane == 0) { pe = carry_e; ps = carry_s; }
+            const int pe = dpp_mov<0x138, 0xf>(carry_e, er), ps = dpp_mov<0x138, 0xf>(carry_s, sr);    // wave_shr:1 (lane 0: the round before)
             if (i < n_c && (sr < pe || sr == ps)) bad = true;
             if (i < n_c && sr >= 0 && sr < wlen) atomicOr(&Wn.bm[sr >> 5], 1u << (sr & 31));
             n_before += __builtin_popcountll(__builtin_amdgcn_ballot_w64(i < n_c && sr < 0));
@@ -3133,6 +3200,7 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
 
         const int cov = out_idx < lo_clip ? lo_clip : (out_idx > hi_clip ? hi_clip : out_idx);
         const int limit = walk_done ? hi_clip : (cov & ~3);
+        if (A.dbg & 8388608) return;              // (timing ablation: head + walk only)
         if (PAINT && !have_win && nseg > 0) {
             // the first entry that reaches into the chunk says where its first value comes from
             // (entry 0: the table only holds entries that reach into what is still to be emitted)
@@ -3157,9 +3225,31 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
                 tab32 = tab32 && rfl(M.phi[t]) == (sp[t] >> 31);
             }
         }
+        if (A.dbg & 16777216) return;             // (timing ablation: ... + the window)
         for (int p0 = emit_pos; p0 < limit; p0 += TRIP) {
             if (tab32 && p0 + TRIP <= limit) {
                 const int fli = (p0 >= so1 ? 1 : 0) + (p0 >= so2 ? 1 : 0) + (p0 >= so3 ? 1 : 0);
+                {   // two trips at once, eight values per lane, when the run reaches that far (half the lookups per value)
+                    const int fnx2 = fli == 0 ? so1 : (fli == 1 ? so2 : (fli == 2 ? so3 : 0x7FFFFFFF));
+                    const int fk2 = fli == 0 ? sk[0] : (fli == 1 ? sk[1] : (fli == 2 ? sk[2] : sk[3]));
+                    const int fp2 = fli == 0 ? sp[0] : (fli == 1 ? sp[1] : (fli == 2 ? sp[2] : sp[3]));
+                    const i64 xs2 = (i64)fp2 + p0;
+                    if (fk2 == T_TRACK && p0 + 2 * TRIP <= limit && p0 + 2 * TRIP <= (fnx2 < cov ? fnx2 : cov) && xs2 >= 0 &&
+                        xs2 + 2 * TRIP <= tlen) {
+                        float v8[2 * GROUP];
+                        const int p = p0 + 2 * GROUP * lane;
+                        S.at8i((int)xs2 + 2 * GROUP * lane, v8);
+                        if (!rc) {
+                            store_f32x4(out_row + p, v8[0], v8[1], v8[2], v8[3]);
+                            store_f32x4(out_row + p + GROUP, v8[4], v8[5], v8[6], v8[7]);
+                        } else {
+                            store_f32x4(out_row + (L - 2 * GROUP - p), v8[7], v8[6], v8[5], v8[4]);
+                            store_f32x4(out_row + (L - GROUP - p), v8[3], v8[2], v8[1], v8[0]);
+                        }
+                        p0 += TRIP;                   // (the loop adds the other one)
+                        continue;
+                    }
+                }
                 const int fnx = fli == 0 ? so1 : (fli == 1 ? so2 : (fli == 2 ? so3 : 0x7FFFFFFF));
                 const int fk = fli == 0 ? sk[0] : (fli == 1 ? sk[1] : (fli == 2 ? sk[2] : sk[3]));
                 const int fp = fli == 0 ? sp[0] : (fli == 1 ? sp[1] : (fli == 2 ? sp[2] : sp[3]));
@@ -3773,6 +3863,7 @@ int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
 // 1048576 rows longer than one chunk never take the lean kernel (LONG): the all-purpose kernel as before
 // 2097152 realignment from intervals never uses its window (every value looked up in the interval list itself)
 // 4194304 tracks are always painted into the scratch track first (no realignment straight from the intervals)
+// 8388608 / 16777216  timing ablations of realign_tracks_kernel (NO output): stop behind the walk / behind the window build
 // and 1 / 2 / 4 = timing ablations (no variants / no stores / no loads).
 int g_debug_override = -1;
 int debug_flags() {
