@@ -4133,7 +4133,8 @@ static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_o
         if (n_rows <= 0 || n_rows * chunks > 0x7FFFFFF0ll) return false;                  // (wave indices are ints in the kernel)
     }
     if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;     // u32 positions in the kernel
-    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576)) == 0;
+    // (2097152 ... 16777216 concern the track kernels only)
+    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216)) == 0;
 }
 
 static int launch_lean(const ReconArgs &RA, int chunks, void *stream) {

@@ -34,7 +34,9 @@ def timeit(fn, n=30):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-def inflight(which, n=60):
+def inflight(which, n=60, warm=True):
+    if warm:
+        inflight(which, 6, False)
     torch.cuda.synchronize()
     e0 = [torch.cuda.Event(enable_timing=True) for _ in streams]; e1 = [torch.cuda.Event(enable_timing=True) for _ in streams]
     for s, a in zip(streams, e0):
@@ -51,5 +53,5 @@ for flags in [int(x) for x in sys.argv[1:]] or [0]:
     lib.gvl_set_debug_flags(flags)
     t_both = timeit(lambda i: dev.launch(slots[i % 3][0], slots[i % 3][1][1]))
     t_oh = timeit(lambda i: dev.launch(slots[i % 3][0], slots[i % 3][2][1]))
-    print(f"GVL_DBG={flags}: one-hot + bytes {t_both:.2f} us alone ({hap_bytes / t_both / 1e6 / 8000:.3f} of 8 TB/s), {inflight(1):.2f} us with 3 streams;"
+    print(f"GVL_DBG={flags}: one-hot + bytes {t_both:.2f} us alone ({hap_bytes / (t_both * 1e-6) / 1e9 / 8000:.3f} of 8 TB/s), {inflight(1):.2f} us with 3 streams;"
           f"  one-hot only {t_oh:.2f} us alone, {inflight(2):.2f} with 3 streams", flush=True)

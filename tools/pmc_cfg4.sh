@@ -19,7 +19,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f[0])):
         acc[r["Kernel_Name"][:70]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
-        if any(x in k for x in ("reconstruct_kernel", "realign", "intervals_to_tracks", "track_lengths")):
+        if any(x in k for x in ("reconstruct_kernel", "recon_lean", "realign", "intervals_to_tracks", "track_lengths")):
             v = sorted(v)
             print(f"{c:11s} {k:70s} n={len(v):4d} median={v[len(v)//2]:12.1f} KB")
 PY

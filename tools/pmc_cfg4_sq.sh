@@ -14,8 +14,9 @@ for d in ("a", "b"):
     if not f: print(d, "no file"); continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
-        acc[(r["Kernel_Name"][:50], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        acc[(r["Kernel_Name"][:64], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in sorted(acc.items()):
-        if any(x in k for x in ("reconstruct_kernel", "realign", "intervals_to_tracks_tiled")):
-            v = sorted(v); print(f"{k:50s} {c:24s} n={len(v):3d} median={v[len(v)//2]:14.1f}")
+        if any(x in k for x in ("reconstruct_kernel", "recon_lean", "realign", "intervals_to_tracks_tiled")):
+            v = sorted(v); print(f"{k:64s} {c:24s} n={len(v):3d} median={v[len(v)//2]:14.1f}")
 PY
+rm -rf $T
