@@ -4148,7 +4148,13 @@ static int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
     A.n_rows = (int)RA.n_rows; A.n_contigs = RA.n_contigs; A.regions_stride = (int)RA.regions_stride;
     A.ploidy_shift = RA.ploidy_shift; A.ploidy = RA.ploidy; A.L = (int)RA.fixed_len; A.dbg = RA.dbg;
     A.chunks = chunks;
-    const unsigned grid = (unsigned)(((i64)A.n_rows * chunks + LEAN_WAVES - 1) / LEAN_WAVES);
+    // rows of several chunks: a wave takes `sub` consecutive chunks, the second and later ones resume the first one's walk.
+    // 2 by default -- BASELINE config 4's 256 rows x 64 chunks are then 8 192 waves, every wave slot of the part once;
+    // GVL_LEAN_SUB overrides (1 = every chunk its own wave and its own walk)
+    static const int sub_env = [] { const char *e = getenv("GVL_LEAN_SUB"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
+    A.sub = chunks > 1 ? (sub_env > 0 ? sub_env : 2) : 1;
+    const i64 per_row = (chunks + A.sub - 1) / A.sub;
+    const unsigned grid = (unsigned)(((i64)A.n_rows * per_row + LEAN_WAVES - 1) / LEAN_WAVES);
     const dim3 g(grid), b(LEAN_THREADS);
     hipStream_t s = (hipStream_t)stream;
     if (chunks > 1) {
