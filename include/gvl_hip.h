@@ -346,8 +346,12 @@ typedef struct gvl_track_set {
     int32_t tile_complete;        /* != 0: the caller vouches (checked once per interval set, see
                                      DeviceHapsTracksDataset) that inside every list starts strictly increase, no interval
                                      begins before its predecessor ends, and no two adjacent index buckets hold more than 256
-                                     intervals.  The painter then needs no second ("leftovers") launch; a chunk that would
-                                     have needed it is reported by gvl_async_error().  Needs the bucket index. */
+                                     intervals.  gvl_tracks_batch / the native loop then realign the track straight from the
+                                     intervals: no scratch track is written or read and the painter is not launched (a part of
+                                     a list the claim does not hold for is looked up interval by interval: slower, never wrong).
+                                     Where the painter still runs (GVL_DBG 4194304, gvl_intervals_to_tracks) it needs no second
+                                     ("leftovers") launch; a chunk that would have needed it is reported by gvl_async_error().
+                                     Needs the bucket index and itv_pmax_ends. */
     int32_t has_fill;             /* != 0: this track's own insertion fill (the reference lowers one per track,
                                      _reconstruct.py:204-208): fill_strategy / fill_param replace the call's strategy_id /
                                      params for this track.  0: the call's */
