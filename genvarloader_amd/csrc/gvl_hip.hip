@@ -2823,7 +2823,7 @@ __device__ float fill_value(const TrackArgs &A, const Src &S, i64 vrp, i64 v_len
 
 // PAINT: the track comes from the query's intervals (SrcPainted; A.tracks is not read), else from memory.
 template <bool PAINT>
-__global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, const PaintSrcArgs PS) {
+__global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, const PaintSrcArgs PS_) {
     __shared__ TrackMirror mirror[4];
     __shared__ PaintWin wins[PAINT ? 4 : 1];
     const int lane = threadIdx.x & (WAVE - 1);
@@ -3025,7 +3025,12 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
     typename std::conditional<PAINT, SrcPainted, SrcGlobal>::type S;
     bool have_win = false;
     if constexpr (PAINT) {
-        const i64 idx = rfl64(PS.offset_idxs[query]) / PS.list_div;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const PaintSrcArgsK PSk = (PaintSrcArgsK)((u64)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(TrackArgs));
+        const i64 idx = rfl64(PSk->offset_idxs[query]) / PSk->list_div;
+#else
+        const i64 idx = 0;
+#endif
         S.W = &wins[wave]; S.x_lo = 0; S.wlen = 0; S.base = -1; S.win_ok = false;
         S.tlen = tlen; S.qs = q_start; S.idx = idx;
         S.ps_kernarg = (u64)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(TrackArgs);
@@ -3039,18 +3044,25 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
         x_lo = x_lo < 0 ? 0 : x_lo;
         const i64 wl64 = tlen - x_lo;
         const int wlen = wl64 > PAINT_WIN ? PAINT_WIN : (wl64 < 0 ? 0 : (int)wl64);
-        const i64 idx = rfl64(PS.offset_idxs[query]) / PS.list_div;
-        const i64 s0 = rfl64(PS.itv_offsets[idx]), e0 = rfl64(PS.itv_offsets[idx + 1]);
-        if (wlen <= 0 || !PS.X.offsets || e0 <= s0) return;
-        const i64 b0 = rfl64(PS.X.offsets[idx]);
-        const i64 nb = rfl64(PS.X.offsets[idx + 1]) - b0;
+        // (the interval set's pointers are read from the kernel's arguments HERE, not held on the scalar side since the
+        // kernel's start: the walk in between needs every scalar register it can get)
+#if defined(__HIP_DEVICE_COMPILE__)
+        const PaintSrcArgsK PS = (PaintSrcArgsK)((u64)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(TrackArgs));
+#else
+        const PaintSrcArgs *const PS = &PS_;
+#endif
+        const i64 idx = rfl64(PS->offset_idxs[query]) / PS->list_div;
+        const i64 s0 = rfl64(PS->itv_offsets[idx]), e0 = rfl64(PS->itv_offsets[idx + 1]);
+        if (wlen <= 0 || !PS->X.offsets || e0 <= s0) return;
+        const i64 b0 = rfl64(PS->X.offsets[idx]);
+        const i64 nb = rfl64(PS->X.offsets[idx + 1]) - b0;
         if (nb <= 0) return;
-        const i64 bbase = rfl(PS.X.base[idx]);
+        const i64 bbase = rfl(PS->X.base[idx]);
         i64 ba = (q_start + x_lo - bbase) >> 11, bb = (q_start + x_lo + wlen - 1 - bbase) >> 11;
         ba = ba < 0 ? 0 : (ba > nb - 1 ? nb - 1 : ba);
         bb = bb < 0 ? 0 : (bb > nb - 1 ? nb - 1 : bb);
-        i64 lo_c = s0 + rfl(PS.X.lo[b0 + ba]);
-        const i64 hi_c = s0 + rfl(PS.X.hi[b0 + bb]);
+        i64 lo_c = s0 + rfl(PS->X.lo[b0 + ba]);
+        const i64 hi_c = s0 + rfl(PS->X.hi[b0 + bb]);
         if (lo_c > hi_c) lo_c = hi_c;
         if (hi_c - lo_c > PAINT_TILE) return;
         const int n_c = (int)(hi_c - lo_c);
@@ -3071,7 +3083,7 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
             const int i = r_ * WAVE + lane;
             c_s[r_] = 0; c_e[r_] = 0; c_v[r_] = 0.0f;
             if (r_ * WAVE < n_c) {
-                if (i < n_c) { c_s[r_] = PS.itv_starts[lo_c + i]; c_e[r_] = PS.itv_ends[lo_c + i]; c_v[r_] = PS.itv_values[lo_c + i]; }
+                if (i < n_c) { c_s[r_] = PS->itv_starts[lo_c + i]; c_e[r_] = PS->itv_ends[lo_c + i]; c_v[r_] = PS->itv_values[lo_c + i]; }
             }
         }
         const i64 qx64 = q_start + x_lo;             // the window's first position on the reference
