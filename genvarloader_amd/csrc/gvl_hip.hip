@@ -3238,7 +3238,35 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
             }
         }
         if (A.dbg & 16777216) return;             // (timing ablation: ... + the window)
-        for (int p0 = emit_pos; p0 < limit; p0 += TRIP) {
+        // the track run the round begins in (the whole chunk, where no indel falls into it): its double trips in a tight
+        // loop -- position and output pointer advance by a constant, nothing is selected per trip
+        int p_begin = emit_pos;
+        if (tab32 && sk[0] == T_TRACK) {
+            int run_end = so1 < cov ? so1 : cov;
+            run_end = run_end < limit ? run_end : limit;
+            const i64 xs0 = (i64)sp[0] + emit_pos;
+            const int n2 = (run_end - emit_pos) / (2 * TRIP);
+            if (n2 > 0 && xs0 >= 0 && xs0 + (i64)n2 * (2 * TRIP) <= tlen) {
+                int x = (int)xs0 + 2 * GROUP * lane;
+                float *o = rc ? out_row + (L - 2 * GROUP - (emit_pos + 2 * GROUP * lane)) : out_row + (emit_pos + 2 * GROUP * lane);
+                const int ostep = rc ? -2 * TRIP : 2 * TRIP;
+#pragma unroll 1
+                for (int i = 0; i < n2; ++i) {
+                    float v8[2 * GROUP];
+                    S.at8i(x, v8);
+                    if (!rc) {
+                        store_f32x4(o, v8[0], v8[1], v8[2], v8[3]);
+                        store_f32x4(o + GROUP, v8[4], v8[5], v8[6], v8[7]);
+                    } else {
+                        store_f32x4(o, v8[7], v8[6], v8[5], v8[4]);
+                        store_f32x4(o + GROUP, v8[3], v8[2], v8[1], v8[0]);
+                    }
+                    x += 2 * TRIP; o += ostep;
+                }
+                p_begin = emit_pos + n2 * (2 * TRIP);
+            }
+        }
+        for (int p0 = p_begin; p0 < limit; p0 += TRIP) {
             if (tab32 && p0 + TRIP <= limit) {
                 const int fli = (p0 >= so1 ? 1 : 0) + (p0 >= so2 ? 1 : 0) + (p0 >= so3 ? 1 : 0);
                 {   // two trips at once, eight values per lane, when the run reaches that far (half the lookups per value)
