@@ -2834,19 +2834,23 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
     const int chunk = blockIdx.y;
     const i64 query = A.ploidy_shift >= 0 ? (k >> A.ploidy_shift) : (i64)((u32)k / (u32)A.ploidy);
     const i64 hap = k - query * A.ploidy;
-    const i64 row_base = rfl64(A.out_offsets[k]);
-    const int L = (int)(rfl64(A.out_offsets[k + 1]) - row_base);
+    // the row's parameters are wave-uniform: scalar loads (through the constant address space, which is what makes the
+    // compiler pick s_load for a global array; as recon_lean_kernel reads its request entries)
+    typedef const int __attribute__((address_space(4))) *KInt;
+    typedef const i64 __attribute__((address_space(4))) *KI64;
+    const i64 row_base = ((KI64)(u64)A.out_offsets)[k];
+    const int L = (int)(((KI64)(u64)A.out_offsets)[k + 1] - row_base);
     const int lo_clip = chunk * A.chunk_len;
     if (lo_clip >= L) return;
     const int hi_clip = (L - lo_clip > A.chunk_len) ? lo_clip + A.chunk_len : L;
-    const i64 t_s = rfl64(A.track_offsets[query]);
-    const i64 tlen = rfl64(A.track_offsets[query + 1]) - t_s;
+    const i64 t_s = ((KI64)(u64)A.track_offsets)[query];
+    const i64 tlen = ((KI64)(u64)A.track_offsets)[query + 1] - t_s;
     const float *track = PAINT ? nullptr : A.tracks + t_s;
-    const i64 q_start = rfl(A.regions[query * A.regions_stride + 1]);
-    const i64 shift = rfl(A.shifts[k]);
-    const i64 o_idx = rfl64(A.geno_offset_idx[k]);
-    const i64 o_s = rfl64(A.go_starts[o_idx]);
-    const i64 nv64 = rfl64(A.go_stops[o_idx]) - o_s;
+    const i64 q_start = ((KInt)(u64)A.regions)[query * A.regions_stride + 1];
+    const i64 shift = ((KInt)(u64)A.shifts)[k];
+    const i64 o_idx = ((KI64)(u64)A.geno_offset_idx)[k];
+    const i64 o_s = ((KI64)(u64)A.go_starts)[o_idx];
+    const i64 nv64 = ((KI64)(u64)A.go_stops)[o_idx] - o_s;
     const int n_var = nv64 < 0 ? 0 : (nv64 > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)nv64);
     const bool has_keep = A.keep && A.keep_offsets;
     const i64 keep_off = has_keep ? rfl64(A.keep_offsets[k]) : 0;
