@@ -1,4 +1,5 @@
-"""Randomised parity sweep of the realignment straight from intervals (gvl_tracks_batch with gvl_track_set.tile_complete:
+"""tools/dbg_fused.py <seed0> <case> [flags...]: one case of tools/fuzz_fused_tracks.py down GVL_DBG paths.
+Randomised parity sweep of the realignment straight from intervals (gvl_tracks_batch with gvl_track_set.tile_complete:
 realign_tracks_kernel<PAINT>, SrcPainted) against the oracle's paint + realign: random interval lists -- gaps, touching,
 OVERLAPPING (the claim is then wrong: the window is rejected, values come from the list itself), dense lists (more than
 256 candidates per window), long intervals, lists that end inside the window -- rows of several chunks, all five
@@ -10,12 +11,11 @@ from genvarloader_amd import HapsDevice, synth
 from genvarloader_amd.loader import DeviceHapsTracksDataset
 from oracle import oracle
 
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 oracle.build()
-bad = 0
-t0 = time.time()
-for ci in range(n_cases):
+def run_case(seed0, ci, flags=0, verbose=False):
+    from genvarloader_amd import _lib
+    _lib.load().gvl_set_debug_flags(flags)
+    bad = 0
     rng = np.random.default_rng(seed0 * 104729 + ci)
     R, S, P = int(rng.integers(1, 4)), int(rng.integers(1, 4)), int(rng.choice([1, 2, 2, 3]))
     L = int(rng.choice([40, 256, 700, 2048, 2500, 4100, 6144, 9000]))
@@ -82,5 +82,24 @@ for ci in range(n_cases):
         w = np.nonzero(got.view(np.uint32) != exp.view(np.uint32))[0]
         print(f"MISMATCH case {ci} (seed {seed0}): mode {mode} honest {honest} L={L} P={P} n={n} strategy {strategy} first bad {w[:5]} of {len(w)} "
               f"(row {w[0] // L}, pos {w[0] % L}) got {got[w[0]]} exp {exp[w[0]]}", flush=True)
-print(f"{n_cases} fused-track cases, {bad} mismatches, {time.time()-t0:.1f} s")
-sys.exit(1 if bad else 0)
+        if verbose:
+            rows = sorted(set((w // L).tolist()))
+            print('   bad rows', rows[:8], 'positions', [(int(x // L), int(x % L)) for x in w[:12]], 'to_rc', None if to_rc is None else [bool(to_rc[r]) for r in rows[:8]])
+            r = int(w[0] // L); q = r // P
+            print('   region', regions[q], 'shift', shifts.ravel()[r], 'tlen', int(tlen[q]))
+            o = goi.ravel()[r]
+            vs = gv[go[0, o]:go[1, o]]
+            rel = st.v_starts[vs] - regions[q, 1]
+            print('   row variants (rel pos, ilen) near the end:', [(int(a_), int(b_)) for a_, b_ in zip(rel, st.ilens[vs]) if a_ > int(tlen[q]) - 400][:40])
+            print('   sum ilen', int(st.ilens[vs][(rel >= 0) & (rel < int(tlen[q]))].sum()))
+            trk = np.zeros(int(track_offsets[-1]), np.float32)
+            oracle.intervals_to_tracks(idx.cpu().numpy().astype(np.int64), regions[:, 1].copy(), a, e, v, io, trk, track_offsets)
+            tq = trk[track_offsets[q]:track_offsets[q + 1]]
+            print('   track tail', [(i_, float(tq[i_])) for i_ in range(len(tq) - 12, len(tq))])
+            print('   exp tail', exp.reshape(-1, L)[r, -20:], ' got tail', got.reshape(-1, L)[r, -20:])
+    return bad
+
+if __name__ == '__main__':
+    seed0, ci = int(sys.argv[1]), int(sys.argv[2])
+    for fl in [int(x) for x in sys.argv[3:]] or [0]:
+        print('GVL_DBG', fl, 'mismatch' if run_case(seed0, ci, fl, True) else 'ok')
