@@ -3539,11 +3539,14 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
     __shared__ int probe_s[WAVE], probe_p[WAVE];
     const i64 q = blockIdx.y;
     const i64 chunk = (i64)blockIdx.x * 4 + wave;
-    const i64 o0 = rfl64(out_offsets[q]);
-    const i64 length = rfl64(out_offsets[q + 1]) - o0;
-    const i64 idx = rfl64(offset_idxs[q]) / list_div;
-    const i64 s0 = rfl64(itv_offsets[idx]), e0 = rfl64(itv_offsets[idx + 1]);
-    const i64 qs = rfl(starts[q * starts_stride]);
+    // (per-query values: scalar loads through the constant address space, see realign_tracks_kernel)
+    typedef const int __attribute__((address_space(4))) *KInt;
+    typedef const i64 __attribute__((address_space(4))) *KI64;
+    const i64 o0 = ((KI64)(u64)out_offsets)[q];
+    const i64 length = ((KI64)(u64)out_offsets)[q + 1] - o0;
+    const i64 idx = ((KI64)(u64)offset_idxs)[q] / list_div;
+    const i64 s0 = ((KI64)(u64)itv_offsets)[idx], e0 = ((KI64)(u64)itv_offsets)[idx + 1];
+    const i64 qs = ((KInt)(u64)starts)[q * starts_stride];
     // the first round of both searches probes the same 64 strided entries of the query's list for
     // every chunk: wave 0 fetches them once for the block's 4 chunks
     if (!X.offsets && wave == 0 && e0 > s0) {
@@ -3563,15 +3566,15 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
     i64 hi_c = 0, lo_c = 0;
     bool indexed = false;
     if (X.offsets) {
-        const i64 b0 = rfl64(X.offsets[idx]);
-        const i64 nb = rfl64(X.offsets[idx + 1]) - b0;
+        const i64 b0 = ((KI64)(u64)X.offsets)[idx];
+        const i64 nb = ((KI64)(u64)X.offsets)[idx + 1] - b0;
         if (nb > 0) {
-            const i64 base = rfl(X.base[idx]);
+            const i64 base = ((KInt)(u64)X.base)[idx];
             i64 ba = (qs + j0 - base) >> 11, bb = (qs + j1 - 1 - base) >> 11;
             ba = ba < 0 ? 0 : (ba > nb - 1 ? nb - 1 : ba);
             bb = bb < 0 ? 0 : (bb > nb - 1 ? nb - 1 : bb);
-            lo_c = s0 + rfl(X.lo[b0 + ba]);
-            hi_c = s0 + rfl(X.hi[b0 + bb]);
+            lo_c = s0 + ((KInt)(u64)X.lo)[b0 + ba];
+            hi_c = s0 + ((KInt)(u64)X.hi)[b0 + bb];
             if (lo_c > hi_c) lo_c = hi_c;
             indexed = hi_c - lo_c <= PAINT_TILE;
         }
