@@ -14,9 +14,14 @@ CPU-runnable plumbing case.
 
 Inputs are COLD by default: the dataset is genome scale (``--scale hg38``: 3.09 Gbp reference,
 10 M variants, a sparse-genotype CSR + inline records > 1 GB, 8.4 M queries drawn across the
-whole genome) and every step takes the next of ``--rotate`` (default 64) distinct batches, so
-no step finds its reference windows, variant records or request arrays in L2 / Infinity Cache.
-``--scale small --rotate 1`` is round 1's cache-hot measurement (64 Mbp contig, one batch).
+whole genome) and every step takes the next of ``--rotate`` (default 256) distinct batches, so
+no step finds its reference windows, variant records or request arrays in L2 / Infinity Cache:
+256 batches touch 690 MB of windows + slot lines, 2.7 x the 256 MB Infinity Cache.  (Until the
+middle of round 3 the default was 64 = 172 MB, which FITS that cache: fine for round 2's kernel,
+which was not bound by its reads -- 64 / 256 / 1024 measured alike then -- but the lean kernel
+runs 8.1-8.4 us per batch at 256 and 6.3-6.6 at 64.  ``--rotate 64`` is kept as the
+"Infinity-Cache-warm" regime.)  ``--scale small --rotate 1`` is round 1's cache-hot measurement
+(64 Mbp contig, one batch).
 
 Timing.  After W warmup steps:
   * contract region: barrier + synchronize, EXACTLY K steps, synchronize + barrier, host clock
@@ -267,7 +272,8 @@ def main() -> None:
     ap.add_argument("--scale", default="hg38", choices=["hg38", "small"],
                     help="dataset size: hg38 = 3.09 Gbp / > 1 GB of genotype records (cold inputs); small = 64 Mbp")
     ap.add_argument("--out-slots", type=int, default=0, help="output buffers the steps rotate over (default: streams + 1 per batch of a launch)")
-    ap.add_argument("--rotate", type=int, default=64, help="distinct batches the steps cycle through (1 = cache-hot)")
+    ap.add_argument("--rotate", type=int, default=256,
+                    help="distinct batches the steps cycle through (256: 2.7 x the Infinity Cache; 64: fits it; 1 = cache-hot)")
     ap.add_argument("--queries", type=int, default=None, help="override the number of queries in the dataset")
     ap.add_argument("--haps", action="store_true", help="also materialise haplotype bytes (h=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -523,7 +529,12 @@ def main() -> None:
                 "genotype_entries": int(ds.geno_v_idxs.numel()), "dataset_queries": int(ds.n_queries),
                 "dataset_bytes": sizes, "inline_record_bytes": 0 if dev.geno_rec is None else int(dev.geno_rec.numel()) * 4,
                 "rotating_batches": n_rot,
-                "inputs": "cold (every step a different batch, dataset >> Infinity Cache)" if n_rot > 1 and args.scale == "hg38"
+                # what a rotation touches of the dataset: per window a slot line (128 B) and L / 2 packed reference bytes
+                "rotation_footprint_bytes": int(n_rot * K * (128 + L // 2 + 48)),
+                "inputs": ("cold (every step a different batch; the rotation touches more than the 256 MB Infinity Cache holds)"
+                           if n_rot * K * (128 + L // 2 + 48) > (320 << 20) else
+                           "Infinity-Cache-warm (every step a different batch, but the rotation's windows and slot lines fit the 256 MB cache)")
+                          if n_rot > 1 and args.scale == "hg38"
                           else ("rotating" if n_rot > 1 else "cache-hot (one batch re-launched)"),
                 "parallelism": f"world_size {world}: " + ("one batch split into contiguous query blocks" if args.strong
                                                           else "rows sharded over the ranks, one full batch per rank per step"),

@@ -4204,13 +4204,14 @@ static int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
     const unsigned grid = (unsigned)(((i64)A.n_rows * per_row + LEAN_WAVES - 1) / LEAN_WAVES);
     const dim3 g(grid), b(LEAN_THREADS);
     hipStream_t s = (hipStream_t)stream;
+    static const unsigned xl = [] { const char *e = getenv("GVL_LEAN_EXTRA_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
     if (chunks > 1) {
         if (A.onehot && A.haps) recon_lean_kernel<true, true, true><<<g, b, 0, s>>>(A, RA);
         else if (A.onehot) recon_lean_kernel<true, false, true><<<g, b, 0, s>>>(A, RA);
         else recon_lean_kernel<false, true, true><<<g, b, 0, s>>>(A, RA);
     } else {
-        if (A.onehot && A.haps) recon_lean_kernel<true, true, false><<<g, b, 0, s>>>(A, RA);
-        else if (A.onehot) recon_lean_kernel<true, false, false><<<g, b, 0, s>>>(A, RA);
+        if (A.onehot && A.haps) recon_lean_kernel<true, true, false><<<g, b, xl, s>>>(A, RA);
+        else if (A.onehot) recon_lean_kernel<true, false, false><<<g, b, xl, s>>>(A, RA);
         else recon_lean_kernel<false, true, false><<<g, b, 0, s>>>(A, RA);
     }
     return check_launch("gvl_reconstruct (lean)");

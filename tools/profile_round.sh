@@ -16,6 +16,9 @@ b default
 for i in 1 2 3; do b k20_$i --steps 20 --warmup 5 --no-cpu-baseline; b k2000_$i --steps 2000 --warmup 50 --no-cpu-baseline --sustained-s 0; done
 GVL_DBG=16384 b nolean --no-cpu-baseline --sustained-s 0
 b hot_small --scale small --rotate 1 --no-cpu-baseline --sustained-s 0
+b warm64 --rotate 64 --no-cpu-baseline --sustained-s 0
+b rotate1024 --rotate 1024 --no-cpu-baseline --sustained-s 0
+GVL_DBG=16384 b nolean_warm64 --rotate 64 --no-cpu-baseline --sustained-s 0
 b cfg2 --workload cfg2 --no-cpu-baseline --sustained-s 0
 b cfg3_haps --haps --no-cpu-baseline --sustained-s 0
 b cfg4 --workload cfg4 --steps 20 --warmup 3
