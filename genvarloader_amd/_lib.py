@@ -138,6 +138,25 @@ def lib_path() -> Path:
     return Path(os.environ.get("GVL_HIP_LIB", _HERE / LIB_NAME))
 
 
+def _check_fresh(p: Path) -> None:
+    """The in-tree library must have been built from the sources next to it (``__graft_entry__.build_hip`` leaves their
+    content hash in ``libgvl_hip.so.content``).  Only checked for the in-tree library with its sources present."""
+    import hashlib
+
+    if "GVL_HIP_LIB" in os.environ or os.environ.get("GVL_ALLOW_STALE_LIB"):
+        return
+    stamp = p.with_suffix(".so.content")
+    srcs = [_HERE / "csrc" / "gvl_hip.hip", _HERE / "csrc" / "gvl_lean.inc", _HERE.parent / "include" / "gvl_hip.h"]
+    if not stamp.exists() or not all(f.exists() for f in srcs):
+        return
+    h = hashlib.sha256()
+    for f in srcs:
+        h.update(f.read_bytes())
+    if stamp.read_text().strip() != h.hexdigest():
+        raise GvlError(f"{p} was not built from the sources next to it (csrc/gvl_hip.hip, csrc/gvl_lean.inc, include/gvl_hip.h changed "
+                       "since): run `python -c 'import __graft_entry__ as g; g.build()'` (GVL_ALLOW_STALE_LIB=1 overrides)")
+
+
 def load() -> C.CDLL:
     """Load the HIP library or raise -- never falls back to a CPU path."""
     global _LIB
@@ -156,6 +175,7 @@ def load() -> C.CDLL:
             f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  genvarloader_amd has no CPU fallback."
         )
+    _check_fresh(p)
     try:
         lib = C.CDLL(str(p))
     except OSError as e:  # pragma: no cover
