@@ -2838,23 +2838,44 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
     // compiler pick s_load for a global array; as recon_lean_kernel reads its request entries)
     typedef const int __attribute__((address_space(4))) *KInt;
     typedef const i64 __attribute__((address_space(4))) *KI64;
+    const i64 *oi_ptr = nullptr;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (PAINT) {       // (the pointer itself is a kernel argument: fetched with the others, not behind round 1)
+        oi_ptr = ((PaintSrcArgsK)((u64)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(TrackArgs)))->offset_idxs;
+        asm volatile("" :: "s"(oi_ptr), "s"(A.out_offsets), "s"(A.track_offsets), "s"(A.regions), "s"(A.shifts), "s"(A.geno_offset_idx));
+    }
+#endif
+    // Round 1: everything the row's number alone addresses, requested as a whole before any of it is used (written value
+    // by value, each load became a memory round trip of its own behind the branch in front of its first use).
     const i64 row_base = ((KI64)(u64)A.out_offsets)[k];
-    const int L = (int)(((KI64)(u64)A.out_offsets)[k + 1] - row_base);
-    const int lo_clip = chunk * A.chunk_len;
-    if (lo_clip >= L) return;
-    const int hi_clip = (L - lo_clip > A.chunk_len) ? lo_clip + A.chunk_len : L;
+    const i64 row_end = ((KI64)(u64)A.out_offsets)[k + 1];
     const i64 t_s = ((KI64)(u64)A.track_offsets)[query];
-    const i64 tlen = ((KI64)(u64)A.track_offsets)[query + 1] - t_s;
-    const float *track = PAINT ? nullptr : A.tracks + t_s;
+    const i64 t_e = ((KI64)(u64)A.track_offsets)[query + 1];
     const i64 q_start = ((KInt)(u64)A.regions)[query * A.regions_stride + 1];
     const i64 shift = ((KInt)(u64)A.shifts)[k];
     const i64 o_idx = ((KI64)(u64)A.geno_offset_idx)[k];
+    const bool has_keep = A.keep && A.keep_offsets;
+    const i64 keep_off = has_keep ? ((KI64)(u64)A.keep_offsets)[k] : 0;
+    // (to_rc is a byte array: the aligned word that holds the row's byte)
+    const u64 rc_addr = (u64)A.to_rc + (u64)k;
+    const int rc_word = A.to_rc ? ((KInt)(rc_addr & ~3ull))[0] : 0;
+    i64 idx_raw = 0;                        // (the interval list's number)
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (PAINT) idx_raw = ((KI64)(u64)oi_ptr)[query];
+    asm volatile("" :: "s"(row_base), "s"(row_end), "s"(t_s), "s"(t_e), "s"((int)q_start), "s"((int)shift), "s"(o_idx), "s"(keep_off),
+                 "s"(rc_word), "s"(idx_raw));
+#endif
+    // Round 2: the genotype list's bounds
     const i64 o_s = ((KI64)(u64)A.go_starts)[o_idx];
     const i64 nv64 = ((KI64)(u64)A.go_stops)[o_idx] - o_s;
+    const int L = (int)(row_end - row_base);
+    const int lo_clip = chunk * A.chunk_len;
+    if (lo_clip >= L) return;
+    const int hi_clip = (L - lo_clip > A.chunk_len) ? lo_clip + A.chunk_len : L;
+    const i64 tlen = t_e - t_s;
+    const float *track = PAINT ? nullptr : A.tracks + t_s;
     const int n_var = nv64 < 0 ? 0 : (nv64 > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)nv64);
-    const bool has_keep = A.keep && A.keep_offsets;
-    const i64 keep_off = has_keep ? rfl64(A.keep_offsets[k]) : 0;
-    const bool rc = A.to_rc ? (rfl((int)A.to_rc[k]) != 0) : false;
+    const bool rc = ((rc_word >> (8 * (int)(rc_addr & 3ull))) & 0xFF) != 0;
     float *out_row = A.out + row_base;
 
     int s_out = 0, s_kind = 0, s_plo = 0, s_phi = 0, s_vlen = 0;
@@ -2902,13 +2923,24 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
                 M.phi[q] = (int)(u32)((u64)pval >> 32); M.vlen[q] = vlen;
             }
         };
+        // (position and length delta sit next to the CSR entry, gvl_grec: one read, not three; a trip's records are
+        // requested a trip ahead)
+        int nxt_pos = 0, nxt_d = 0;
+        if (A.grec && lane < n_var) {
+            const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.grec + (o_s + lane));
+            nxt_pos = rec.x; nxt_d = rec.y;
+        }
         for (int tb = 0; tb < n_var && ok && !ended && !past_chunk; tb += WAVE) {
             int pos = 0, d = 0;
             bool valid = tb + lane < n_var;
+            const int rec_pos = nxt_pos, rec_d = nxt_d;
+            if (A.grec && tb + WAVE + lane < n_var) {
+                const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.grec + (o_s + tb + WAVE + lane));
+                nxt_pos = rec.x; nxt_d = rec.y;
+            }
             if (valid) {
-                if (A.grec) {           // position and length delta sit next to the CSR entry: one read, not three
-                    const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.grec + (o_s + tb + lane));
-                    pos = rec.x; d = rec.y;
+                if (A.grec) {
+                    pos = rec_pos; d = rec_d;
                 } else {
                     int v = A.geno_v_idxs[o_s + tb + lane];
                     v = v < 0 ? 0 : ((i64)v >= A.n_variants ? (int)(A.n_variants - 1) : v);
@@ -3031,7 +3063,8 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
     if constexpr (PAINT) {
 #if defined(__HIP_DEVICE_COMPILE__)
         const PaintSrcArgsK PSk = (PaintSrcArgsK)((u64)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(TrackArgs));
-        const i64 idx = rfl64(PSk->offset_idxs[query]) / PSk->list_div;
+        const i64 dv = PSk->list_div;
+        const i64 idx = dv == 1 ? idx_raw : rfl64(idx_raw / dv);
 #else
         const i64 idx = 0;
 #endif
@@ -3055,18 +3088,35 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
 #else
         const PaintSrcArgs *const PS = &PS_;
 #endif
-        const i64 idx = rfl64(PS->offset_idxs[query]) / PS->list_div;
-        const i64 s0 = rfl64(PS->itv_offsets[idx]), e0 = rfl64(PS->itv_offsets[idx + 1]);
+        i64 idx = 0;
+        if constexpr (PAINT) idx = S.idx;
+        // the list's bounds and its bucket index's: four lanes of ONE load (+ the index's first position), then both bucket
+        // bounds in one -- written value by value the compiler made each of them a memory round trip of its own, and the
+        // kernel's time is the length of a wave's chain of dependent round trips as much as its instruction count
+        // (measured: 59 us at 7 waves per SIMD, 67 at 4, 79 at 3)
+        int h_lo = 0, h_hi = 0, h_b = 0;
+        {
+            const i64 *const io = PS->itv_offsets, *const xo = PS->X.offsets;
+            const int *const xb = PS->X.base;
+            if (lane < 4 && (lane < 2 || xo)) {
+                const i64 h = lane < 2 ? io[idx + lane] : xo[idx + (lane - 2)];
+                h_lo = (int)(u32)(u64)h; h_hi = (int)(u32)((u64)h >> 32);
+            }
+            if (lane == 0 && xb) h_b = xb[idx];
+        }
+        const i64 s0 = rdl64(h_lo, h_hi, 0), e0 = rdl64(h_lo, h_hi, 1);
         if (wlen <= 0 || !PS->X.offsets || e0 <= s0) return;
-        const i64 b0 = rfl64(PS->X.offsets[idx]);
-        const i64 nb = rfl64(PS->X.offsets[idx + 1]) - b0;
+        const i64 b0 = rdl64(h_lo, h_hi, 2);
+        const i64 nb = rdl64(h_lo, h_hi, 3) - b0;
         if (nb <= 0) return;
-        const i64 bbase = rfl(PS->X.base[idx]);
+        const i64 bbase = rdl(h_b, 0);
         i64 ba = (q_start + x_lo - bbase) >> 11, bb = (q_start + x_lo + wlen - 1 - bbase) >> 11;
         ba = ba < 0 ? 0 : (ba > nb - 1 ? nb - 1 : ba);
         bb = bb < 0 ? 0 : (bb > nb - 1 ? nb - 1 : bb);
-        i64 lo_c = s0 + rfl(PS->X.lo[b0 + ba]);
-        const i64 hi_c = s0 + rfl(PS->X.hi[b0 + bb]);
+        int lohi = 0;
+        if (lane < 2) lohi = lane == 0 ? PS->X.lo[b0 + ba] : PS->X.hi[b0 + bb];
+        i64 lo_c = s0 + rdl(lohi, 0);
+        const i64 hi_c = s0 + rdl(lohi, 1);
         if (lo_c > hi_c) lo_c = hi_c;
         if (hi_c - lo_c > PAINT_TILE) return;
         const int n_c = (int)(hi_c - lo_c);
@@ -3542,11 +3592,28 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
     // (per-query values: scalar loads through the constant address space, see realign_tracks_kernel)
     typedef const int __attribute__((address_space(4))) *KInt;
     typedef const i64 __attribute__((address_space(4))) *KI64;
+    // Three rounds, each requested as a whole before any of it is used (the asm statements name the values as scalar
+    // operands: written value by value the compiler had put every load behind the use of the one before -- eight memory
+    // round trips in a row in front of the first candidate record, and a chunk's wave is exactly that chain long):
+    //   1. the query's output range, list number and first position,  2. the list's bounds and its bucket index's,
+    //   3. (below) both bucket bounds;  then the candidate records.
     const i64 o0 = ((KI64)(u64)out_offsets)[q];
-    const i64 length = ((KI64)(u64)out_offsets)[q + 1] - o0;
-    const i64 idx = ((KI64)(u64)offset_idxs)[q] / list_div;
-    const i64 s0 = ((KI64)(u64)itv_offsets)[idx], e0 = ((KI64)(u64)itv_offsets)[idx + 1];
+    const i64 o1 = ((KI64)(u64)out_offsets)[q + 1];
+    const i64 idx_raw = ((KI64)(u64)offset_idxs)[q];
     const i64 qs = ((KInt)(u64)starts)[q * starts_stride];
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" :: "s"(o0), "s"(o1), "s"(idx_raw), "s"((int)qs));
+#endif
+    const i64 length = o1 - o0;
+    const i64 idx = list_div == 1 ? idx_raw : idx_raw / list_div;
+    const i64 s0 = ((KI64)(u64)itv_offsets)[idx], e0 = ((KI64)(u64)itv_offsets)[idx + 1];
+    // (without a bucket index the three reads below land on the list's own bounds and are not used)
+    const i64 *const xo = X.offsets ? X.offsets : itv_offsets;
+    const i64 xb0 = ((KI64)(u64)xo)[idx], xb1 = ((KI64)(u64)xo)[idx + 1];
+    const int xbase = ((KInt)(u64)(X.offsets && X.base ? X.base : (const int *)itv_offsets))[idx];
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" :: "s"(s0), "s"(e0), "s"(xb0), "s"(xb1), "s"(xbase));
+#endif
     // the first round of both searches probes the same 64 strided entries of the query's list for
     // every chunk: wave 0 fetches them once for the block's 4 chunks
     if (!X.offsets && wave == 0 && e0 > s0) {
@@ -3566,15 +3633,19 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
     i64 hi_c = 0, lo_c = 0;
     bool indexed = false;
     if (X.offsets) {
-        const i64 b0 = ((KI64)(u64)X.offsets)[idx];
-        const i64 nb = ((KI64)(u64)X.offsets)[idx + 1] - b0;
+        const i64 b0 = xb0;
+        const i64 nb = xb1 - b0;
         if (nb > 0) {
-            const i64 base = ((KInt)(u64)X.base)[idx];
+            const i64 base = xbase;
             i64 ba = (qs + j0 - base) >> 11, bb = (qs + j1 - 1 - base) >> 11;
             ba = ba < 0 ? 0 : (ba > nb - 1 ? nb - 1 : ba);
             bb = bb < 0 ? 0 : (bb > nb - 1 ? nb - 1 : bb);
-            lo_c = s0 + ((KInt)(u64)X.lo)[b0 + ba];
-            hi_c = s0 + ((KInt)(u64)X.hi)[b0 + bb];
+            const int r_lo = ((KInt)(u64)X.lo)[b0 + ba], r_hi = ((KInt)(u64)X.hi)[b0 + bb];
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" :: "s"(r_lo), "s"(r_hi));
+#endif
+            lo_c = s0 + r_lo;
+            hi_c = s0 + r_hi;
             if (lo_c > hi_c) lo_c = hi_c;
             indexed = hi_c - lo_c <= PAINT_TILE;
         }
@@ -3641,11 +3712,18 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
         // all candidate records are requested before the first one is used (<= 4 rounds of 64: one memory
         // round trip instead of one per round)
         int c_s[PAINT_TILE / WAVE], c_e[PAINT_TILE / WAVE]; float c_v[PAINT_TILE / WAVE];
+        // (every lane of every round reads SOME candidate -- those behind the last one the last one again -- and does not use
+        // it: a load under a predicate, or in a round that is skipped, is merged with a default value, and the merge
+        // waits for it: one round trip per round again)
 #pragma unroll
-        for (int r_ = 0; r_ < PAINT_TILE / WAVE; ++r_) {
-            const int i = r_ * WAVE + lane;
-            c_s[r_] = 0; c_e[r_] = 0; c_v[r_] = 0.0f;
-            if (i < n_c) { c_s[r_] = itv_starts[lo_c + i]; c_e[r_] = itv_ends[lo_c + i]; c_v[r_] = itv_values[lo_c + i]; }
+        for (int r_ = 0; r_ < PAINT_TILE / WAVE; ++r_) { c_s[r_] = 0; c_e[r_] = 0; c_v[r_] = 0.0f; }
+        if (n_c > 0) {
+#pragma unroll
+            for (int r_ = 0; r_ < PAINT_TILE / WAVE; ++r_) {
+                const int i = r_ * WAVE + lane;
+                const i64 at = lo_c + (i < n_c ? i : n_c - 1);
+                c_s[r_] = itv_starts[at]; c_e[r_] = itv_ends[at]; c_v[r_] = itv_values[at];
+            }
         }
 #pragma unroll
         for (int r_ = 0; r_ < PAINT_TILE / WAVE; ++r_) {
@@ -4586,7 +4664,9 @@ static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const 
     A.dbg = debug_flags();
     if (A.n_rows > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: batch too large");
     const i64 grid = (A.n_rows + 3) / 4;
-    if (ps) realign_tracks_kernel<true><<<dim3((unsigned)grid, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream>>>(A, *ps);
+    // (GVL_TRACK_EXTRA_LDS: bytes of unused LDS per workgroup, to measure the kernel at fewer waves per SIMD)
+    static const unsigned xl = [] { const char *e = getenv("GVL_TRACK_EXTRA_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
+    if (ps) realign_tracks_kernel<true><<<dim3((unsigned)grid, (unsigned)chunks), dim3(256), xl, (hipStream_t)stream>>>(A, *ps);
     else realign_tracks_kernel<false><<<dim3((unsigned)grid, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream>>>(A, PaintSrcArgs());
     return check_launch("gvl_realign_tracks");
 }
