@@ -282,8 +282,10 @@ static void batch_row(const batch_args *a, int64_t k)
  * _threads.py:102-115) keeps its workers parked between par_iter calls; so does this
  * one: workers sleep on a condition variable, a job is (fn, n rows, chunk) with an
  * atomic cursor, the caller works too and then waits for the stragglers.  Rows are
- * handed out in chunks of n / (threads * 8) like rayon's adaptive splitting of the
- * row range (reconstruct/mod.rs:424-539). */
+ * handed out in chunks of n / (threads * 8) (at least 8) like rayon's adaptive splitting
+ * of the row range (reconstruct/mod.rs:424-539).  Between jobs that arrive back to back
+ * nobody touches the mutex: workers spin on the generation, check in through an atomic
+ * count, and only the last one signals the poster. */
 typedef struct {
     const void *args;
     void (*fn)(const void *, int64_t);
@@ -321,34 +323,37 @@ static void *pool_worker(void *born_at)
      * workers, so no job can be posted in between): a worker born into a pool that has already run jobs must
      * not mistake the old generation count for a new job -- g_pool.job is NULL then */
     uint64_t seen = (uint64_t)(uintptr_t)born_at;
-    pthread_mutex_lock(&g_pool.mu);
     for (;;) {
         /* like rayon's workers: look for the next job for a while before going to sleep (a condition-variable wake
-         * costs tens of microseconds; batches arrive back to back) */
-        if (!g_pool.stop && g_pool.generation == seen) {
-            pthread_mutex_unlock(&g_pool.mu);
-            for (int spin = 0; spin < 20000; spin++) {
-                if (__atomic_load_n(&g_pool.generation, __ATOMIC_ACQUIRE) != seen || __atomic_load_n(&g_pool.stop, __ATOMIC_ACQUIRE)) break;
-                __builtin_ia32_pause();
-            }
-            pthread_mutex_lock(&g_pool.mu);
+         * costs tens of microseconds; batches arrive back to back).  The mutex is only taken to sleep: with a few
+         * hundred workers, every one of them locking it twice per job WAS the job. */
+        for (int spin = 0; spin < 20000; spin++) {
+            if (__atomic_load_n(&g_pool.generation, __ATOMIC_ACQUIRE) != seen || __atomic_load_n(&g_pool.stop, __ATOMIC_ACQUIRE)) break;
+            __builtin_ia32_pause();
         }
-        while (!g_pool.stop && g_pool.generation == seen) pthread_cond_wait(&g_pool.cv_work, &g_pool.mu);
-        if (g_pool.stop) break;
-        seen = g_pool.generation;
-        pool_job *job = g_pool.job;
-        pthread_mutex_unlock(&g_pool.mu);
+        if (__atomic_load_n(&g_pool.generation, __ATOMIC_ACQUIRE) == seen && !__atomic_load_n(&g_pool.stop, __ATOMIC_ACQUIRE)) {
+            pthread_mutex_lock(&g_pool.mu);
+            while (!g_pool.stop && g_pool.generation == seen) pthread_cond_wait(&g_pool.cv_work, &g_pool.mu);
+            pthread_mutex_unlock(&g_pool.mu);
+        }
+        if (__atomic_load_n(&g_pool.stop, __ATOMIC_ACQUIRE)) break;
+        /* (every worker is counted in `pending` of every job, so the poster cannot return -- and its job cannot go out
+         * of scope, nor the next one be posted -- before this worker has checked in below) */
+        seen = __atomic_load_n(&g_pool.generation, __ATOMIC_ACQUIRE);
+        pool_job *job = __atomic_load_n(&g_pool.job, __ATOMIC_ACQUIRE);
         job_drain(job);
-        pthread_mutex_lock(&g_pool.mu);
-        if (--g_pool.pending == 0) pthread_cond_signal(&g_pool.cv_done);
+        if (__atomic_sub_fetch(&g_pool.pending, 1, __ATOMIC_ACQ_REL) == 0) {
+            pthread_mutex_lock(&g_pool.mu);          /* (under the mutex: the poster checks `pending` under it before it sleeps) */
+            pthread_cond_signal(&g_pool.cv_done);
+            pthread_mutex_unlock(&g_pool.mu);
+        }
     }
-    pthread_mutex_unlock(&g_pool.mu);
     return NULL;
 }
 
 static void pool_shutdown_locked(void)
 {
-    g_pool.stop = 1;
+    __atomic_store_n(&g_pool.stop, 1, __ATOMIC_RELEASE);
     pthread_cond_broadcast(&g_pool.cv_work);
     pthread_mutex_unlock(&g_pool.mu);
     for (int t = 0; t < g_pool.n_workers; t++) pthread_join(g_pool.th[t], NULL);
@@ -356,7 +361,7 @@ static void pool_shutdown_locked(void)
     free(g_pool.th);
     g_pool.th = NULL;
     g_pool.n_workers = 0;
-    g_pool.stop = 0;
+    __atomic_store_n(&g_pool.stop, 0, __ATOMIC_RELEASE);
 }
 
 /* (Re)size the pool to `n_threads` (the caller counts as one). */
@@ -388,18 +393,20 @@ static void run_rows(const void *args, void (*fn)(const void *, int64_t),
     }
     pthread_mutex_lock(&g_job_mu);
     int have = gvlo_pool_resize(n_threads);
-    pool_job job = {args, fn, n, max64(1, n / ((int64_t)have * 8)), 0};
+    /* (at least 8 rows per grab: with hundreds of threads n / (threads * 8) is one or two rows, and the atomic cursor's cache
+     * line becomes the job) */
+    pool_job job = {args, fn, n, max64(n >= 64 ? 8 : 1, n / ((int64_t)have * 8)), 0};
     pthread_mutex_lock(&g_pool.mu);
-    g_pool.job = &job;
-    g_pool.pending = g_pool.n_workers;
-    g_pool.generation++;
+    __atomic_store_n(&g_pool.job, &job, __ATOMIC_RELEASE);
+    __atomic_store_n(&g_pool.pending, g_pool.n_workers, __ATOMIC_RELEASE);
+    __atomic_store_n(&g_pool.generation, g_pool.generation + 1, __ATOMIC_RELEASE);
     pthread_cond_broadcast(&g_pool.cv_work);
     pthread_mutex_unlock(&g_pool.mu);
     job_drain(&job);
     for (int spin = 0; spin < 20000 && __atomic_load_n(&g_pool.pending, __ATOMIC_ACQUIRE) > 0; spin++) __builtin_ia32_pause();
     pthread_mutex_lock(&g_pool.mu);
-    while (g_pool.pending > 0) pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
-    g_pool.job = NULL;
+    while (__atomic_load_n(&g_pool.pending, __ATOMIC_ACQUIRE) > 0) pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
+    __atomic_store_n(&g_pool.job, NULL, __ATOMIC_RELEASE);
     pthread_mutex_unlock(&g_pool.mu);
     pthread_mutex_unlock(&g_job_mu);
 }

@@ -119,3 +119,33 @@ def test_onehot_definition(oracle):
     np.testing.assert_array_equal(lc[0, 0, :6], [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0],
                                                  [0, 0, 0, 1], [0, 0, 0, 0], [0, 0, 0, 0]])
     np.testing.assert_array_equal(oracle.onehot(x, "cl"), np.swapaxes(lc, -1, -2))
+
+
+def test_worker_pool_thread_counts():
+    """The oracle's worker pool (what `cpu_baseline` times): the same bytes for every thread count, through many
+    back-to-back jobs and resizes of the pool in between (workers spin for the next job, check in through an atomic
+    count; the reference's counterpart is rayon's global pool, test_rayon_equivalence.py:31-62)."""
+    from genvarloader_amd import synth
+    from oracle import oracle as orc
+
+    st, bt = synth.make_config("cfg3", contig=1 << 20)
+    K = bt.geno_offset_idx.size
+    L = int(bt.output_length)
+    oo = np.arange(K + 1, dtype=np.int64) * L
+
+    def run(nt, reps):
+        out = np.zeros(K * L, np.uint8)
+        oh = np.zeros((K * L, 4), np.uint8)
+        call = orc.BatchCall(out, oo, bt.regions, bt.shifts, bt.geno_offset_idx, bt.geno_offsets, bt.geno_v_idxs,
+                             st.v_starts, st.ilens, st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets,
+                             st.pad_char, to_rc=bt.to_rc, onehot_out=oh)
+        for _ in range(reps):
+            call.run(nt)
+        return out, oh
+
+    want, want_oh = run(1, 1)
+    assert want.any() and want_oh.any()
+    for nt, reps in ((2, 3), (5, 40), (16, 40), (3, 5), (48, 20), (1, 2), (7, 60)):
+        got, got_oh = run(nt, reps)
+        np.testing.assert_array_equal(got, want, err_msg=f"{nt} threads")
+        np.testing.assert_array_equal(got_oh, want_oh, err_msg=f"{nt} threads (one-hot)")
