@@ -36,7 +36,7 @@ Timing.  After W warmup steps:
     same way -> the kernel's own average duration (what ``rocprofv3 --kernel-trace --stats``
     reports) -> ``achieved`` = algorithmic bytes per launch / that;
   * ``sustained``: >= ``--sustained-s`` (3) seconds of back-to-back cold batches on the same
-    4-stream schedule between ONE pair of HIP events (no gate, no per-region synchronisation):
+    schedule (``--streams``, default 3 batches in flight) between ONE pair of HIP events (no gate, no per-region synchronisation):
     the rate at seconds, with the shader / memory clocks read from rocm-smi before and after.
 
 For N > 1 the driver launches one rank per GPU (torch.distributed.run); rows are independent,
@@ -279,8 +279,9 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-only", action="store_true", help="time the CPU oracle only (cfg1 plumbing case); no GPU")
     ap.add_argument("--cpu-budget", type=float, default=8.0)
-    ap.add_argument("--streams", type=int, default=4,
-                    help="HIP streams the launches of the timed region rotate over")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams the launches of the timed region rotate over = batches in flight (3: what the native "
+                         "loader keeps in flight; measured against 2 / 4 / 5 / 6 / 8, DESIGN 5)")
     ap.add_argument("--many", type=int, default=1,
                     help="batches per launch in the timed region (gvl_reconstruct_many; a step is still ONE batch)")
     ap.add_argument("--min-region-ms", type=float, default=1000.0,
@@ -365,13 +366,23 @@ def main() -> None:
                             for b in batches[: min(8, n_rot)]]))
     counter = [0]
 
+    import ctypes as _C
+    _dref = _C.byref(dev.c)
+    _bref = [_C.byref(b.c) for b in batches]
+    _sref = [_C.byref(s_[1]) for s_ in slots]
+    _sptr = [_C.c_void_p(s_.cuda_stream) for s_ in streams]
+    _fn = dev.lib.gvl_reconstruct
+
     def step_pipelined(i: int) -> None:
         # a batch is independent of the previous one: the loader keeps `--streams` batches in
         # flight on separate HIP streams, so the latency-bound head of one batch (parameter
-        # and variant gathers, scans) overlaps the store-bound tail of another
+        # and variant gathers, scans) overlaps the store-bound tail of another.  (The C-ABI entry with its
+        # arguments converted once: 3 us of host time per launch -- through HapsDevice.launch it is 7, and a region of
+        # hundreds of steps then runs at the host's rate, not the GPU's.)
         j = counter[0]
         counter[0] += 1
-        dev.launch(batches[j % n_rot], slots[j % n_slots][1], streams[i % len(streams)])
+        if _fn(_dref, _bref[j % n_rot], _sref[j % n_slots], _sptr[i % len(streams)]):
+            raise RuntimeError("gvl_reconstruct failed")
 
     class ManyStepper:
         """--many G: steps are gathered into launches of G batches (gvl_reconstruct_many), launch g on
