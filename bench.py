@@ -35,7 +35,7 @@ Timing.  After W warmup steps:
   * ``roofline``: K back-to-back launches on ONE stream between two HIP events, repeated the
     same way -> the kernel's own average duration (what ``rocprofv3 --kernel-trace --stats``
     reports) -> ``achieved`` = algorithmic bytes per launch / that;
-  * ``sustained``: >= ``--sustained-s`` (3) seconds of back-to-back cold batches on the same
+  * ``sustained``: >= ``--sustained-s`` (6) seconds of back-to-back cold batches on the same
     schedule (``--streams``, default 3 batches in flight) between ONE pair of HIP events (no gate, no per-region synchronisation):
     the rate at seconds, with the shader / memory clocks read from rocm-smi before and after.
 
@@ -248,8 +248,11 @@ class Timer:
         for i in range(burst):
             bad |= fn(*calls[i % m])
         t_burst = time.perf_counter() - t0
+        marks = {n // 3: torch.cuda.Event(enable_timing=True), 2 * n // 3: torch.cuda.Event(enable_timing=True)}
         for i in range(burst, n):
             bad |= fn(*calls[i % m])
+            if i in marks:                    # (two more events on streams[0]: the rate of each third of the leg)
+                marks[i].record(streams[0])
         t_host = time.perf_counter() - t0
         for s_, ev in zip(streams[1:], joins):
             ev.record(s_)
@@ -260,6 +263,8 @@ class Timer:
         if bad:
             raise RuntimeError("gvl_reconstruct failed inside the sustained leg")
         ms = self.allmax([e0.elapsed_time(e1)])[0]
+        pts = [(0, 0.0)] + sorted((i, e0.elapsed_time(e)) for i, e in marks.items() if i >= burst) + [(n, e0.elapsed_time(e1))]
+        self.last_thirds = [(pts[k][1] - pts[k - 1][1]) / max(pts[k][0] - pts[k - 1][0], 1) for k in range(1, len(pts))]
         return ms / n, n, t_host, t_burst / burst
 
 
@@ -288,7 +293,7 @@ def main() -> None:
                     help="GPU time to sample per timed leg (repeated K-step regions)")
     ap.add_argument("--max-regions", type=int, default=20000)
     ap.add_argument("--max-leg-s", type=float, default=8.0, help="host time one timed leg may take")
-    ap.add_argument("--sustained-s", type=float, default=3.0,
+    ap.add_argument("--sustained-s", type=float, default=6.0,
                     help="length of the sustained leg (back-to-back cold batches, one event pair); 0 = skip")
     ap.add_argument("--strong", action="store_true", help="N > 1: split ONE batch across the ranks (strong scaling)")
     ap.add_argument("--gather", action="store_true", help="N > 1: also time the RCCL all-gather of the one-hot shards")
@@ -476,6 +481,10 @@ def main() -> None:
         sustained = {"ms_per_step": sus_ms, "steps": sus_n, "seconds": sus_ms * sus_n * 1e-3,
                      "windows_per_s": k_all / (sus_ms * 1e-3),
                      "vs_median_region": sus_ms / (region_ms / steps),
+                     # the leg in thirds: with 3 batches in flight the lean kernel's launches settle into a faster steady state
+                     # after 1-2.5 s without a pause; `steady_ms_per_step` = the last third
+                     "ms_per_step_thirds": list(tm.last_thirds), "steady_ms_per_step": tm.last_thirds[-1],
+                     "steady_windows_per_s": k_all / (tm.last_thirds[-1] * 1e-3),
                      "host_enqueue_s": sus_host, "host_us_per_launch_unthrottled": sus_launch * 1e6,
                      "host_bound": bool(sus_launch * 1e3 > 0.9 * sus_ms),
                      "how": "back-to-back gvl_reconstruct launches, step i on stream i % streams, rotating cold batches, "
