@@ -2114,6 +2114,7 @@ static recon_fn recon_table(int oh, bool haps, bool annot) {
 }
 
 #include "gvl_lean.inc"
+#include "gvl_lean_pipe.inc"
 
 // ---------------------------------------------------------------------------
 // get_diffs_sparse (genotypes/mod.rs:15-125): one lane per (query, hap) row.
@@ -4259,7 +4260,7 @@ static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_o
     }
     if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;     // u32 positions in the kernel
     // (2097152 ... 16777216 concern the track kernels only)
-    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216)) == 0;
+    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864)) == 0;
 }
 
 static int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
@@ -4295,32 +4296,109 @@ static int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
     return check_launch("gvl_reconstruct (lean)");
 }
 
+// ---- the pipelined form (gvl_lean_pipe.inc): rows of one chunk, `n` batches of the same shape in ONE grid ----------
+// GVL_PIPE_MIN_ROWS (default 8192): launches with fewer rows keep recon_lean_kernel (a wave per row: with one row per wave
+// there is nothing to pipeline); GVL_PIPE_WAVES (default 8192 = every wave slot of the part): waves in the grid, each takes
+// rows w, w + waves, ...; GVL_DBG & 33554432: always, with ONE workgroup (the suite's small batches then run many rows per
+// wave); GVL_DBG & 67108864: never.
+static int pipe_env(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static bool lean_pipe_wanted(i64 total_rows) {
+    if (debug_flags() & 67108864) return false;
+    if (debug_flags() & 33554432) return true;
+    static const int min_rows = pipe_env("GVL_PIPE_MIN_ROWS", 8192);
+    return min_rows >= 0 && total_rows >= min_rows;
+}
+// can these (lean-eligible, one-chunk) batches share a grid?  the same shape and outputs; every batch but the last has the
+// first one's row count
+static bool lean_pipe_compatible(const ReconArgs *RAs, int n) {
+    const ReconArgs &F = RAs[0];
+    if (((uintptr_t)F.ref4 & 15) || ((uintptr_t)F.srec & 15)) return false;        // (16-byte DMA sources)
+    i64 total = 0;
+    for (int i = 0; i < n; ++i) {
+        const ReconArgs &R = RAs[i];
+        if (R.fixed_len != F.fixed_len || R.ploidy != F.ploidy || R.regions_stride != F.regions_stride ||
+            (R.onehot != nullptr) != (F.onehot != nullptr) || (R.haps != nullptr) != (F.haps != nullptr) || R.dbg != F.dbg)
+            return false;
+        if (R.n_rows <= 0 || R.n_rows > F.n_rows || (i + 1 < n && R.n_rows != F.n_rows)) return false;
+        total += R.n_rows;
+    }
+    return total <= 0x7FFFFFF0ll && F.regions_stride <= 0x7FFFFFFFll;
+}
+static int launch_lean_rows(const ReconArgs *RAs, int n, void *stream) {
+    const ReconArgs &RA = RAs[0];
+    LeanArgs A;
+    LeanMany M;
+    memset(&A, 0, sizeof(A));
+    memset(&M, 0, sizeof(M));
+    A.ref4 = RA.ref4; A.ref_offsets = RA.ref_offsets; A.srec = RA.srec;
+    A.regions = RA.regions; A.shifts = RA.shifts; A.geno_offset_idx = RA.geno_offset_idx; A.to_rc = RA.to_rc;
+    A.onehot = RA.onehot; A.haps = RA.haps; A.out_offsets_w = RA.out_offsets_w; A.alt_alleles = RA.alt_alleles;
+    A.go_starts = RA.go_starts; A.go_stops = RA.go_stops; A.grec = RA.grec; A.alt_offsets = RA.alt_offsets;
+    A.n_geno_offsets = RA.n_geno_offsets;
+    A.n_contigs = RA.n_contigs; A.regions_stride = (int)RA.regions_stride;
+    A.ploidy_shift = RA.ploidy_shift; A.ploidy = RA.ploidy; A.L = (int)RA.fixed_len; A.dbg = RA.dbg;
+    A.chunks = 1; A.sub = 1;
+    A.rows_per_batch = (int)RA.n_rows; A.n_batches = n;
+    i64 total = 0;
+    for (int i = 0; i < n; ++i) {
+        LeanBatch &b = M.b[i];
+        b.regions = RAs[i].regions; b.shifts = RAs[i].shifts; b.geno_offset_idx = RAs[i].geno_offset_idx; b.to_rc = RAs[i].to_rc;
+        b.onehot = RAs[i].onehot; b.haps = RAs[i].haps; b.out_offsets_w = RAs[i].out_offsets_w; b.n_rows = RAs[i].n_rows;
+        total += RAs[i].n_rows;
+    }
+    A.n_rows = (int)total;
+    static const int cap_env = pipe_env("GVL_PIPE_WAVES", 8192);
+    i64 waves = (debug_flags() & 33554432) ? LEAN_WAVES : (cap_env < LEAN_WAVES ? LEAN_WAVES : cap_env);
+    if (waves > total) waves = total;
+    if (waves * PIPE_MAX_ROWS < total) waves = (total + PIPE_MAX_ROWS - 1) / PIPE_MAX_ROWS;
+    const unsigned grid = (unsigned)((waves + LEAN_WAVES - 1) / LEAN_WAVES);
+    const dim3 g(grid), b(LEAN_THREADS);
+    hipStream_t s = (hipStream_t)stream;
+    if (A.onehot && A.haps) recon_lean_rows_kernel<true, true><<<g, b, 0, s>>>(A, RA, M);
+    else if (A.onehot) recon_lean_rows_kernel<true, false><<<g, b, 0, s>>>(A, RA, M);
+    else recon_lean_rows_kernel<false, true><<<g, b, 0, s>>>(A, RA, M);
+    return check_launch("gvl_reconstruct (lean, pipelined)");
+}
+
 int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *out, void *stream) {
     ReconArgs A;
     int chunks = 1, variant = 0;
     const int rc = fill_recon_args(st, bt, out, A, &chunks, &variant);
     if (rc) return rc;
-    if (A.n_rows > 0 && lean_eligible(st, bt, out, chunks, A.chunk_len)) return launch_lean(A, chunks, stream);
+    if (A.n_rows > 0 && lean_eligible(st, bt, out, chunks, A.chunk_len)) {
+        if (chunks == 1 && lean_pipe_wanted(A.n_rows) && lean_pipe_compatible(&A, 1)) return launch_lean_rows(&A, 1, stream);
+        return launch_lean(A, chunks, stream);
+    }
     return launch_recon(A, chunks, variant, stream);
 }
 
-// Measured and not done as ONE launch (blockIdx.z = batch, per-batch arguments indexed in the kernarg
-// segment): the indirection cost 1.2-1.8 us per batch (scalar loads of the arguments at their use
-// instead of one preload) and the batches of one launch overlapped no better than launches on
-// separate streams.  The entry point stays: one host call, all arguments validated before the
-// first launch, back-to-back launches on `stream`.
+// `n` batches in one host call.  Batches the lean kernel's pipelined form can take together (one-chunk rows, the same
+// shape and outputs) are ONE grid: row k of the launch belongs to batch k / rows_per_batch, a wave takes rows w, w + W, ...
+// and keeps its next row's reads in flight under the stores of the row in hand (gvl_lean_pipe.inc) -- which is what makes
+// one grid better than launches on separate streams.  (Round 2 measured blockIdx.z = batch for the all-purpose kernel: the
+// per-batch arguments behind an index cost 1.2-1.8 us per batch THERE, at their use; here they are fetched a row ahead.)
+// Everything else: back-to-back launches on `stream`, every batch validated before the first launch.
 int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_out *outs, int32_t n, void *stream) {
     if (n < 0 || n > GVL_MANY_MAX || (n > 0 && (!bts || !outs))) return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct_many: bad arguments (n <= GVL_MANY_MAX)");
     ReconArgs A[GVL_MANY_MAX];
     int chunks[GVL_MANY_MAX], variant[GVL_MANY_MAX];
+    bool lean[GVL_MANY_MAX];
+    bool all_one_chunk_lean = n > 0;
+    i64 total = 0;
     for (int i = 0; i < n; ++i) {
         chunks[i] = 1; variant[i] = 0;
         const int rc = fill_recon_args(st, &bts[i], &outs[i], A[i], &chunks[i], &variant[i]);
         if (rc) return rc;
+        lean[i] = A[i].n_rows > 0 && lean_eligible(st, &bts[i], &outs[i], chunks[i], A[i].chunk_len);
+        all_one_chunk_lean = all_one_chunk_lean && lean[i] && chunks[i] == 1;
+        total += A[i].n_rows;
     }
+    if (all_one_chunk_lean && lean_pipe_wanted(total) && lean_pipe_compatible(A, n)) return launch_lean_rows(A, n, stream);
     for (int i = 0; i < n; ++i) {
-        const bool lean = A[i].n_rows > 0 && lean_eligible(st, &bts[i], &outs[i], chunks[i], A[i].chunk_len);
-        const int rc = lean ? launch_lean(A[i], chunks[i], stream) : launch_recon(A[i], chunks[i], variant[i], stream);
+        const int rc = lean[i] ? launch_lean(A[i], chunks[i], stream) : launch_recon(A[i], chunks[i], variant[i], stream);
         if (rc) return rc;
     }
     return GVL_OK;

@@ -16,10 +16,11 @@ pytestmark = pytest.mark.gpu
 REPO = Path(__file__).resolve().parent.parent
 
 
-def _run(script, n, seed, dbg=None):
+def _run(script, n, seed, dbg=None, **extra_env):
     env = dict(os.environ)
     if dbg is not None:
         env["GVL_DBG"] = str(dbg)
+    env.update({k: str(v) for k, v in extra_env.items()})
     r = subprocess.run([sys.executable, str(REPO / "tools" / script), str(n), str(seed)], capture_output=True,
                        text=True, env=env, cwd=REPO, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
@@ -76,3 +77,31 @@ def test_fuzz_lean_kernel():
 def test_fuzz_lean_kernel_every_row_solo():
     """GVL_DBG=32768: the lean kernel hands EVERY row to the all-purpose body in SOLO mode."""
     _run("fuzz_lean.py", 300, 202, dbg=32768)
+
+
+def test_fuzz_lean_kernel_rereads_indel_rows():
+    """GVL_DBG=65536: rows with indels re-read their runs from the packed reference instead of re-aligning the window in LDS."""
+    _run("fuzz_lean.py", 300, 203, dbg=65536)
+
+
+@pytest.mark.parametrize("dbg", [33554432, 33554432 + 65536, 33554432 + 32768],
+                         ids=["pipelined", "pipelined-defers-indel-rows", "pipelined-defers-every-row"])
+def test_fuzz_lean_kernel_pipelined(dbg):
+    """GVL_DBG & 33554432: the lean kernel's pipelined form (gvl_lean_pipe.inc) on ONE workgroup -- a wave takes every fourth
+    row, up to 30 rows per wave: window + slot line by LDS-DMA a row ahead, rows it cannot take run at the wave's end."""
+    _run("fuzz_lean.py", 400, 204 + (dbg >> 15) % 7, dbg=dbg)
+
+
+@pytest.mark.parametrize("dbg,sub", [(0, 2), (32768, 2), (65536, 2), (0, 1), (0, 4)],
+                         ids=["default", "every-chunk-solo", "rereads", "one-chunk-per-wave", "four-chunks-per-wave"])
+def test_fuzz_lean_kernel_long_rows(dbg, sub):
+    """FUZZ_LONG=1: rows of 2 052 ... 40 000 bases = the lean kernel's chunked form (BASELINE config 4's haplotype kernel),
+    with 1 / 2 / 4 consecutive chunks per wave (GVL_LEAN_SUB)."""
+    _run("fuzz_lean.py", 120, 210 + sub + (dbg >> 15), dbg=dbg, FUZZ_LONG=1, GVL_LEAN_SUB=sub)
+
+
+@pytest.mark.parametrize("dbg", [0, 2097152], ids=["default", "no-window"])
+def test_fuzz_tracks_straight_from_intervals(dbg):
+    """tools/fuzz_fused_tracks.py: realign_tracks_kernel<PAINT> (BASELINE config 4's track kernel): a batch's tracks realigned
+    straight from their intervals, `tile_complete` interval sets."""
+    _run("fuzz_fused_tracks.py", 150, 220, dbg=dbg)

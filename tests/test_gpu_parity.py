@@ -42,7 +42,11 @@ def gpu():
 # kernel path: gvl_set_debug_flags removes one way at a time.
 KERNEL_PATHS = {0: "default", 8: "scalar-walk", 64: "csr-inline-records", 80: "csr-vrec-gather", 32: "no-scan-free-plan",
                 128: "no-speculative-reads", 512: "per-wave-scans", 2048: "wave-per-row-diffs",
-                16384: "no-lean-kernel", 32768: "lean-lists-every-row", 1048576: "no-lean-long"}
+                16384: "no-lean-kernel", 32768: "lean-lists-every-row", 65536: "lean-rereads-indel-rows", 1048576: "no-lean-long",
+                # the lean kernel's pipelined form (gvl_lean_pipe.inc) on ONE workgroup -- a wave takes every fourth row of the
+                # batch, many rows per wave --; with every row / every indel row deferred to the wave's end; and never
+                33554432: "lean-pipelined", 33554432 + 32768: "lean-pipelined-defers-every-row",
+                33554432 + 65536: "lean-pipelined-defers-indel-rows", 67108864: "no-lean-pipeline"}
 
 
 @pytest.fixture(params=sorted(KERNEL_PATHS), ids=[KERNEL_PATHS[k] for k in sorted(KERNEL_PATHS)])
@@ -274,6 +278,42 @@ def test_cfg3_full_with_properties(gpu, oracle, kpath):
     assert int(out.onehot.sum(dim=1).max()) <= 1
     n_acgt = sum(int((out.haps == c).sum()) for c in b"ACGT")
     assert int(out.onehot.sum()) == n_acgt
+
+
+@pytest.mark.parametrize("want", ["onehot", "both", "haps"])
+def test_many_batches_in_one_grid(gpu, oracle, want, kpath):
+    """gvl_reconstruct_many: batches of one shape share a grid (gvl_lean_pipe.inc: row k of the launch belongs to batch
+    k / rows_per_batch, per-batch arrays behind a table) -- five batches of a dataset with a SHORTER last one, one of them
+    without a strand mask, their outputs in separate buffers; every batch must equal the oracle's."""
+    from genvarloader_amd import synth
+
+    rng = np.random.default_rng(77)
+    st = synth.make_static(rng, (60_000, 90_001), density=1 / 60, indel_frac=0.3, af_beta=(0.6, 0.9), max_indel=30)
+    L, P = 512, 2
+    # ONE genotype CSR for the dataset: draw a big batch, then cut its queries into the launch's batches
+    full = synth.make_batch(rng, st, 6 * 9 + 4, P, L, rc_frac=0.5, random_shifts=True, edge_frac=0.15, permute_csr=True)
+    dev = make_dev(gpu, st, full)
+    cuts = [(0, 9), (9, 18), (18, 27), (27, 36), (36, 45), (45, 54), (54, 58)]           # the last one shorter
+    onehot, haps = want in ("onehot", "both"), want in ("both", "haps")
+    bts, outs, keep = [], [], []
+    for i, (a, b) in enumerate(cuts):
+        rc = None if i == 2 else full.to_rc[a * P:b * P]
+        dbt = dev.prepare_batch(full.regions[a:b], full.shifts[a:b], full.geno_offset_idx[a:b], L, to_rc=rc)
+        o, oc = dev.alloc_output(dbt, (b - a) * P * L, haps=haps, onehot=onehot)
+        bts.append(dbt); outs.append(oc); keep.append(o)
+    dev.launch_many(dev.pack_many(bts, outs))
+    gpu.torch.cuda.synchronize()
+    for i, (a, b) in enumerate(cuts):
+        rc = None if i == 2 else full.to_rc[a * P:b * P]
+        exp, exp_off, exp_oh = oracle.reconstruct_haplotypes_fused(
+            full.regions[a:b], full.shifts[a:b], full.geno_offset_idx[a:b], full.geno_offsets, full.geno_v_idxs, st.v_starts,
+            st.ilens, st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, L, None, None, rc, True,
+            onehot=True, n_threads=4)
+        if haps:
+            np.testing.assert_array_equal(keep[i].haps.cpu().numpy(), exp, err_msg=f"batch {i}")
+        if onehot:
+            np.testing.assert_array_equal(keep[i].onehot.cpu().numpy(), exp_oh, err_msg=f"batch {i}")
+        np.testing.assert_array_equal(keep[i].out_offsets.cpu().numpy(), exp_off, err_msg=f"batch {i}")
 
 
 def test_cfg1_plumbing(gpu, oracle, kpath):
