@@ -75,8 +75,12 @@ def cpu_baseline(st, bt, budget_s: float = 12.0, thread_counts=None) -> dict:
     """The oracle (C restatement of the reference's Rust/rayon path: reconstruct ->
     rc_flat_rows -> one-hot, rows handed to a persistent worker pool) timed on the host cores
     over one full batch, at several thread counts (1 and nproc at least).
-    The gate ``should_parallelize`` (_threads.py:122-127) would be ON for this batch
-    (8 MiB of output >> its 32 KiB threshold), so threads > 1 is what the reference runs."""
+    The reference's gate ``should_parallelize(total_bytes)`` (_threads.py:24,122-127) is
+    ``total_bytes >= num_threads() * 1 MiB`` with num_threads() = GVL_NUM_THREADS or the host's CPUs
+    (cgroup-aware): this batch's haplotype bytes (K x L = 8 MiB for cfg3) run in PARALLEL only with at most 8
+    threads (or GVL_FORCE_PARALLEL=1) -- on a many-core host the reference's DEFAULT is the serial path.
+    ``reference_default`` says which of the sweep's rows that is; ``value`` stays the best of the sweep
+    (= the reference with GVL_FORCE_PARALLEL=1 and the best GVL_NUM_THREADS)."""
     from oracle import oracle
 
     try:      # a -march=native copy in a scratch dir; the tree's x86-64-v3 .so stays as it is
@@ -113,6 +117,9 @@ def cpu_baseline(st, bt, budget_s: float = 12.0, thread_counts=None) -> dict:
         total_iters += len(times)
         total_s += sum(times)
     best = max(sweep, key=lambda k: sweep[k]["windows_per_s"])
+    gate_bytes = K * L                                # what _haps.py:865 hands to should_parallelize
+    gate_on = gate_bytes >= nproc * (1 << 20)         # with the reference's default thread count = this host's CPUs
+    ref_default = sweep[str(nproc)] if gate_on else sweep["1"]
     return {
         "value": sweep[best]["windows_per_s"], "unit": "windows/s", "cores": int(best), "kind": "port",
         "sample": f"one full batch ({K} windows x {L} bp, reconstruct+RC+one-hot) per iteration, "
@@ -121,7 +128,15 @@ def cpu_baseline(st, bt, budget_s: float = 12.0, thread_counts=None) -> dict:
         "single_thread_windows_per_s": sweep["1"]["windows_per_s"],
         "single_thread_hap_GBps": sweep["1"]["hap_GBps"],
         "threads_sweep": sweep,
-        "parallel_gate": "on (should_parallelize: 8 MiB batch >> 32 KiB threshold); threads=1 row = gate off",
+        "value_is": "best of the thread sweep = the reference with GVL_FORCE_PARALLEL=1 (or GVL_NUM_THREADS <= batch MiB) and the best thread count",
+        "parallel_gate": f"reference: parallel iff haplotype bytes >= threads x 1 MiB (_threads.py:24,127): {gate_bytes / (1 << 20):.0f} MiB here, "
+                         f"so parallel only with GVL_NUM_THREADS <= {max(1, gate_bytes >> 20)} or GVL_FORCE_PARALLEL=1",
+        "reference_default": {
+            "threads": nproc if gate_on else 1, "gate": "on" if gate_on else "off",
+            "windows_per_s": ref_default["windows_per_s"], "ms_per_batch": ref_default["ms_per_batch"],
+            "what": f"what the reference does on this host WITHOUT environment overrides: num_threads() = {nproc} CPUs, gate "
+                    + ("on: the rayon path at that width" if gate_on else "off: the serial path (the sweep's 1-thread row)"),
+        },
     }
 
 
@@ -284,11 +299,12 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-only", action="store_true", help="time the CPU oracle only (cfg1 plumbing case); no GPU")
     ap.add_argument("--cpu-budget", type=float, default=8.0)
-    ap.add_argument("--streams", type=int, default=3,
-                    help="HIP streams the launches of the timed region rotate over = batches in flight (3: what the native "
-                         "loader keeps in flight; measured against 2 / 4 / 5 / 6 / 8, DESIGN 5)")
-    ap.add_argument("--many", type=int, default=1,
-                    help="batches per launch in the timed region (gvl_reconstruct_many; a step is still ONE batch)")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="HIP streams the launches of the timed region rotate over = launches in flight (4 x 5 batches: a "
+                         "20-step region is in flight as a whole; measured against 2 / 3, profiles/r04_pipe_experiments.txt)")
+    ap.add_argument("--many", type=int, default=5,
+                    help="batches per launch (gvl_reconstruct_many: ONE grid over the group, what the native loader submits per "
+                         "group; a step is still ONE batch).  1 = a launch per batch (round 3's measurement)")
     ap.add_argument("--min-region-ms", type=float, default=1000.0,
                     help="GPU time to sample per timed leg (repeated K-step regions)")
     ap.add_argument("--max-regions", type=int, default=20000)
@@ -377,6 +393,7 @@ def main() -> None:
     _sref = [_C.byref(s_[1]) for s_ in slots]
     _sptr = [_C.c_void_p(s_.cuda_stream) for s_ in streams]
     _fn = dev.lib.gvl_reconstruct
+    _many = dev.lib.gvl_reconstruct_many
 
     def step_pipelined(i: int) -> None:
         # a batch is independent of the previous one: the loader keeps `--streams` batches in
@@ -390,20 +407,28 @@ def main() -> None:
             raise RuntimeError("gvl_reconstruct failed")
 
     class ManyStepper:
-        """--many G: steps are gathered into launches of G batches (gvl_reconstruct_many), launch g on
-        stream g % streams; flush() sends the partial last group of a region."""
+        """--many G: steps are gathered into launches of G batches (gvl_reconstruct_many: one grid over the group), launch g on
+        stream g % streams; flush() sends the partial last group of a region.  hot: every launch re-reads the first G batches."""
 
-        def __init__(self):
+        def __init__(self, use_streams, hot=False):
             self.pending, self.g, self.cache, self.group = 0, 0, {}, G
+            self.streams, self.hot = use_streams, hot
+            self.sp = [_C.c_void_p(s_.cuda_stream) for s_ in use_streams]
 
         def pack(self, g, size):
-            key = (g % (n_rot // G if n_rot >= G else 1), size, g % (len(streams) + 1))
+            key = (0 if self.hot else g % (n_rot // G if n_rot >= G else 1), size, g % (len(streams) + 1))
             p = self.cache.get(key)
             if p is None:
                 b0, s0 = key[0] * G, key[2] * G
                 p = self.cache[key] = dev.pack_many([batches[(b0 + i) % n_rot] for i in range(size)],
                                                     [slots[s0 + i][1] for i in range(size)])
             return p
+
+        def prebuild(self, sizes):
+            for g in range(max(1, n_rot // G) * (len(streams) + 1)):     # the argument arrays, ahead of the timed code
+                for size in sizes:
+                    if size:
+                        self.pack(g, size)
 
         def __call__(self, i):
             self.pending += 1
@@ -412,7 +437,9 @@ def main() -> None:
 
         def flush(self):
             if self.pending:
-                dev.launch_many(self.pack(self.g, self.pending), streams[self.g % len(streams)])
+                b, o, n = self.pack(self.g, self.pending)
+                if _many(_dref, b, o, n, self.sp[self.g % len(self.sp)]):
+                    raise RuntimeError("gvl_reconstruct_many failed")
                 self.g += 1
                 self.pending = 0
 
@@ -431,13 +458,13 @@ def main() -> None:
         k_all = int(t.item())
     tm = Timer(torch, dist, backend, streams, args.min_region_ms, args.max_regions, args.max_leg_s)
     steps = args.steps
+    step_kern, step_hot_k = step_single, step_hot
     if G > 1:
-        step_pipelined = ManyStepper()
-        for g in range(max(1, n_rot // G) * (len(streams) + 1)):     # build the argument arrays ahead of the timed code
-            step_pipelined.pack(g, G)
-        if steps % G:
-            for g in range(max(1, n_rot // G) * (len(streams) + 1)):
-                step_pipelined.pack(g, steps % G)
+        step_pipelined = ManyStepper(streams)
+        step_kern = ManyStepper([stream])
+        step_hot_k = ManyStepper([stream], hot=True)
+        for st_ in (step_pipelined, step_kern, step_hot_k):
+            st_.prebuild((G, steps % G))
     flush = getattr(step_pipelined, "flush", lambda: None)
 
     # ---- warmup, then the contract region: EXACTLY K steps between barrier + synchronize ----
@@ -459,24 +486,37 @@ def main() -> None:
     # ---- the same region repeated; GPU time per region from HIP events ---------------------
     region_ms, n_regions, spans = tm.measure(step_pipelined, steps, streams)
     # ---- the kernel's own duration: K launches back to back on ONE stream ---------------------
-    kern_region_ms, n_kregions, _ = tm.measure(step_single, steps, [stream])
-    kern_ms = kern_region_ms / steps
+    # (--many G: a launch = one grid over G batches; its duration = the region's / launches, G x the bytes per launch)
+    kern_region_ms, n_kregions, _ = tm.measure(step_kern, steps, [stream])
+    kern_ms = kern_region_ms * G / steps
     hot_ms = None
     if not args.no_hot:
-        hot_ms = tm.measure(step_hot, steps, [stream])[0] / steps
+        hot_ms = tm.measure(step_hot_k, steps, [stream])[0] * G / steps
     # ---- sustained: seconds of back-to-back cold batches, the timed region's schedule, ONE event pair ----
     sustained = None
     if args.sustained_s > 0:
         import ctypes as C
         import math
 
-        period = math.lcm(n_rot, n_slots, len(streams))
-        period = min(period, 4096 - 4096 % len(streams))
         sp = [C.c_void_p(s_.cuda_stream) for s_ in streams]
-        calls = [(C.byref(dev.c), C.byref(batches[j % n_rot].c), C.byref(slots[j % n_slots][1]), sp[j % len(streams)])
-                 for j in range(period)]
+        if G > 1:
+            n_groups = max(1, n_rot // G) * (len(streams) + 1)
+            period = math.lcm(n_groups, len(streams))
+            period = min(period, 4096 - 4096 % len(streams))
+            packs = [step_pipelined.pack(j, G) for j in range(period)]
+            calls = [(C.byref(dev.c), packs[j][0], packs[j][1], packs[j][2], sp[j % len(streams)]) for j in range(period)]
+            sus_fn = dev.lib.gvl_reconstruct_many
+        else:
+            period = math.lcm(n_rot, n_slots, len(streams))
+            period = min(period, 4096 - 4096 % len(streams))
+            calls = [(C.byref(dev.c), C.byref(batches[j % n_rot].c), C.byref(slots[j % n_slots][1]), sp[j % len(streams)])
+                     for j in range(period)]
+            sus_fn = dev.lib.gvl_reconstruct
         clk0 = gpu_clocks(dev_index)
-        sus_ms, sus_n, sus_host, sus_launch = tm.sustained(calls, dev.lib.gvl_reconstruct, streams, args.sustained_s, region_ms / steps)
+        sus_ms, sus_n, sus_host, sus_launch = tm.sustained(calls, sus_fn, streams, args.sustained_s, region_ms / steps * G)
+        sus_ms /= G                                   # (a call = G steps)
+        sus_n *= G
+        tm.last_thirds = [t / G for t in tm.last_thirds]
         clk1 = gpu_clocks(dev_index)
         sustained = {"ms_per_step": sus_ms, "steps": sus_n, "seconds": sus_ms * sus_n * 1e-3,
                      "windows_per_s": k_all / (sus_ms * 1e-3),
@@ -487,8 +527,9 @@ def main() -> None:
                      "steady_windows_per_s": k_all / (tm.last_thirds[-1] * 1e-3),
                      "host_enqueue_s": sus_host, "host_us_per_launch_unthrottled": sus_launch * 1e6,
                      "host_bound": bool(sus_launch * 1e3 > 0.9 * sus_ms),
-                     "how": "back-to-back gvl_reconstruct launches, step i on stream i % streams, rotating cold batches, "
-                            "one HIP event pair around all of them (no gate kernel, no synchronisation in between)",
+                     "how": ("back-to-back gvl_reconstruct_many launches of %d batches each, launch g on stream g %% streams" % G if G > 1 else
+                             "back-to-back gvl_reconstruct launches, step i on stream i % streams")
+                            + ", rotating cold batches, one HIP event pair around all of them (no gate kernel, no synchronisation in between)",
                      "clocks_before": clk0, "clocks_after": clk1}
     # ---- single-batch latency, host wall clock: launch -> synchronize --------
     lat = []
@@ -518,19 +559,25 @@ def main() -> None:
         gather_ms = tm.allmax([float(np.median(ts)) * 1e3])[0]
 
     lean = (dev.ref4 is not None and dev.slot_rec is not None and L <= 2048 and L % 4 == 0
-            and (int(os.environ.get("GVL_DBG", "0")) & ~(2 | 4 | 32768 | 65536 | 262144 | 524288)) == 0)
+            and (int(os.environ.get("GVL_DBG", "0")) & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 33554432 | 67108864)) == 0)
+    piped = lean and G > 1 and K * G >= int(os.environ.get("GVL_PIPE_MIN_ROWS", "8192")) and not (int(os.environ.get("GVL_DBG", "0")) & 67108864)
     if rank == 0:
         ms_per_step = region_ms / steps
-        abytes = algorithmic_bytes_per_window(L, mean_v, args.haps, True) * K
-        achieved = abytes / (kern_ms * 1e-3) / 1e9
+        abytes = algorithmic_bytes_per_window(L, mean_v, args.haps, True) * K      # per batch
+        lbytes = abytes * G                                                        # per launch: one grid over G batches
+        achieved = lbytes / (kern_ms * 1e-3) / 1e9
         pipelined = abytes / (ms_per_step * 1e-3) / 1e9
         traffic = None
         tf = REPO / "profiles" / "traffic.json"
         if tf.exists():
             try:
-                traffic = json.loads(tf.read_text()).get(
-                    f"{args.workload}{'+haps' if args.haps else ''}@{args.scale}" + ("" if n_rot > 1 else "@hot")
-                    + ("" if lean or args.workload != "cfg3" else "@allpurpose"))
+                tj = json.loads(tf.read_text())
+                key = (f"{args.workload}{'+haps' if args.haps else ''}@{args.scale}" + ("" if n_rot > 1 else "@hot")
+                       + ("" if lean or args.workload != "cfg3" else "@allpurpose"))
+                # (the pipelined kernel's own PMC pass is keyed ...@pipelined, bytes per BATCH; a launch moves G times that)
+                traffic = tj.get(key + "@pipelined", tj.get(key)) if piped else tj.get(key)
+                if traffic is not None and G > 1:
+                    traffic = traffic * G
             except Exception:
                 traffic = None
         sizes = ds.nbytes()
@@ -563,7 +610,7 @@ def main() -> None:
                 "layouts": {"slot_rec": dev.slot_rec is not None, "geno_rec": dev.geno_rec is not None, "ref4": dev.ref4 is not None,
                             "note": None if dev.slot_rec is not None else
                             "slot_rec NOT built (128 B x genotype slots exceeds a quarter of the free HBM): rows find their records through the CSR"},
-                "kernel_path": "lean" if lean else "all-purpose",
+                "kernel_path": ("lean, pipelined over rows" if piped else "lean") if lean else "all-purpose",
             },
             "timing": {
                 "how": "median of repeated K-step regions, each between barrier+synchronize; GPU time of a region from "
@@ -576,12 +623,16 @@ def main() -> None:
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "frac_of_copy_ceiling": achieved / HBM_COPY_GBS,
-                "kernel": ("recon_lean_kernel<onehot, haps=%s> (nibble-packed reference; rows it cannot express run the all-purpose body inside the same launch)" % ("true" if args.haps else "false")
+                "kernel": (("recon_lean_rows_kernel<onehot, haps=%s> (ONE grid over the launch's %d batches; a wave takes rows w, w + W, ... and keeps "
+                            "its next row's window + slot line in flight by LDS-DMA under the stores of the row in hand; nibble-packed reference)"
+                            % ("true" if args.haps else "false", G)) if piped else
+                           "recon_lean_kernel<onehot, haps=%s> (nibble-packed reference; rows it cannot express run the all-purpose body inside the same launch)" % ("true" if args.haps else "false")
                            if lean else "reconstruct_kernel<OH_LC, haps=%s, annot=false>" % ("true" if args.haps else "false")),
-                "kernel_ms": kern_ms,
-                "kernel_ms_how": "HIP events around K back-to-back launches on one stream (rotating batches), median region",
-                "kernel_ms_hot": hot_ms, "hot_frac": None if hot_ms is None else abytes / (hot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_launch": abytes,
+                "kernel_ms": kern_ms, "batches_per_launch": G, "kernel_ms_per_batch": kern_ms / G,
+                "kernel_ms_how": "HIP events around the K steps' launches back to back on ONE stream (rotating batches), median region, per launch"
+                                 + (" = one grid over %d batches" % G if G > 1 else ""),
+                "kernel_ms_hot": hot_ms, "hot_frac": None if hot_ms is None else lbytes / (hot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": lbytes, "algorithmic_bytes_per_batch": abytes,
                 "pipelined_GBps": pipelined, "pipelined_frac": pipelined / HBM_PEAK_GBS,
                 "pipelined_frac_of_copy_ceiling": pipelined / HBM_COPY_GBS,
                 "single_batch_wall_ms": single_ms,

@@ -4039,9 +4039,9 @@ extern "C" {
 
 int gvl_abi_version(void) { return GVL_ABI_VERSION; }
 int gvl_set_debug_flags(int flags) { g_debug_override = flags; return GVL_OK; }
-#ifdef GVL_DIAG
+// diagnostics (not in gvl_hip.h): a device buffer the kernels may leave counters / time stamps in.  Phase stamps need a
+// -DGVL_DIAG build; lean_solo_rows counts the rows and waves that reach it in words 0 and 1 in every build (tools/pipe_deferred.py).
 void gvl_diag_set_stamps(void *buf) { g_stamps = (u64 *)buf; }
-#endif
 const char *gvl_last_error(void) { return g_err; }
 
 int gvl_async_error(int clear) {
@@ -4351,9 +4351,12 @@ static int launch_lean_rows(const ReconArgs *RAs, int n, void *stream) {
     }
     A.n_rows = (int)total;
     static const int cap_env = pipe_env("GVL_PIPE_WAVES", 8192);
-    i64 waves = (debug_flags() & 33554432) ? LEAN_WAVES : (cap_env < LEAN_WAVES ? LEAN_WAVES : cap_env);
-    if (waves > total) waves = total;
-    if (waves * PIPE_MAX_ROWS < total) waves = (total + PIPE_MAX_ROWS - 1) / PIPE_MAX_ROWS;
+    const i64 cap = (debug_flags() & 33554432) ? LEAN_WAVES : (cap_env < LEAN_WAVES ? LEAN_WAVES : cap_env);
+    // every wave the same number of rows (20 480 rows on 8 192 waves would be 3 rows for half of them and 2 for the others: the
+    // launch ends a third late): R = rows per wave at `cap` waves, then as few waves as R rows each need
+    i64 rows_per_wave = (total + cap - 1) / cap;
+    if (rows_per_wave > PIPE_MAX_ROWS) rows_per_wave = PIPE_MAX_ROWS;
+    const i64 waves = (total + rows_per_wave - 1) / rows_per_wave;
     const unsigned grid = (unsigned)((waves + LEAN_WAVES - 1) / LEAN_WAVES);
     const dim3 g(grid), b(LEAN_THREADS);
     hipStream_t s = (hipStream_t)stream;

@@ -143,7 +143,7 @@ class DeviceHapsDataset:
         (``_draw_override``), so that an index draws the same whatever batch, batch size or rank delivers it."""
         ov = getattr(self, "_draw_override", None)
         if ov is not None:
-            return ov
+            return ov[0], ov[1]
         self._counter += 1
         return self.seed, self._counter
 
@@ -453,7 +453,13 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
             from .sharding import splitmix64
 
             ov = getattr(self, "_draw_override", None)
-            seed = splitmix64(self.seed ^ splitmix64(self._counter + 1)) if ov is None else splitmix64(ov[0] ^ splitmix64(ov[1]))
+            # a fresh base seed per BATCH (_reconstruct.py:215-222).  Under a loader: keyed by (draw seed, epoch + 1, batch number of
+            # the epoch) exactly as the native loop's batch_seeds_kernel keys it, so both submit loops fill alike
+            if ov is None:
+                seed = splitmix64(self.seed ^ splitmix64(self._counter + 1))
+            else:
+                j = int(ov[2]) if len(ov) > 2 else 0
+                seed = splitmix64(ov[0] ^ splitmix64(((int(ov[1]) << 32) + j) & 0xFFFFFFFFFFFFFFFF))
         base = super().__getitem__(idx)
         dev, d = self.dev, self.dev.device
         b, P, L = int(base.idx.numel()), self.ploidy, self.output_length
@@ -488,12 +494,14 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
 
     def to_dataloader(self, batch_size: int = 1, shuffle: bool = False, sampler=None, drop_last: bool = False,
                       generator=None, in_flight: int = 3, rank: int = 0, world_size: int = 1, seed: int = 0,
-                      threaded: bool = False, group: int = 1, python_loop: bool = False) -> "DeviceLoader":
+                      threaded: bool = False, group: int = 1, python_loop: bool = False,
+                      draw_stream: int | None = None, pad_to: int | None = None) -> "DeviceLoader":
         """The native ring carries the tracks too (``gvl_tracks_batch`` per batch into the slot, per-batch
         FlankSample seeds computed on the device); ``python_loop=True`` (or a custom sampler) submits every
-        batch from Python instead and lets it own its memory."""
+        batch from Python instead and lets it own its memory.  ``draw_stream`` / ``pad_to`` as in
+        :meth:`DeviceHapsDataset.to_dataloader`."""
         return DeviceLoader(self, batch_size, shuffle, sampler, drop_last, generator, in_flight, rank, world_size,
-                            seed, threaded, group, python_loop=python_loop)
+                            seed, threaded, group, python_loop=python_loop, draw_stream=draw_stream, pad_to=pad_to)
 
 
 def splice_plan_device(lengths: torch.Tensor, pair_len: torch.Tensor):
@@ -957,7 +965,7 @@ class DeviceLoader:
             k += 1
             st.wait_stream(torch.cuda.current_stream(self.ds.dev.device))
             with torch.cuda.stream(st):
-                self.ds._draw_override = draw
+                self.ds._draw_override = (draw[0], draw[1], k - 1)      # (k - 1: this batch's number in the epoch)
                 try:
                     batch = self.ds[idx]
                 finally:

@@ -390,6 +390,55 @@ def test_haps_tracks_dataset_matches_oracle(oracle, dbg):
 
 
 @pytest.mark.gpu
+def test_random_fill_seeds_are_per_batch_and_the_same_in_both_submit_loops():
+    """Non-deterministic datasets draw a fresh FlankSample base seed per BATCH (_reconstruct.py:215-222).  The native loop keys it
+    by (draw seed, epoch + 1, batch number) on the device (batch_seeds_kernel); the Python submit loop must key it the same way
+    -- it once pinned ONE seed for the whole epoch -- so: both loops deliver identical tracks, batch by batch,
+    and the insertion fills of two batches of an epoch differ."""
+    from genvarloader_amd import HapsDevice
+    from genvarloader_amd.loader import DeviceHapsTracksDataset
+
+    R, S, P, L = 4, 6, 2, 600
+    st, full_regions, go, gv = _grid_dataset(43, R, S, P, L, indel_frac=0.9, slack=30)
+    rng = np.random.default_rng(8)
+    starts, ends, vals, offs = [], [], [], [0]
+    for r in range(R):
+        for s_ in range(S):
+            pos = int(full_regions[r, 1]) - 20
+            while pos < int(full_regions[r, 2]) + 40:
+                w = int(rng.geometric(1 / 9))
+                starts.append(pos); ends.append(pos + w); vals.append(float(rng.random() * 5)); pos += w
+            offs.append(len(starts))
+    tracks = {"t": (np.array(starts, np.int32), np.array(ends, np.int32), np.array(vals, np.float32), np.array(offs, np.int64))}
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+
+    def epoch(python_loop):
+        ds = DeviceHapsTracksDataset(dev, full_regions, S, P, tracks=tracks, strategy_id=3, param=8.0, base_seed=None,
+                                     deterministic=False, seed=5, output_length=L, onehot=False, haps=True)
+        dl = ds.to_dataloader(batch_size=6, shuffle=False, python_loop=python_loop, draw_stream=1)
+        dl.set_epoch(2)
+        return [(b.idx.clone(), b.tracks.clone()) for b in dl]
+
+    nat, py = epoch(False), epoch(True)
+    assert len(nat) == len(py) == 4
+    for (i0, t0), (i1, t1) in zip(nat, py):
+        assert torch.equal(i0, i1)
+        assert torch.equal(t0.view(torch.int32), t1.view(torch.int32))
+    # the same dataset indices in another batch slot of the epoch get another seed: deliver the epoch's queries rotated by one batch
+    ds = DeviceHapsTracksDataset(dev, full_regions, S, P, tracks=tracks, strategy_id=3, param=8.0, base_seed=None,
+                                 deterministic=False, seed=5, output_length=L, onehot=False, haps=True)
+    order = torch.arange(R * S)
+    rot = torch.cat([order[6:], order[:6]])
+    dl = ds.to_dataloader(batch_size=6, sampler=[rot[i:i + 6].tolist() for i in range(0, R * S, 6)], draw_stream=1)
+    dl.set_epoch(2)
+    shifted = [(b.idx.clone(), b.tracks.clone()) for b in dl]
+    assert torch.equal(shifted[0][0].cpu(), py[1][0].cpu())               # batch 1's indices, now delivered as batch 0
+    assert not torch.equal(shifted[0][1].view(torch.int32), py[1][1].view(torch.int32))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dbg", [0, 1024, 8192, 2097152, 4194304],
                          ids=["bucket-index", "exact-searches", "painter-image-path", "intervals-without-window", "painter-first"])
 def test_tracks_batch_long_rows_jitter_and_dense_lists(oracle, dbg):
