@@ -283,6 +283,80 @@ class Timer:
         return ms / n, n, t_host, t_burst / burst
 
 
+def secondary_ragged(torch, dev, ds, qsets, rc_on, streams, budget_s: float = 3.0) -> dict:
+    """cfg3 with RAGGED rows (output_length = -1: the reference's default ``ds[r, s]`` shape, _haps.py:794-811,
+    src/ffi/mod.rs:794-815) on the same cold genome-scale dataset: per batch the sizing kernels (``gvl_hap_offsets``:
+    query-mode length deltas -> row lengths -> exclusive scan) and the reconstruct launch that READS those offsets,
+    no host round trip (what the native loader submits per ragged batch).  us per batch with the region's launches on
+    ``streams`` (in flight) and on one stream (alone)."""
+    import ctypes as C
+
+    lib = dev.lib
+    P = ds.ploidy
+    n_rot = min(len(qsets), 64)
+    prep = []
+    mx_all, tot_all, rows = 0, 0, 0
+    for q in qsets[:n_rot]:
+        r = ds.request(q, rc=rc_on)
+        b0 = dev.prepare_batch(r["regions"], r["shifts"], r["geno_offset_idx"], -1, to_rc=r["to_rc"])
+        oo, tm, _ = dev.hap_offsets(b0)
+        tot, mx = (int(v) for v in tm.cpu().tolist())
+        mx_all, tot_all, rows = max(mx_all, mx), tot_all + tot, rows + b0.n_rows
+        prep.append((b0, oo, tm, r))
+    K = prep[0][0].n_rows
+    cap = K * mx_all                                   # bases a slot holds: every row at the longest row's length
+    runs = [(b0, oo, tm, dev.prepare_batch(r["regions"], r["shifts"], r["geno_offset_idx"], -1, None, None, r["to_rc"], oo, max_row_len=mx_all))
+            for b0, oo, tm, r in prep]
+    slots = [dev.alloc_output(runs[0][3], cap, haps=False, onehot=True) for _ in range(len(streams) + 1)]
+    dref = C.byref(dev.c)
+    calls = [(C.byref(b0.c), C.c_void_p(oo.data_ptr()), C.c_void_p(tm.data_ptr()), C.byref(b1.c)) for b0, oo, tm, b1 in runs]
+    sref = [C.byref(s_[1]) for s_ in slots]
+
+    def step(i, sps):
+        # (a batch always runs on the SAME stream: its offsets buffer is rewritten by every pass, and nothing orders two streams)
+        j = i % n_rot
+        a, sp = calls[j], sps[j % len(sps)]
+        if lib.gvl_hap_offsets(dref, a[0], None, a[1], a[2], sp) or lib.gvl_reconstruct(dref, a[3], sref[i % len(sref)], sp):
+            raise RuntimeError("ragged step failed")
+
+    def leg(use, seconds):
+        sp = [C.c_void_p(s_.cuda_stream) for s_ in use]
+        for i in range(3 * len(use)):
+            step(i, sp)
+        torch.cuda.synchronize()
+        n = int(max(60, seconds / 12e-6))
+        n -= n % len(use)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start = torch.cuda.Event()
+        start.record(use[0])
+        for s_ in use[1:]:
+            s_.wait_event(start)
+        e0.record(use[0])
+        for i in range(n):
+            step(i, sp)
+        for s_ in use[1:]:
+            ev = torch.cuda.Event()
+            ev.record(s_)
+            use[0].wait_event(ev)
+        e1.record(use[0])
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    ms_flight = leg(streams[:3], budget_s * 0.6)
+    ms_alone = leg(streams[:1], budget_s * 0.4)
+    mean_len = tot_all / max(rows, 1)
+    mean_v = float((dev.geno_offsets[1][prep[0][0].geno_offset_idx.reshape(-1)] - dev.geno_offsets[0][prep[0][0].geno_offset_idx.reshape(-1)]).double().mean())
+    abytes = (mean_len * 5 + 28.0 * mean_v + 61.0) * K
+    return {
+        "workload": f"cfg3 ragged: {K} windows, output_length = -1 (row = region + its haplotype's length delta, mean {mean_len:.1f} bases, "
+                    f"longest {mx_all}), one-hot (total, 4); per batch gvl_hap_offsets + gvl_reconstruct, cold rotating batches",
+        "ms_per_step": ms_flight, "windows_per_s": K / (ms_flight * 1e-3), "batches_in_flight": min(3, len(streams)),
+        "ms_per_step_alone": ms_alone, "algorithmic_bytes_per_step": abytes,
+        "step_frac": abytes / (ms_flight * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_alone": abytes / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "kernel": "recon_lean_kernel / reconstruct_kernel as gvl_reconstruct routes ragged rows (DESIGN 4.0)",
+    }
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -314,6 +388,8 @@ def main() -> None:
     ap.add_argument("--strong", action="store_true", help="N > 1: split ONE batch across the ranks (strong scaling)")
     ap.add_argument("--gather", action="store_true", help="N > 1: also time the RCCL all-gather of the one-hot shards")
     ap.add_argument("--no-hot", action="store_true", help="skip the extra cache-hot kernel timing")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short ragged-cfg3 and cfg4 legs of the default run (N = 1 only; `secondary` in the line)")
     args = ap.parse_args()
 
     if args.cpu_only:
@@ -558,6 +634,39 @@ def main() -> None:
         assert g.shape[1:] == oh.shape[1:] and g.shape[0] >= K
         gather_ms = tm.allmax([float(np.median(ts)) * 1e3])[0]
 
+    # ---- secondary legs (N = 1, default workload): the reference's default ragged rows and BASELINE config 4, a few seconds each ----
+    secondary = None
+    if world == 1 and args.workload == "cfg3" and not args.no_secondary and not args.haps:
+        secondary = {}
+        t_s = time.perf_counter()
+        skip = os.environ.get("GVL_BENCH_SKIP", "")
+        try:
+            if "ragged" in skip:
+                raise RuntimeError("skipped (GVL_BENCH_SKIP)")
+            secondary["ragged"] = secondary_ragged(torch, dev, ds, qsets, rc_on, streams)
+        except Exception as exc:      # (a secondary leg never takes the headline down)
+            secondary["ragged"] = {"error": repr(exc)}
+        secondary["ragged_s"] = round(time.perf_counter() - t_s, 2)
+        t_s = time.perf_counter()
+        try:
+            if "cfg4" in skip:
+                raise RuntimeError("skipped (GVL_BENCH_SKIP)")
+            from tools import bench_cfg4
+
+            class _A:
+                gpus, steps, warmup, min_region_ms, max_regions = 1, 20, 5, 1200.0, 400
+            c4 = bench_cfg4.measure(_A, init_dist=False)
+            secondary["cfg4"] = {
+                "workload": c4["config"]["workload"], "ms_per_step": c4["ms_per_step"], "windows_per_s": c4["value"],
+                "step_frac": c4["roofline"]["step_frac"], "step_GBps": c4["roofline"]["step_GBps"],
+                "step_algorithmic_bytes": c4["roofline"]["step_algorithmic_bytes"],
+                "kernel_ms": c4["roofline"]["kernel_ms"], "kernel": c4["roofline"]["kernel"], "kernel_frac": c4["roofline"]["frac"],
+                "kernels": c4["kernels"], "loop": c4["config"]["loop"], "steps": c4["steps"], "regions": c4["timing"]["regions"],
+            }
+        except Exception as exc:
+            secondary["cfg4"] = {"error": repr(exc)}
+        secondary["cfg4_s"] = round(time.perf_counter() - t_s, 2)
+
     lean = (dev.ref4 is not None and dev.slot_rec is not None and L <= 2048 and L % 4 == 0
             and (int(os.environ.get("GVL_DBG", "0")) & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 33554432 | 67108864)) == 0)
     piped = lean and G > 1 and K * G >= int(os.environ.get("GVL_PIPE_MIN_ROWS", "8192")) and not (int(os.environ.get("GVL_DBG", "0")) & 67108864)
@@ -641,6 +750,8 @@ def main() -> None:
         if sustained is not None:
             res["sustained"] = sustained
             res["sustained_ms_per_step"] = sustained["ms_per_step"]
+        if secondary is not None:
+            res["secondary"] = secondary
         if gather_ms is not None:
             res["gather_ms"] = gather_ms
             res["gather_bytes_per_rank"] = K * L * 4

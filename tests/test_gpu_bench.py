@@ -13,7 +13,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 REPO = Path(__file__).resolve().parent.parent
-SMALL = ["--scale", "small", "--queries", "16384", "--rotate", "8", "--min-region-ms", "2", "--cpu-budget", "1.5"]
+SMALL = ["--scale", "small", "--queries", "16384", "--rotate", "8", "--min-region-ms", "2", "--cpu-budget", "1.5", "--no-secondary"]
 
 
 def _free_port():
@@ -51,6 +51,20 @@ def test_bench_contract_single_gpu():
     assert c["kind"] == "port" and c["value"] > 0 and "1" in c["threads_sweep"] and c["cores"] >= 1
     assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_bench_secondary_legs():
+    """The default run's short extra legs: ragged cfg3 rows (the reference's default output) and the cfg4 step, under
+    `secondary` next to the unchanged headline (here on a small dataset and a small cfg4 grid)."""
+    args = [a for a in SMALL if a != "--no-secondary"]
+    d = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--sustained-s", "0", *args],
+             env={"GVL_CFG4_R": "2", "GVL_CFG4_S": "64"})
+    sec = d["secondary"]
+    rg, c4 = sec["ragged"], sec["cfg4"]
+    assert "error" not in rg and "error" not in c4, sec
+    assert rg["ms_per_step"] > 0 and 0 < rg["step_frac"] < 1 and rg["ms_per_step_alone"] >= 0.5 * rg["ms_per_step"]
+    assert c4["ms_per_step"] > 0 and 0 < c4["step_frac"] < 1 and c4["kernel_ms"] > 0 and "131072" in c4["workload"]
+    assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]          # the headline is cfg3's
 
 
 @pytest.mark.parametrize("extra", [["--gather"], ["--strong", "--gather"]], ids=["weak+gather", "strong+gather"])

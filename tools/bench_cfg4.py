@@ -62,6 +62,14 @@ def build(device, R=16, S=64, P=2, L=131072, seed=20260802 + 4):
 
 
 def main(args) -> None:
+    res = measure(args)
+    if res is not None:
+        print(json.dumps(res), flush=True)
+
+
+def measure(args, init_dist=True):
+    """The cfg4 step + its kernels -> the bench line as a dict (rank 0; None on the other ranks).  bench.py's default run calls
+    this with a short budget for its ``secondary.cfg4`` keys (init_dist=False: single process, no process group)."""
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -72,7 +80,7 @@ def main(args) -> None:
     torch.cuda.set_device(local)
     dist = None
     backend = os.environ.get("GVL_BENCH_BACKEND", "nccl")
-    if world > 1:
+    if world > 1 and init_dist:
         import torch.distributed as dist
 
         dist.init_process_group(backend, **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
@@ -228,7 +236,9 @@ def main(args) -> None:
                 "tracks_path": "realign_tracks_kernel<PAINT> (no scratch track)" if fused else "intervals_to_tracks_tiled_kernel + realign_tracks_kernel",
                 "sum_of_kernels_ms": t_recon + (t_tracks if fused else t_realign + t_paint)},
         }
-        print(json.dumps(res), flush=True)
+    else:
+        res = None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return res
