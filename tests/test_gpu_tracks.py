@@ -171,6 +171,51 @@ def test_cfg4_full_haps_and_track(ffi, oracle, tpath):
     print(f"\ncfg4: V/row={bt.mean_variants:.0f}  haps+onehot {t_h*1e3:.2f} ms  track {t_t*1e3:.2f} ms (host-timed, incl. upload)")
 
 
+def test_cfg4_full_size_batch_through_the_native_ring(oracle):
+    """BASELINE configs[3] as bench.py's cfg4 step runs it: ONE full-size batch (256 windows x 131 072 bp) from dataset
+    indices through DeviceHapsTracksDataset's native ring -- the lean kernel's chunked form for the haplotypes (one-hot +
+    bytes) and realign_tracks_kernel<PAINT> for the track (a BigWig-like, `tile_complete` interval set, realigned straight
+    from its intervals) -- against the haplotype oracle and the oracle's fused paint + realign."""
+    import torch
+
+    from tools import bench_cfg4
+
+    R, S, P, L = 2, 64, 2, 131072
+    st, dev, ds, tracks, _ = bench_cfg4.build("cuda:0", R, S, P, L, seed=99, contig=48 << 20)
+    assert all(ds._tile_complete)
+    full_regions = ds.full_regions.cpu().numpy() if hasattr(ds.full_regions, "cpu") else np.asarray(ds.full_regions)
+    go, gv = dev.geno_offsets.cpu().numpy(), dev.geno_v_idxs.cpu().numpy()
+    batches = list(ds.to_dataloader(batch_size=R * S, shuffle=True, seed=3, in_flight=1, group=1))
+    assert len(batches) == 1
+    batch = batches[0]
+    torch.cuda.synchronize()
+    idx = batch.idx.cpu().numpy()
+    assert sorted(idx.tolist()) == list(range(R * S))
+    r_idx, s_idx = np.unravel_index(idx, (R, S))
+    regions = np.ascontiguousarray(full_regions[r_idx])
+    goi = np.ravel_multi_index((r_idx[:, None], s_idx[:, None], np.arange(P)), (R, S, P))
+    to_rc = np.repeat(regions[:, 3] == -1, P)
+    shifts = np.zeros_like(goi, dtype=np.int32)
+    exp_h, _, exp_oh = oracle.reconstruct_haplotypes_fused(
+        regions, shifts, goi, go, gv, st.v_starts, st.ilens, st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets,
+        st.pad_char, L, None, None, to_rc, True, onehot=True, n_threads=8)
+    np.testing.assert_array_equal(batch.haps.cpu().numpy().ravel(), exp_h)
+    np.testing.assert_array_equal(batch.onehot.cpu().numpy().reshape(-1, 4), exp_oh)
+    diffs = oracle.get_diffs_sparse(goi, gv, go, st.ilens, None, None, regions[:, 1], regions[:, 2], st.v_starts)
+    tlen = (regions[:, 2] - regions[:, 1]).astype(np.int64) - np.minimum(diffs.min(axis=1), 0)
+    track_offsets = np.concatenate([[0], np.cumsum(tlen)]).astype(np.int64)
+    out_offsets = np.arange(len(idx) * P + 1, dtype=np.int64) * L
+    a, e, v, io = tracks["cov"]
+    exp = np.zeros(len(idx) * P * L, np.float32)
+    oracle.intervals_and_realign_track_fused(exp, out_offsets, regions, shifts, goi, gv, go, st.v_starts, st.ilens, idx.astype(np.int64),
+                                             a, e, v, io, track_offsets, np.array([0.0]), 0, 0, None, None, to_rc)
+    got = batch.tracks[:, 0].contiguous().cpu().numpy().ravel()
+    np.testing.assert_array_equal(bits(got), bits(exp))
+    # size-independent properties at full size: at most one hot channel per base, the one-hot is the bytes' one-hot
+    assert int(batch.onehot.sum(dim=-1).max()) <= 1
+    assert int(batch.onehot.sum()) == sum(int((batch.haps == c).sum()) for c in b"ACGT")
+
+
 def test_painting_dense_nested_and_gappy_intervals(ffi, oracle, tpath):
     """Painting beyond the tiled kernel's comfort zone: thousands of 1-3 bp intervals per 2048-value
     chunk (more candidates than one LDS tile -> the per-value kernel takes those chunks), long

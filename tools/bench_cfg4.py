@@ -32,14 +32,14 @@ def _traffic(key):
         return None
 
 
-def build(device, R=16, S=64, P=2, L=131072, seed=20260802 + 4):
+def build(device, R=16, S=64, P=2, L=131072, seed=20260802 + 4, contig=256 << 20):
     import torch
 
     from genvarloader_amd import HapsDevice, synth
     from genvarloader_amd.loader import DeviceHapsTracksDataset
 
     rng = np.random.default_rng(seed)
-    st = synth.make_static(rng, (256 << 20,), indel_frac=0.15)
+    st = synth.make_static(rng, (contig,), indel_frac=0.15)
     full_regions, go, gv = synth.make_grid(rng, st, R, S, P, L)
     starts, ends, vals, offs = [], [], [], [0]
     for r in range(R):
