@@ -283,77 +283,51 @@ class Timer:
         return ms / n, n, t_host, t_burst / burst
 
 
-def secondary_ragged(torch, dev, ds, qsets, rc_on, streams, budget_s: float = 3.0) -> dict:
+def secondary_ragged(torch, dev, ds, budget_s: float = 2.5) -> dict:
     """cfg3 with RAGGED rows (output_length = -1: the reference's default ``ds[r, s]`` shape, _haps.py:794-811,
-    src/ffi/mod.rs:794-815) on the same cold genome-scale dataset: per batch the sizing kernels (``gvl_hap_offsets``:
-    query-mode length deltas -> row lengths -> exclusive scan) and the reconstruct launch that READS those offsets,
-    no host round trip (what the native loader submits per ragged batch).  us per batch with the region's launches on
-    ``streams`` (in flight) and on one stream (alone)."""
-    import ctypes as C
+    src/ffi/mod.rs:794-815) on the same cold genome-scale dataset, FROM DATASET INDICES through the native loader
+    (``DeviceHapsDataset(output_length=-1).to_dataloader``: request prep once per epoch; per group of 16 batches one sizing --
+    query-mode length deltas -> row lengths -> offsets, on the device -- and ONE grid of the lean kernel's pipelined form
+    that reads those offsets; no host round trip).  Every window of the dataset is read once per epoch: cold.
+    -> us per 4096-window batch over chained epochs."""
+    from genvarloader_amd.loader import DeviceHapsDataset
 
-    lib = dev.lib
-    P = ds.ploidy
-    n_rot = min(len(qsets), 64)
-    prep = []
-    mx_all, tot_all, rows = 0, 0, 0
-    for q in qsets[:n_rot]:
-        r = ds.request(q, rc=rc_on)
-        b0 = dev.prepare_batch(r["regions"], r["shifts"], r["geno_offset_idx"], -1, to_rc=r["to_rc"])
-        oo, tm, _ = dev.hap_offsets(b0)
-        tot, mx = (int(v) for v in tm.cpu().tolist())
-        mx_all, tot_all, rows = max(mx_all, mx), tot_all + tot, rows + b0.n_rows
-        prep.append((b0, oo, tm, r))
-    K = prep[0][0].n_rows
-    cap = K * mx_all                                   # bases a slot holds: every row at the longest row's length
-    runs = [(b0, oo, tm, dev.prepare_batch(r["regions"], r["shifts"], r["geno_offset_idx"], -1, None, None, r["to_rc"], oo, max_row_len=mx_all))
-            for b0, oo, tm, r in prep]
-    slots = [dev.alloc_output(runs[0][3], cap, haps=False, onehot=True) for _ in range(len(streams) + 1)]
-    dref = C.byref(dev.c)
-    calls = [(C.byref(b0.c), C.c_void_p(oo.data_ptr()), C.c_void_p(tm.data_ptr()), C.byref(b1.c)) for b0, oo, tm, b1 in runs]
-    sref = [C.byref(s_[1]) for s_ in slots]
-
-    def step(i, sps):
-        # (a batch always runs on the SAME stream: its offsets buffer is rewritten by every pass, and nothing orders two streams)
-        j = i % n_rot
-        a, sp = calls[j], sps[j % len(sps)]
-        if lib.gvl_hap_offsets(dref, a[0], None, a[1], a[2], sp) or lib.gvl_reconstruct(dref, a[3], sref[i % len(sref)], sp):
-            raise RuntimeError("ragged step failed")
-
-    def leg(use, seconds):
-        sp = [C.c_void_p(s_.cuda_stream) for s_ in use]
-        for i in range(3 * len(use)):
-            step(i, sp)
-        torch.cuda.synchronize()
-        n = int(max(60, seconds / 12e-6))
-        n -= n % len(use)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        start = torch.cuda.Event()
-        start.record(use[0])
-        for s_ in use[1:]:
-            s_.wait_event(start)
-        e0.record(use[0])
-        for i in range(n):
-            step(i, sp)
-        for s_ in use[1:]:
-            ev = torch.cuda.Event()
-            ev.record(s_)
-            use[0].wait_event(ev)
-        e1.record(use[0])
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n
-
-    ms_flight = leg(streams[:3], budget_s * 0.6)
-    ms_alone = leg(streams[:1], budget_s * 0.4)
-    mean_len = tot_all / max(rows, 1)
-    mean_v = float((dev.geno_offsets[1][prep[0][0].geno_offset_idx.reshape(-1)] - dev.geno_offsets[0][prep[0][0].geno_offset_idx.reshape(-1)]).double().mean())
+    P, bs = ds.ploidy, 2048
+    hds = DeviceHapsDataset(dev, ds.full_regions.cpu().numpy(), 1, P, output_length=-1, deterministic=True, seed=1)
+    dl = hds.to_dataloader(batch_size=bs, shuffle=True, in_flight=3, group=16)
+    n_b, tot_rows, tot_len, mx = 0, 0, 0, 0
+    sample = []
+    for batch in dl:                                   # a first epoch: warms up, and samples the row lengths
+        n_b += 1
+        if n_b <= 4:
+            sample.append(batch.sizes.clone())
+            tot_rows += int(batch.idx.numel()) * P
+    torch.cuda.synchronize()
+    for sz in sample:
+        t, m = (int(v) for v in sz.cpu().tolist())
+        tot_len, mx = tot_len + t, max(mx, m)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_ep = 0
+    while time.perf_counter() - t0 < budget_s or n_ep < 2:
+        for batch in dl:
+            pass
+        n_ep += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = dt / (n_ep * n_b) * 1e3
+    K = bs * P
+    mean_len = tot_len / max(tot_rows, 1)
+    mean_v = float((dev.geno_offsets[1] - dev.geno_offsets[0])[:1 << 20].double().mean())
     abytes = (mean_len * 5 + 28.0 * mean_v + 61.0) * K
     return {
-        "workload": f"cfg3 ragged: {K} windows, output_length = -1 (row = region + its haplotype's length delta, mean {mean_len:.1f} bases, "
-                    f"longest {mx_all}), one-hot (total, 4); per batch gvl_hap_offsets + gvl_reconstruct, cold rotating batches",
-        "ms_per_step": ms_flight, "windows_per_s": K / (ms_flight * 1e-3), "batches_in_flight": min(3, len(streams)),
-        "ms_per_step_alone": ms_alone, "algorithmic_bytes_per_step": abytes,
-        "step_frac": abytes / (ms_flight * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_alone": abytes / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "kernel": "recon_lean_kernel / reconstruct_kernel as gvl_reconstruct routes ragged rows (DESIGN 4.0)",
+        "workload": f"cfg3 ragged: {K} windows per batch, output_length = -1 (row = region + its haplotype's length delta, mean {mean_len:.1f} bases, "
+                    f"longest seen {mx}), one-hot (total, 4), from dataset indices through the native loader (in_flight 3, groups of 16), "
+                    f"{n_b} batches per epoch, every window read once per epoch",
+        "ms_per_step": ms, "windows_per_s": K / (ms * 1e-3), "epochs_timed": n_ep, "batches_per_epoch": n_b,
+        "algorithmic_bytes_per_step": abytes, "step_frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "kernel": "recon_lean_rows_kernel<onehot, ragged> (one grid per group of 16 batches) behind hap_lengths_group_kernel + hap_scan_group_kernel",
+        "how": "host clock over chained epochs (no synchronisation between them), steady state",
     }
 
 
@@ -643,7 +617,7 @@ def main() -> None:
         try:
             if "ragged" in skip:
                 raise RuntimeError("skipped (GVL_BENCH_SKIP)")
-            secondary["ragged"] = secondary_ragged(torch, dev, ds, qsets, rc_on, streams)
+            secondary["ragged"] = secondary_ragged(torch, dev, ds)
         except Exception as exc:      # (a secondary leg never takes the headline down)
             secondary["ragged"] = {"error": repr(exc)}
         secondary["ragged_s"] = round(time.perf_counter() - t_s, 2)

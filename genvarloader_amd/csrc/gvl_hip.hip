@@ -2420,6 +2420,64 @@ __global__ __launch_bounds__(256) void track_scan_batches_kernel(i64 *lengths, i
     }
 }
 
+// The ragged sizing of a whole GROUP of batches in two launches (the native loader's ragged groups; per batch it was two
+// latency-bound launches each, 16 us per batch alone -- twice the reconstruct grid's time).  The group's request arrays are
+// consecutive rows of the epoch table, its offsets live in the batches' own slots: a pointer per batch in the kernarg segment.
+struct HapGroupOut { i64 *offs[GVL_MANY_MAX]; i64 *sizes[GVL_MANY_MAX]; };
+__global__ __launch_bounds__(256) void hap_lengths_group_kernel(const DiffArgs A, const int *regions, i64 regions_stride, i64 rows_per_batch,
+                                                                 const HapGroupOut O) {
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.n_rows) return;
+    const int d = (int)row_diff(A, k);      // `as i32` truncation
+    const int *reg = regions + (k / A.ploidy) * regions_stride;
+    i64 len = imax((i64)(reg[2] - reg[1]) + d, 0);                  // src/ffi/mod.rs:801-807
+    if (A.len_cap > 0 && len > A.len_cap) { len = A.len_cap; if (A.async_err) *A.async_err = 1; }
+    const i64 b = k / rows_per_batch, i = k - b * rows_per_batch;
+    i64 *const offs = O.offs[b];
+    offs[i + 1] = len;
+    if (i == 0) offs[0] = 0;
+}
+// one workgroup per batch: the row lengths at offs[1 ..] become offsets in place; sizes = {total, longest row}
+__global__ __launch_bounds__(256) void hap_scan_group_kernel(const HapGroupOut O, i64 rows_per_batch, i64 n_rows_total) {
+    __shared__ i64 wsum[4];
+    __shared__ i64 wmax[4];
+    __shared__ i64 carry_s;
+    const i64 j = blockIdx.x;
+    const i64 n = (n_rows_total - j * rows_per_batch < rows_per_batch) ? n_rows_total - j * rows_per_batch : rows_per_batch;
+    i64 *const offs = O.offs[j];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    i64 mx = 0;
+    for (i64 base = 0; base < n; base += 256) {
+        const i64 i = base + tid;
+        const i64 x = i < n ? offs[i + 1] : 0;
+        mx = imax(mx, x);
+        i64 sc = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const i64 y = __shfl_up(sc, o, 64);
+            if (lane >= o) sc += y;
+        }
+        if (lane == 63) wsum[wv] = sc;
+        __syncthreads();
+        i64 pre = carry_s;
+        for (int w = 0; w < wv; ++w) pre += wsum[w];
+        if (i < n) offs[i + 1] = sc + pre;
+        __syncthreads();
+        if (tid == 255) carry_s = sc + pre;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = imax(mx, __shfl_down(mx, o, 64));
+    if (lane == 0) wmax[wv] = mx;
+    __syncthreads();
+    if (tid == 0 && O.sizes[j]) {
+        O.sizes[j][0] = carry_s;
+        O.sizes[j][1] = imax(imax(wmax[0], wmax[1]), imax(wmax[2], wmax[3]));
+    }
+}
+
 // ---------------------------------------------------------------------------
 // choose_exonic_variants (src/genotypes/mod.rs:127-176): keep[v] = the variant lies entirely
 // inside its query's [start, end).  Offsets first (counts -> the scan above), then the mask.
@@ -4305,6 +4363,20 @@ static int pipe_env(const char *name, int dflt) {
     const char *e = getenv(name);
     return e ? atoi(e) : dflt;
 }
+// RAG: rows at out_offsets (ragged output, output_length = -1, or a caller's plan): row-major one-hot and / or bytes, no keep
+// mask, no annotations, the slot-major records and the packed reference present, and the caller's bound on the longest row
+// within the pipelined kernel's 10 trips.  There is no wave-per-row lean kernel for these: pipelined form or the all-purpose kernel.
+static bool lean_rag_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_out *out) {
+    if (!st->ref4 || !st->slot_rec || (!out->onehot && !out->haps) || !bt->out_offsets) return false;
+    if (out->annot_v_idxs || out->annot_ref_pos || (out->onehot && out->onehot_layout != GVL_ONEHOT_LC)) return false;
+    if (bt->keep || bt->keep_offsets) return false;
+    const i64 ml = bt->max_row_len > bt->output_length ? bt->max_row_len : bt->output_length;
+    if (ml <= 0 || ml > (i64)PipeCfg<true>::MAXT * TRIP) return false;
+    const i64 n_rows = bt->batch * bt->ploidy;
+    if (n_rows <= 0 || n_rows > 0x7FFFFFF0ll) return false;
+    if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;
+    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432)) == 0;
+}
 static bool lean_pipe_wanted(i64 total_rows) {
     if (debug_flags() & 67108864) return false;
     if (debug_flags() & 33554432) return true;
@@ -4320,6 +4392,7 @@ static bool lean_pipe_compatible(const ReconArgs *RAs, int n) {
     for (int i = 0; i < n; ++i) {
         const ReconArgs &R = RAs[i];
         if (R.fixed_len != F.fixed_len || R.ploidy != F.ploidy || R.regions_stride != F.regions_stride ||
+            (R.out_offsets != nullptr) != (F.out_offsets != nullptr) ||
             (R.onehot != nullptr) != (F.onehot != nullptr) || (R.haps != nullptr) != (F.haps != nullptr) || R.dbg != F.dbg)
             return false;
         if (R.n_rows <= 0 || R.n_rows > F.n_rows || (i + 1 < n && R.n_rows != F.n_rows)) return false;
@@ -4327,7 +4400,7 @@ static bool lean_pipe_compatible(const ReconArgs *RAs, int n) {
     }
     return total <= 0x7FFFFFF0ll && F.regions_stride <= 0x7FFFFFFFll;
 }
-static int launch_lean_rows(const ReconArgs *RAs, int n, void *stream) {
+static int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks = 1) {
     const ReconArgs &RA = RAs[0];
     LeanArgs A;
     LeanMany M;
@@ -4342,11 +4415,13 @@ static int launch_lean_rows(const ReconArgs *RAs, int n, void *stream) {
     A.ploidy_shift = RA.ploidy_shift; A.ploidy = RA.ploidy; A.L = (int)RA.fixed_len; A.dbg = RA.dbg;
     A.chunks = 1; A.sub = 1;
     A.rows_per_batch = (int)RA.n_rows; A.n_batches = n;
+    A.max_row_len = (int)((i64)RA.chunk_len * (RA.out_offsets ? rag_chunks : 1));
     i64 total = 0;
     for (int i = 0; i < n; ++i) {
         LeanBatch &b = M.b[i];
         b.regions = RAs[i].regions; b.shifts = RAs[i].shifts; b.geno_offset_idx = RAs[i].geno_offset_idx; b.to_rc = RAs[i].to_rc;
         b.onehot = RAs[i].onehot; b.haps = RAs[i].haps; b.out_offsets_w = RAs[i].out_offsets_w; b.n_rows = RAs[i].n_rows;
+        b.out_offsets = RAs[i].out_offsets;
         total += RAs[i].n_rows;
     }
     A.n_rows = (int)total;
@@ -4360,9 +4435,15 @@ static int launch_lean_rows(const ReconArgs *RAs, int n, void *stream) {
     const unsigned grid = (unsigned)((waves + LEAN_WAVES - 1) / LEAN_WAVES);
     const dim3 g(grid), b(LEAN_THREADS);
     hipStream_t s = (hipStream_t)stream;
-    if (A.onehot && A.haps) recon_lean_rows_kernel<true, true><<<g, b, 0, s>>>(A, RA, M);
-    else if (A.onehot) recon_lean_rows_kernel<true, false><<<g, b, 0, s>>>(A, RA, M);
-    else recon_lean_rows_kernel<false, true><<<g, b, 0, s>>>(A, RA, M);
+    if (RA.out_offsets) {
+        if (A.onehot && A.haps) recon_lean_rows_kernel<true, true, true><<<g, b, 0, s>>>(A, RA, M);
+        else if (A.onehot) recon_lean_rows_kernel<true, false, true><<<g, b, 0, s>>>(A, RA, M);
+        else recon_lean_rows_kernel<false, true, true><<<g, b, 0, s>>>(A, RA, M);
+    } else {
+        if (A.onehot && A.haps) recon_lean_rows_kernel<true, true, false><<<g, b, 0, s>>>(A, RA, M);
+        else if (A.onehot) recon_lean_rows_kernel<true, false, false><<<g, b, 0, s>>>(A, RA, M);
+        else recon_lean_rows_kernel<false, true, false><<<g, b, 0, s>>>(A, RA, M);
+    }
     return check_launch("gvl_reconstruct (lean, pipelined)");
 }
 
@@ -4375,6 +4456,8 @@ int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *ou
         if (chunks == 1 && lean_pipe_wanted(A.n_rows) && lean_pipe_compatible(&A, 1)) return launch_lean_rows(&A, 1, stream);
         return launch_lean(A, chunks, stream);
     }
+    if (A.n_rows > 0 && !(debug_flags() & 67108864) && lean_rag_eligible(st, bt, out) && lean_pipe_compatible(&A, 1))
+        return launch_lean_rows(&A, 1, stream, chunks);
     return launch_recon(A, chunks, variant, stream);
 }
 
@@ -4389,7 +4472,7 @@ int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_o
     ReconArgs A[GVL_MANY_MAX];
     int chunks[GVL_MANY_MAX], variant[GVL_MANY_MAX];
     bool lean[GVL_MANY_MAX];
-    bool all_one_chunk_lean = n > 0;
+    bool all_one_chunk_lean = n > 0, all_rag = n > 0 && !(debug_flags() & 67108864);
     i64 total = 0;
     for (int i = 0; i < n; ++i) {
         chunks[i] = 1; variant[i] = 0;
@@ -4397,9 +4480,15 @@ int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_o
         if (rc) return rc;
         lean[i] = A[i].n_rows > 0 && lean_eligible(st, &bts[i], &outs[i], chunks[i], A[i].chunk_len);
         all_one_chunk_lean = all_one_chunk_lean && lean[i] && chunks[i] == 1;
+        all_rag = all_rag && A[i].n_rows > 0 && lean_rag_eligible(st, &bts[i], &outs[i]);
         total += A[i].n_rows;
     }
     if (all_one_chunk_lean && lean_pipe_wanted(total) && lean_pipe_compatible(A, n)) return launch_lean_rows(A, n, stream);
+    if (all_rag && lean_pipe_compatible(A, n)) {
+        int min_chunks = chunks[0];             // (the launch reports a row longer than the smallest bound any of its batches gave)
+        for (int i = 1; i < n; ++i) min_chunks = chunks[i] < min_chunks ? chunks[i] : min_chunks;
+        return launch_lean_rows(A, n, stream, min_chunks);
+    }
     for (int i = 0; i < n; ++i) {
         const int rc = lean[i] ? launch_lean(A[i], chunks[i], stream) : launch_recon(A[i], chunks[i], variant[i], stream);
         if (rc) return rc;
@@ -5272,6 +5361,9 @@ static int loader_submit(gvl_loader *ld, i64 g) {
     const gvl_loader_config &c = ld->cfg;
     gvl_batch bts[GVL_MANY_MAX];
     gvl_out ocs[GVL_MANY_MAX];
+    HapGroupOut grp;
+    memset(&grp, 0, sizeof(grp));
+    bool group_sizing = false;
     int m = 0;
     for (i64 j = g * ld->G; j < (g + 1) * ld->G && j < ld->n_batches; ++j, ++m) {
         gvl_loader_batch o;
@@ -5287,12 +5379,40 @@ static int loader_submit(gvl_loader *ld, i64 g) {
         oc.annot_v_idxs = o.annot_v_idxs; oc.annot_ref_pos = o.annot_ref_pos;
         if (loader_ragged(&c)) {
             // row lengths and offsets on the device (rows cut to the slot's capacity are reported, never silent);
-            // the reconstruct launch below then reads them -- no host round trip
-            const int rc0 = hap_offsets_impl(&ld->st, &bt, nullptr, o.out_offsets, o.sizes, c.max_row_len, s);
-            if (rc0) return rc0;
+            // the reconstruct launch below then reads them -- no host round trip.  One sizing per GROUP (below) unless the
+            // dataset's rows take the wave-per-row length kernel (or GVL_DBG & 134217728: per batch, as before round 4)
+            if (diffs_long_rows(&ld->st) || (debug_flags() & 134217728)) {
+                const int rc0 = hap_offsets_impl(&ld->st, &bt, nullptr, o.out_offsets, o.sizes, c.max_row_len, s);
+                if (rc0) return rc0;
+            } else {
+                grp.offs[m] = (i64 *)o.out_offsets; grp.sizes[m] = (i64 *)o.sizes;
+                group_sizing = true;
+            }
             bt.out_offsets = o.out_offsets;
             oc.out_offsets = nullptr;
         }
+    }
+    if (group_sizing) {
+        // the group's request arrays are consecutive rows of the epoch table: ONE length launch over all of its rows, ONE scan
+        // launch with a workgroup per batch
+        gvl_batch gb = bts[0];
+        i64 total_q = 0;
+        for (int i = 0; i < m; ++i) total_q += bts[i].batch;
+        gb.batch = total_q;
+        DiffArgs D;
+        int rc0 = fill_diff_args(D, &ld->st, &gb, "gvl_loader(ragged sizing)");
+        if (rc0) return rc0;
+        D.q_starts = gb.regions + 1; D.q_ends = gb.regions + 2; D.q_stride = gb.regions_stride;
+        D.diffs = nullptr; D.output_length = -1; D.lengths = nullptr;
+        D.len_cap = c.max_row_len; D.async_err = async_err_word();
+        const i64 rpb = c.batch_size * c.ploidy;
+        const unsigned grid = (unsigned)((D.n_rows + 255) / 256);
+        hap_lengths_group_kernel<<<dim3(grid), dim3(256), 0, s>>>(D, gb.regions, (i64)gb.regions_stride, rpb, grp);
+        rc0 = check_launch("gvl_loader(ragged lengths)");
+        if (rc0) return rc0;
+        hap_scan_group_kernel<<<dim3((unsigned)m), dim3(256), 0, s>>>(grp, rpb, D.n_rows);
+        rc0 = check_launch("gvl_loader(ragged offsets)");
+        if (rc0) return rc0;
     }
     int rc = GVL_OK;
     (void)traced("launch reconstruct", [&] { rc = gvl_reconstruct_many(&ld->st, bts, ocs, m, s); return hipSuccess; });

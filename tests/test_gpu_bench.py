@@ -62,7 +62,7 @@ def test_bench_secondary_legs():
     sec = d["secondary"]
     rg, c4 = sec["ragged"], sec["cfg4"]
     assert "error" not in rg and "error" not in c4, sec
-    assert rg["ms_per_step"] > 0 and 0 < rg["step_frac"] < 1 and rg["ms_per_step_alone"] >= 0.5 * rg["ms_per_step"]
+    assert rg["ms_per_step"] > 0 and 0 < rg["step_frac"] < 1 and rg["epochs_timed"] >= 2 and rg["batches_per_epoch"] == 8
     assert c4["ms_per_step"] > 0 and 0 < c4["step_frac"] < 1 and c4["kernel_ms"] > 0 and "131072" in c4["workload"]
     assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]          # the headline is cfg3's
 

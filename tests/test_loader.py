@@ -488,9 +488,21 @@ def test_tracks_batch_long_rows_jitter_and_dense_lists(oracle, dbg):
         _lib.load().gvl_set_debug_flags(-1)
 
 
+@pytest.fixture(params=[0, 134217728, 67108864, 33554432], ids=["default", "sizing-per-batch", "no-pipelined-kernel", "pipelined-one-workgroup"])
+def ragged_path(request):
+    """Ragged rows reach their output through the lean kernel's pipelined form behind ONE sizing per group of batches (default), behind
+    a sizing per batch, through the all-purpose kernel, and through the pipelined form on one workgroup (many rows per wave)."""
+    from genvarloader_amd import _lib
+
+    lib = _lib.load()
+    lib.gvl_set_debug_flags(int(request.param))
+    yield request.param
+    lib.gvl_set_debug_flags(-1)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("python_loop", [False, True], ids=["native-ring", "python-loop"])
-def test_loader_ragged_and_annotated_modes(oracle, python_loop):
+def test_loader_ragged_and_annotated_modes(oracle, python_loop, ragged_path):
     """The reference loader's other haplotype outputs from dataset indices: ragged rows (its default,
     _haps.py:794-811) and annotated haplotypes (ffi/mod.rs:2237-2397), through the native ring (rows packed
     inside a slot of fixed capacity, sizes stay on the device) and through the Python submit loop

@@ -28,7 +28,10 @@ else:
     dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens, alt_alleles=st.alt_alleles,
                      alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv, pad_char=st.pad_char)
 for det in (True, False):
-    ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, jitter=0 if det else 16, deterministic=det, seed=1)
+    ragged = bool(os.environ.get("RAGGED"))          # RAGGED=1: output_length = -1, the reference's default row shape (deterministic only)
+    if ragged and not det:
+        continue
+    ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=-1 if ragged else L, jitter=0 if det else 16, deterministic=det, seed=1)
     combos = ((1, 1, None, False), (3, 1, None, False), (2, 4, None, False), (3, 4, None, False), (4, 4, None, False),
               (3, 4, None, True), (3, 8, None, False), (3, 16, None, False), (3, 16, None, True), (2, 16, None, False),
               (3, None, None, False), (3, 16, torch.Generator().manual_seed(0), False))      # (group None = the loader's default)
@@ -46,7 +49,7 @@ for det in (True, False):
             for batch in dl:
                 if t_first is None:
                     t_first = time.perf_counter()
-                n += batch.onehot.shape[0] * P
+                n += int(batch.idx.numel()) * P
             t_issue = time.perf_counter()
             torch.cuda.synchronize(); t1 = time.perf_counter()
         dt = t1 - t0

@@ -20,7 +20,7 @@ def main():
     leg_s = float(sys.argv[2]) if len(sys.argv) > 2 else 0.4
     gs = [int(x) for x in os.environ.get("GS", "1,2,4,8,16").split(",")]
     sts = [int(x) for x in os.environ.get("STREAMS", "1,2,3").split(",")]
-    ds = synth.make_genome(scale, "cfg3", device="cuda:0", seed=20260805)
+    ds = synth.make_genome(scale, os.environ.get("WORKLOAD", "cfg3"), device="cuda:0", seed=20260805)
     dev = HapsDevice(**ds.static_kwargs(), device="cuda:0")
     P, L = ds.ploidy, ds.length
     K = 4096
@@ -32,7 +32,7 @@ def main():
         qsets = ds.draw_batches(n_rot, G * K // P, seed=11 + G)
         batches = []
         for q in qsets:
-            r = ds.request(q, rc=True)
+            r = ds.request(q, rc=os.environ.get("WORKLOAD", "cfg3") == "cfg3")
             batches.append(dev.prepare_batch(r["regions"], r["shifts"], r["geno_offset_idx"], L, to_rc=r["to_rc"]))
         n_slots = max(sts) + 1
         slots = [dev.alloc_output(batches[0], G * K * L, haps=False, onehot=True) for _ in range(n_slots)]

@@ -20,3 +20,5 @@ torch.cuda.synchronize()
 dev.lib.gvl_diag_set_stamps(None)
 rows, waves = int(st[0]), int(st[1])
 print(f"{bt.n_rows} rows in one launch: {rows} deferred ({100.0 * rows / bt.n_rows:.3f} %) by {waves} waves")
+names = {1: "not a lean row (edge / range / forced)", 2: "bad or overflowing records", 3: "no fixed point", 4: "trailing pad", 5: "runs leave the window / allele starts < 8 apart"}
+print("   reasons:", {names[i]: int(st[2 + i]) for i in names if int(st[2 + i])}, "(rows with other bytes -- bytes-writing launches -- are not listed)")
