@@ -147,8 +147,13 @@ def _check_fresh(p: Path) -> None:
         return
     stamp = p.with_suffix(".so.content")
     srcs = [_HERE / "csrc" / "gvl_hip.hip", _HERE / "csrc" / "gvl_lean.inc", _HERE / "csrc" / "gvl_lean_pipe.inc", _HERE.parent / "include" / "gvl_hip.h"]
-    if not stamp.exists() or not all(f.exists() for f in srcs):
+    if not all(f.exists() for f in srcs):
         return
+    if not stamp.exists():
+        # an in-tree library next to its sources but without its stamp (e.g. a snapshot that shipped the .so alone): nothing says
+        # what it was built from -- the situation this check exists for
+        raise GvlError(f"{p} has no {stamp.name} next to it: cannot tell whether it was built from the sources in csrc/ -- run "
+                       "`python -c 'import __graft_entry__ as g; g.build()'` (GVL_ALLOW_STALE_LIB=1 overrides)")
     h = hashlib.sha256()
     for f in srcs:
         h.update(f.read_bytes())

@@ -75,8 +75,8 @@ def _key(a):
     only guards against accidents; ``clear_static_cache()`` forces a re-upload."""
     import weakref
 
-    a = np.asarray(a)
-    if not a.flags.writeable:
+    a = np.asanyarray(a)      # (asanyarray: an np.memmap stays THAT object -- np.asarray makes a fresh base-class view per call)
+    if not a.flags.writeable and not _writable_ancestor(a):
         hit = _FP_CACHE.get(id(a))
         if hit is not None and hit[0]() is a:
             return hit[1]
@@ -88,6 +88,20 @@ def _key(a):
             pass
         return key
     return (a.__array_interface__["data"][0], a.shape, a.dtype.str, _fingerprint(a))
+
+
+def _writable_ancestor(a) -> bool:
+    """A read-only VIEW over a writable array can still change under it (through the base): only an array none of whose
+    ancestors is writable is fingerprinted once.  (A read-only np.memmap's base is the mmap object itself: fine.)"""
+    b = getattr(a, "base", None)
+    while b is not None:
+        if isinstance(b, np.ndarray):
+            if b.flags.writeable:
+                return True
+            b = b.base
+        else:
+            return False
+    return False
 
 
 def _req(a, dt, name, ndim=None):
@@ -103,8 +117,8 @@ def _static(geno_offsets, geno_v_idxs, v_starts, ilens, alt_alleles, alt_offsets
             pad_char, device="cuda") -> HapsDevice:
     # np.asarray is the identity for ndarrays; anything else becomes an array we keep
     # alive in the cache entry, so an address-based key can never alias a dead buffer
-    arrs = tuple(np.asarray(a) for a in (geno_offsets, geno_v_idxs, v_starts, ilens, alt_alleles,
-                                         alt_offsets, ref_, ref_offsets))
+    arrs = tuple(np.asanyarray(a) for a in (geno_offsets, geno_v_idxs, v_starts, ilens, alt_alleles,
+                                            alt_offsets, ref_, ref_offsets))
     geno_offsets, geno_v_idxs, v_starts, ilens, alt_alleles, alt_offsets, ref_, ref_offsets = arrs
     key = tuple(_key(a) for a in arrs) + (int(pad_char), str(device))
     dev = _STATIC_CACHE.get(key)

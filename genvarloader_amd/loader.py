@@ -855,12 +855,16 @@ class DeviceLoader:
                 # that those are not held up by the host work here): the epoch boundary then costs nothing -- the
                 # next epoch's first batches queue right behind this epoch's last
                 nkey = (next_epoch,) + ekey[1:]
+                # on the consumer's LIVE current stream (read now, not the one captured when the epoch started: the consumer may
+                # have switched streams since): the order's randperm and the table fill are then ordered on ONE stream, and that
+                # stream is the one gvl_loader_next sees in the same iteration
+                live = torch.cuda.current_stream(d)
                 norder = make_order(next_epoch)
                 nn = int(norder.numel())
                 ntab, _ = self._epoch_table(nn, 1 - which)
                 _lib.check(lib.gvl_loader_prefetch_epoch(handle, C.c_uint64(next_epoch & 0xFFFFFFFFFFFFFFFF),
                                                          C.c_void_p(norder.data_ptr()), C.c_int64(nn), C.c_int32(int(self.drop_last)),
-                                                         C.c_void_p(ntab.data_ptr()), C.c_void_p(cur.cuda_stream)))
+                                                         C.c_void_p(ntab.data_ptr()), C.c_void_p(live.cuda_stream)))
                 nat["prefetch"] = (nkey, norder, 1 - which)
             nxt, ref_out, bs = lib.gvl_loader_next, C.byref(out), self.batch_size
             nxt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]          # plain ints in, no wrapper objects per call

@@ -215,13 +215,15 @@ int gvl_pack_slots(const gvl_static *st, gvl_srec *srec_out, void *stream);
 int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *out,
                     void *stream);
 
-/* The same for `n` <= GVL_MANY_MAX batches (arrays of n structs) in ONE host call: every batch is
- * validated before the first launch, then the launches go back to back on `stream` -- what the
- * native loader issues per group of batches (one event pair per group instead of per batch).
- * Equivalent to n calls of gvl_reconstruct; outputs of different batches must not overlap.
- * (One launch for all n batches, blockIdx.z = batch, was built and measured: the per-batch
- * arguments then sit behind an index in the kernarg segment, which cost 1.2-1.8 us per batch, and
- * the batches overlapped no better than launches on separate streams -- DESIGN.md 4.1.) */
+/* The same for `n` <= GVL_MANY_MAX batches (arrays of n structs) in ONE host call: every batch is validated before
+ * the first launch -- what the native loader issues per group of batches.  Equivalent to n calls of gvl_reconstruct;
+ * outputs of different batches must not overlap.
+ * Batches of the same shape that the lean path takes (fixed-length rows of at most 2048 bases, or rows at out_offsets
+ * of at most 2560 bases; row-major one-hot and / or bytes, no keep mask, no annotations; slot_rec + ref4 present; every
+ * batch but the last with the first one's row count) are ONE grid: row k of the launch belongs to batch
+ * k / rows_per_batch, a wave takes rows w, w + W, ... and keeps its next row's reads in flight under the stores of the row in
+ * hand (recon_lean_rows_kernel) -- the form that makes groups pay: 6.3-7.2 us per 4096 x 2048 batch
+ * cold against 7.8-8.3 us for launches of single batches.  Anything else: back-to-back launches on `stream`. */
 #define GVL_MANY_MAX 16
 int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_out *outs,
                          int32_t n, void *stream);
@@ -508,7 +510,12 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
  * epoch's last batches, so the first batches of the new epoch are queued behind them without a gap (without it an
  * epoch boundary costs the table fill + a pipeline refill: ~90 us for BASELINE config 4, 0.25-0.5 ms of a 1.6 ms
  * config-5 epoch).  Anything else (another order, table, length, epoch) is a normal start; a prepared epoch that is
- * never started costs its kernels only.  `order` and `table` must stay alive until that epoch has ended. */
+ * never started costs its kernels only.  `order` and `table` must stay alive until that epoch has ended.
+ * Contract: call it from the CONSUMER's thread (the one that calls gvl_loader_next / gvl_loader_start_epoch; with
+ * cfg.threaded the library's producer thread may be submitting meanwhile: the fill touches only the OTHER table and
+ * state that only the consumer's thread reads; error strings are per thread), and `stream` must be the stream the later
+ * gvl_loader_start_epoch for that epoch is called with (the prepared start does not wait for anything: it relies on
+ * stream order between this fill and the epoch's first batches, which it makes wait for `stream` through an event). */
 int gvl_loader_prefetch_epoch(gvl_loader *ld, uint64_t epoch, const int64_t *order, int64_t n, int32_t drop_last,
                               void *table, void *stream);
 /* Name the epoch the next gvl_loader_start_epoch begins (like DistributedSampler.set_epoch).  The jitter /

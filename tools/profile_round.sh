@@ -13,27 +13,38 @@ cd $R
 [ -x $R/tools/kbench.bin ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 $R/tools/kbench.hip -o $R/tools/kbench.bin
 b() { local name=$1; shift; timeout 900 python3 bench.py "$@" > $T/bench_$name.json 2> $T/bench_$name.err || echo "bench $name FAILED" | tee -a $T/status.txt; }
 b default
-for i in 1 2 3; do b k20_$i --steps 20 --warmup 5 --no-cpu-baseline; b k2000_$i --steps 2000 --warmup 50 --no-cpu-baseline --sustained-s 0; done
-GVL_DBG=16384 b nolean --no-cpu-baseline --sustained-s 0
-b hot_small --scale small --rotate 1 --no-cpu-baseline --sustained-s 0
-b warm64 --rotate 64 --no-cpu-baseline --sustained-s 0
-b rotate1024 --rotate 1024 --no-cpu-baseline --sustained-s 0
-GVL_DBG=16384 b nolean_warm64 --rotate 64 --no-cpu-baseline --sustained-s 0
+for i in 1 2 3; do b k20_$i --steps 20 --warmup 5 --no-cpu-baseline --no-secondary; b k2000_$i --steps 2000 --warmup 50 --no-cpu-baseline --sustained-s 0 --no-secondary; done
+# round 3's path on the same box: a launch per batch, 3 in flight (recon_lean_kernel), at the driver's arguments and at 200 steps
+b many1_k20 --many 1 --streams 3 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary
+b many1 --many 1 --streams 3 --no-cpu-baseline --sustained-s 0 --no-secondary
+GVL_DBG=67108864 b nopipe_many5 --no-cpu-baseline --sustained-s 0 --no-secondary
+GVL_DBG=16384 b nolean --no-cpu-baseline --sustained-s 0 --no-secondary
+b hot_small --scale small --rotate 1 --no-cpu-baseline --sustained-s 0 --no-secondary
+b warm64 --rotate 64 --no-cpu-baseline --sustained-s 0 --no-secondary
+b rotate1024 --rotate 1024 --no-cpu-baseline --sustained-s 0 --no-secondary
 b cfg2 --workload cfg2 --no-cpu-baseline --sustained-s 0
 b cfg3_haps --haps --no-cpu-baseline --sustained-s 0
 b cfg4 --workload cfg4 --steps 20 --warmup 3
 b cfg1_cpu --workload cfg1 --cpu-only
 timeout 300 $R/tools/kbench.bin > $T/kbench.txt 2>&1
+# the loader: cfg5 epoch, genome-scale epoch, genome-scale RAGGED epoch (and each without the pipelined kernel / with per-batch sizing)
+COMBOS=3x16,3x8 python3 tools/epoch_bench.py > $T/cfg5_epoch.txt 2>&1
+SCALE=hg38 COMBOS=3x16,3x8,2x16 CHAIN=3 python3 tools/epoch_bench.py > $T/cfg5_epoch_hg38.txt 2>&1
+GVL_DBG=67108864 SCALE=hg38 COMBOS=3x16 CHAIN=3 python3 tools/epoch_bench.py > $T/cfg5_epoch_hg38_nopipe.txt 2>&1
+RAGGED=1 SCALE=hg38 COMBOS=3x16,3x8 CHAIN=3 python3 tools/epoch_bench.py > $T/ragged_epoch_hg38.txt 2>&1
+GVL_DBG=134217728 RAGGED=1 SCALE=hg38 COMBOS=3x16 CHAIN=3 python3 tools/epoch_bench.py > $T/ragged_epoch_hg38_sizing_per_batch.txt 2>&1
+GVL_DBG=67108864 RAGGED=1 SCALE=hg38 COMBOS=3x16 CHAIN=3 python3 tools/epoch_bench.py > $T/ragged_epoch_hg38_nopipe.txt 2>&1
+python3 tools/pipe_deferred.py hg38 16 > $T/deferred_rows.txt 2>&1
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats_default -- python3 $R/bench.py --no-cpu-baseline --sustained-s 0 --min-region-ms 100 > $T/stats_default.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats_1stream -- python3 $R/bench.py --no-cpu-baseline --streams 1 --no-hot --sustained-s 0 --min-region-ms 100 > $T/stats_1stream.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats_1stream_hot -- python3 $R/bench.py --no-cpu-baseline --streams 1 --no-hot --sustained-s 0 --min-region-ms 100 --scale small --rotate 1 > $T/stats_1stream_hot.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats_default -- python3 $R/bench.py --no-cpu-baseline --sustained-s 0 --no-secondary --min-region-ms 100 > $T/stats_default.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats_1stream -- python3 $R/bench.py --no-cpu-baseline --streams 1 --no-hot --sustained-s 0 --no-secondary --min-region-ms 100 > $T/stats_1stream.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats_1stream_hot -- python3 $R/bench.py --no-cpu-baseline --streams 1 --no-hot --sustained-s 0 --no-secondary --min-region-ms 100 --scale small --rotate 1 > $T/stats_1stream_hot.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $T/pmc_cold_$c -- python3 $R/bench.py --no-cpu-baseline --no-hot --streams 1 --steps 30 --warmup 5 --min-region-ms 1 --sustained-s 0 > $T/pmc_cold_$c.log 2>&1
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $T/pmc_hot_$c -- python3 $R/bench.py --no-cpu-baseline --no-hot --streams 1 --steps 30 --warmup 5 --min-region-ms 1 --sustained-s 0 --scale small --rotate 1 > $T/pmc_hot_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $T/pmc_cold_$c -- python3 $R/bench.py --no-cpu-baseline --no-hot --streams 1 --steps 30 --warmup 5 --min-region-ms 1 --sustained-s 0 --no-secondary > $T/pmc_cold_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $T/pmc_hot_$c -- python3 $R/bench.py --no-cpu-baseline --no-hot --streams 1 --steps 30 --warmup 5 --min-region-ms 1 --sustained-s 0 --no-secondary --scale small --rotate 1 > $T/pmc_hot_$c.log 2>&1
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $T/pmc_kbench_$c -- $R/tools/kbench.bin > $T/pmc_kbench_$c.log 2>&1
 done
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAVES --output-format csv -d $T/pmc_cold_SQ -- python3 $R/bench.py --no-cpu-baseline --no-hot --streams 1 --steps 30 --warmup 5 --min-region-ms 1 --sustained-s 0 > $T/pmc_cold_SQ.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAVES --output-format csv -d $T/pmc_cold_SQ -- python3 $R/bench.py --no-cpu-baseline --no-hot --streams 1 --steps 30 --warmup 5 --min-region-ms 1 --sustained-s 0 --no-secondary > $T/pmc_cold_SQ.log 2>&1
 for d in stats_default stats_1stream stats_1stream_hot; do echo "== $d"; head -3 $(find $T/$d -name "*kernel_stats.csv" | head -1) | cut -c1-220; done
 python3 - $T <<'PY'
 import csv, sys, glob, collections, json
