@@ -33,6 +33,7 @@ SYMBOLS = (
     "gvl_reconstruct_many",
     "gvl_get_diffs_sparse",
     "gvl_hap_offsets",
+    "gvl_paint_tracks",
     "gvl_get_reference",
     "gvl_keep_offsets",
     "gvl_choose_exonic_variants",
@@ -58,7 +59,7 @@ SYMBOLS = (
     "gvl_loader_destroy",
 )
 
-ABI_VERSION = 6          # include/gvl_hip.h: GVL_ABI_VERSION
+ABI_VERSION = 7          # include/gvl_hip.h: GVL_ABI_VERSION
 GVL_ONEHOT_LC = 0
 GVL_ONEHOT_CL = 1
 

@@ -3685,7 +3685,7 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
     __syncthreads();
     if (chunk >= n_chunks) return;
     const i64 j0 = chunk * chunk_len;
-    if (j0 >= length) { if (lane == 0) chunk_todo[q * n_chunks + chunk].flag = 0; return; }
+    if (j0 >= length) { if (lane == 0 && chunk_todo) chunk_todo[q * n_chunks + chunk].flag = 0; return; }
     const i64 j1 = (length - j0 > chunk_len) ? j0 + chunk_len : length;
     // first start - qs >= j1 and first pmax - qs > j0: both searches advance together so that
     // their probe loads overlap (2 dependent rounds for lists of thousands instead of 4)
@@ -3749,9 +3749,10 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
         hi_c = b1; lo_c = b2 < hi_c ? b2 : hi_c;
     }
     const i64 n_c64 = hi_c - lo_c;
-    PaintTodo *todo = chunk_todo + q * n_chunks + chunk;
-    if (n_c64 > PAINT_TILE) { if (lane == 0) { todo->flag = 1; if (complete_err) *complete_err = 2; } return; }   // the per-value path takes it
-    if (lane == 0) todo->flag = 0;
+    // (chunk_todo == NULL: a `tile_complete` interval set painted without the leftovers launch -- nobody reads the flags)
+    PaintTodo *todo = chunk_todo ? chunk_todo + q * n_chunks + chunk : nullptr;
+    if (n_c64 > PAINT_TILE) { if (lane == 0) { if (todo) todo->flag = 1; if (complete_err) *complete_err = 2; } return; }   // the per-value path takes it
+    if (lane == 0 && todo) todo->flag = 0;
     const int n_c = (int)n_c64;
     const int clen = (int)(j1 - j0);
     float *row = out + o0 + j0;
@@ -3856,7 +3857,7 @@ __global__ __launch_bounds__(256) void intervals_to_tracks_tiled_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     // overlapping candidates or equal starts: the leftovers kernel paints this chunk into an LDS image
-    if (lane == 0) { todo->flag = 2; todo->n_c = n_c; todo->lo_c = lo_c; if (complete_err) *complete_err = 2; }
+    if (lane == 0) { if (todo) { todo->flag = 2; todo->n_c = n_c; todo->lo_c = lo_c; } if (complete_err) *complete_err = 2; }
 }
 
 // bucket counts of every list (written at counts[i + 1] for the scan) and the list's base position
@@ -4720,6 +4721,7 @@ int gvl_intervals_bucket_fill(const int32_t *itv_starts, const int32_t *itv_pmax
 
 // paint launches; `todo` (n_queries * n_chunks bytes, nullable) selects the tiled kernel + the per-value
 // kernel for the chunks it leaves, NULL the per-value kernel alone
+static bool paint_can_tile(const int32_t *pmax, int64_t max_row_len);
 static int paint_launch(const int64_t *offset_idxs, const int32_t *starts, int64_t starts_stride, int64_t n_queries,
                         const int32_t *itv_starts, const int32_t *itv_ends, const float *itv_values,
                         const int64_t *itv_offsets, const int32_t *itv_pmax_ends, float *out, const int64_t *out_offsets,
@@ -4728,7 +4730,8 @@ static int paint_launch(const int64_t *offset_idxs, const int32_t *starts, int64
     if (list_div < 1) list_div = 1;
     const int chunk_len = 2048;
     const i64 n_chunks = (max_row_len + chunk_len - 1) / chunk_len;
-    if (todo) {
+    const bool complete_no_flags = !todo && tile_complete && X.offsets && !(debug_flags() & (8192 | 1024)) && paint_can_tile(itv_pmax_ends, max_row_len);
+    if (todo || complete_no_flags) {
         // tile_complete: the interval set's owner vouches that the tiled kernel finishes every chunk (no overlaps, no equal
         // starts, at most 256 candidates in any two adjacent index buckets), so the leftovers launch -- 5.8 us that find
         // nothing -- is skipped; a chunk that needs it after all is reported through gvl_async_error, never silently wrong
@@ -4750,6 +4753,22 @@ static int paint_launch(const int64_t *offset_idxs, const int32_t *starts, int64
     }
     return check_launch("gvl_intervals_to_tracks");
 }
+// The painter's stream-ordered scratch (hipMallocAsync): keep what the library has allocated in the device's default pool instead
+// of handing it back to the driver at the next synchronisation (the pool's default release threshold is 0: every call then
+// paid a driver allocation, 25 of the 45 us of a stand-alone painting of BASELINE config 4's batch).  Once per process.
+static void paint_keep_pool() {
+    static const bool once = [] {
+        int dev = 0;
+        hipMemPool_t pool = nullptr;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+            uint64_t thr = UINT64_MAX;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+        }
+        (void)hipGetLastError();
+        return true;
+    }();
+    (void)once;
+}
 static bool paint_can_tile(const int32_t *pmax, int64_t max_row_len) {
     return pmax && max_row_len < 0x7FFFFF00ll && (max_row_len + 2047) / 2048 <= 0x7FFFFFFFll / 4;
 }
@@ -4767,6 +4786,7 @@ int gvl_intervals_to_tracks(const int64_t *offset_idxs, const int32_t *starts, i
         return fail(GVL_ERR_INVALID, "%s", "gvl_intervals_to_tracks: NULL interval array");
     if (n_queries > 65535) return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_intervals_to_tracks: more than 65535 queries per call");
     hipStream_t s = (hipStream_t)stream;
+    paint_keep_pool();
     int *scratch = nullptr;
     if (!itv_pmax_ends && n_intervals > 0) {
         // no precomputed prefix maxima: build them for the queried lists in stream-ordered scratch
@@ -4793,6 +4813,43 @@ int gvl_intervals_to_tracks(const int64_t *offset_idxs, const int32_t *starts, i
                                 itv_pmax_ends, out, out_offsets, max_row_len, todo, s);
     if (todo) (void)hipFreeAsync(todo, s);
     if (scratch) (void)hipFreeAsync(scratch, s);
+    return rc;
+}
+
+// The painter over an interval set that carries its derived arrays (gvl_track_set: prefix maxima + the coarse bucket index): the
+// tiled + bitmap path gvl_tracks_batch uses, for callers of the reference's two-call entry points (intervals_to_tracks, then
+// shift_and_realign_tracks_sparse) -- gvl_intervals_to_tracks has no place for the index and paints 0.17 of the HBM peak.
+int gvl_paint_tracks(const gvl_track_set *ts, const int64_t *offset_idxs, const int32_t *starts, int64_t starts_stride,
+                     int64_t n_queries, float *out, const int64_t *out_offsets, int64_t max_row_len, void *stream) {
+    if (!ts || n_queries < 0 || max_row_len < 0 || ts->n_intervals < 0) return fail(GVL_ERR_INVALID, "%s", "gvl_paint_tracks: bad arguments");
+    if (n_queries == 0 || max_row_len == 0) return GVL_OK;
+    if (!offset_idxs || !starts || !ts->itv_offsets || !out || !out_offsets || starts_stride < 1)
+        return fail(GVL_ERR_INVALID, "%s", "gvl_paint_tracks: NULL/invalid array");
+    if (ts->n_intervals > 0 && (!ts->itv_starts || !ts->itv_ends || !ts->itv_values))
+        return fail(GVL_ERR_INVALID, "%s", "gvl_paint_tracks: NULL interval array");
+    if (n_queries > 65535) return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_paint_tracks: more than 65535 queries per call");
+    if (!ts->itv_pmax_ends)      // (no derived arrays: the plain entry builds what it needs)
+        return gvl_intervals_to_tracks(offset_idxs, starts, starts_stride, n_queries, ts->itv_starts, ts->itv_ends, ts->itv_values,
+                                       ts->itv_offsets, ts->n_intervals, nullptr, out, out_offsets, max_row_len, stream);
+    hipStream_t s = (hipStream_t)stream;
+    paint_keep_pool();
+    PaintIndex X{nullptr, nullptr, nullptr, nullptr};
+    if (ts->bkt_offsets && ts->bkt_base && ts->bkt_lo && ts->bkt_hi && !(debug_flags() & 1024))
+        X = PaintIndex{(const i64 *)ts->bkt_offsets, ts->bkt_base, ts->bkt_lo, ts->bkt_hi};
+    const i64 n_chunks = (max_row_len + 2047) / 2048;
+    PaintTodo *todo = nullptr;
+    // (a tile_complete set with its index needs no flags and no second launch: no scratch allocation either -- the stream-ordered
+    // malloc + free pair cost more than the painting itself)
+    const bool complete = ts->tile_complete != 0 && X.offsets && !(debug_flags() & (8192 | 1024));
+    if (!complete && paint_can_tile(ts->itv_pmax_ends, max_row_len) &&
+        hipMallocAsync((void **)&todo, (size_t)(n_queries * n_chunks) * sizeof(PaintTodo), s) != hipSuccess) {
+        (void)hipGetLastError();
+        todo = nullptr;
+    }
+    const int rc = paint_launch(offset_idxs, starts, starts_stride, n_queries, ts->itv_starts, ts->itv_ends, ts->itv_values,
+                                ts->itv_offsets, ts->itv_pmax_ends, out, out_offsets, max_row_len, todo, s, X,
+                                ts->tile_complete != 0, ts->list_div);
+    if (todo) (void)hipFreeAsync(todo, s);
     return rc;
 }
 

@@ -437,9 +437,27 @@ def intervals_bucket_index(itv_starts, itv_pmax_ends, itv_offsets, device="cuda"
     return bo, base, lo, hi
 
 
+def make_track_set(itv_starts, itv_ends, itv_values, itv_offsets, itv_pmax_ends=None, bucket_index=None, device="cuda"):
+    """A ``gvl_track_set`` over device-resident interval arrays (+ their derived arrays) for ``gvl_paint_tracks``;
+    -> (struct, tensors to keep alive)."""
+    d = torch.device(device)
+    a, b = _dev(itv_starts, torch.int32, d), _dev(itv_ends, torch.int32, d)
+    v, io = _dev(itv_values, torch.float32, d), _dev(itv_offsets, torch.int64, d)
+    pm = _dev(itv_pmax_ends, torch.int32, d)
+    bk = bucket_index
+    ts = _lib.GvlTrackSet(
+        itv_starts=a.data_ptr(), itv_ends=b.data_ptr(), itv_values=v.data_ptr(), itv_offsets=io.data_ptr(), n_intervals=int(a.numel()),
+        itv_pmax_ends=None if pm is None else pm.data_ptr(),
+        bkt_offsets=None if bk is None else bk[0].data_ptr(), bkt_base=None if bk is None else bk[1].data_ptr(),
+        bkt_lo=None if bk is None else bk[2].data_ptr(), bkt_hi=None if bk is None else bk[3].data_ptr(),
+        tile_complete=0, has_fill=0, fill_strategy=0, fill_param=0.0, list_div=1)
+    return ts, (a, b, v, io, pm, bk)
+
+
 def intervals_to_tracks(offset_idxs, starts, itv_starts, itv_ends, itv_values, itv_offsets, out_offsets,
-                        device="cuda", starts_stride=1, max_row_len=None, itv_pmax_ends=None) -> torch.Tensor:
-    """intervals_to_tracks (src/intervals.rs:19-126) -> f32[out_offsets[-1]] device tensor."""
+                        device="cuda", starts_stride=1, max_row_len=None, itv_pmax_ends=None, track_set=None) -> torch.Tensor:
+    """intervals_to_tracks (src/intervals.rs:19-126) -> f32[out_offsets[-1]] device tensor.  ``track_set`` (from
+    :func:`make_track_set`, with the prefix maxima and the bucket index): the painter's tiled + bitmap path (``gvl_paint_tracks``)."""
     lib = _lib.load()
     d = torch.device(device)
     oi, st = _dev(offset_idxs, torch.int64, d), _dev(starts, torch.int32, d)
@@ -453,6 +471,11 @@ def intervals_to_tracks(offset_idxs, starts, itv_starts, itv_ends, itv_values, i
         return out
     if max_row_len is None:
         max_row_len = int((oo[1:] - oo[:-1]).max().item())
+    if track_set is not None:
+        with torch.cuda.device(d):
+            _lib.check(lib.gvl_paint_tracks(C.byref(track_set), _ptr(oi), _ptr(st), C.c_int64(starts_stride), C.c_int64(n), _ptr(out),
+                                            _ptr(oo), C.c_int64(max_row_len), _stream_ptr()))
+        return out
     with torch.cuda.device(d):
         pm = _dev(itv_pmax_ends, torch.int32, d)
         _lib.check(lib.gvl_intervals_to_tracks(_ptr(oi), _ptr(st), C.c_int64(starts_stride), C.c_int64(n), _ptr(a),

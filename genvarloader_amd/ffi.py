@@ -363,21 +363,31 @@ def _itv_static(itv_starts, itv_ends, itv_values, itv_offsets, device="cuda"):
         v = torch.from_numpy(_req(arrs[2], np.float32, "itv_values", 1)).to(d)
         io = torch.from_numpy(_req(arrs[3], np.int64, "itv_offsets", 1)).to(d)
         pm = _device.intervals_prefix_max(b, io, device) if b.numel() else None
-        ent = (a, b, v, io, pm, arrs)           # arrs: keep the host buffers alive (address key)
+        # ... and the painter's coarse bucket index + the gvl_track_set that carries both (gvl_paint_tracks: the tiled + bitmap
+        # path; the plain gvl_intervals_to_tracks has no place for the index and paints at 0.17 of the HBM peak)
+        bk = _device.intervals_bucket_index(a, pm, io, device) if pm is not None else None
+        ts, keep = _device.make_track_set(a, b, v, io, pm, bk, device) if pm is not None else (None, None)
+        if ts is not None:
+            # BigWig-like lists (no overlaps, distinct starts, <= 256 intervals in two adjacent buckets: checked once, here): the
+            # tiled kernel finishes every chunk and the painter needs no second ("leftovers") launch
+            from .loader import DeviceHapsTracksDataset
+
+            ts.tile_complete = 1 if DeviceHapsTracksDataset._tiles_complete(a, b, io, bk) else 0
+        ent = (a, b, v, io, pm, ts, (arrs, keep, bk))           # arrs: keep the host buffers alive (address key)
         _ITV_CACHE[key] = ent
         while len(_ITV_CACHE) > _STATIC_CACHE_MAX:
             _ITV_CACHE.popitem(last=False)
     else:
         _ITV_CACHE.move_to_end(key)
-    return ent[:5]
+    return ent[:6]
 
 
 def intervals_to_tracks(offset_idxs, starts, itv_starts, itv_ends, itv_values, itv_offsets, out, out_offsets,
                         parallel=False):
     """In place: paints `out` (src/ffi/mod.rs:188-240)."""
-    a, b, v, io, pm = _itv_static(itv_starts, itv_ends, itv_values, itv_offsets)
+    a, b, v, io, pm, ts = _itv_static(itv_starts, itv_ends, itv_values, itv_offsets)
     res = _device.intervals_to_tracks(offset_idxs, starts, a, b, v, io, _req(out_offsets, np.int64, "out_offsets", 1),
-                                      itv_pmax_ends=pm)
+                                      itv_pmax_ends=pm, track_set=ts)
     out[...] = _np(res)
 
 
@@ -399,9 +409,9 @@ def intervals_and_realign_track_fused(out, out_offsets, regions, shifts, geno_of
     The scratch track never leaves the device."""
     dev = _track_static(geno_offsets, geno_v_idxs, v_starts, ilens)
     regions = _req(regions, np.int32, "regions", 2)
-    a, b, v, io, pm = _itv_static(itv_starts, itv_ends, itv_values, itv_offsets)
+    a, b, v, io, pm, ts = _itv_static(itv_starts, itv_ends, itv_values, itv_offsets)
     scratch = _device.intervals_to_tracks(offset_idxs, np.ascontiguousarray(regions[:, 1]), a, b, v, io,
-                                          _req(track_offsets, np.int64, "track_offsets", 1), itv_pmax_ends=pm)
+                                          _req(track_offsets, np.int64, "track_offsets", 1), itv_pmax_ends=pm, track_set=ts)
     res = _device.realign_tracks(dev, regions, shifts, geno_offset_idx, _req(out_offsets, np.int64, "out_offsets", 1),
                                  scratch, track_offsets, params, strategy_id, base_seed, keep, keep_offsets, to_rc)
     out[...] = _np(res)

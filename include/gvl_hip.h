@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GVL_ABI_VERSION 6
+#define GVL_ABI_VERSION 7
 
 enum {
     GVL_OK = 0,
@@ -376,6 +376,13 @@ int gvl_intervals_bucket_counts(const int32_t *itv_starts, const int64_t *itv_of
 int gvl_intervals_bucket_fill(const int32_t *itv_starts, const int32_t *itv_pmax_ends, const int64_t *itv_offsets,
                               int64_t n_lists, const int64_t *bkt_offsets, const int32_t *bkt_base,
                               int64_t n_buckets, int32_t *bkt_lo, int32_t *bkt_hi, void *stream);
+
+/* intervals_to_tracks (src/intervals.rs:19-126) over an interval set that carries its derived arrays (ABI 7): with
+ * ts->itv_pmax_ends + the bucket index the painter takes the tiled + bitmap path gvl_tracks_batch uses (the plain
+ * gvl_intervals_to_tracks has no place for the index).  Same result, bit for bit.  ts->tile_complete as in gvl_track_set;
+ * ts->list_div > 1: region-level lists.  starts / offset_idxs / out_offsets / max_row_len as gvl_intervals_to_tracks. */
+int gvl_paint_tracks(const gvl_track_set *ts, const int64_t *offset_idxs, const int32_t *starts, int64_t starts_stride,
+                     int64_t n_queries, float *out, const int64_t *out_offsets, int64_t max_row_len, void *stream);
 
 /* The track half of a haplotypes + tracks batch in ONE call (what Haps/Tracks reconstruction does per
  * batch and track, _reconstruct.py:183-307 -> intervals_and_realign_track_fused, src/ffi/mod.rs:2551-2672):

@@ -177,6 +177,12 @@ def measure(args, init_dist=True):
     t_paint = timeit(lambda: _lib.check(lib.gvl_intervals_to_tracks(
         gdev._ptr(idx0), gdev._ptr(qs), C.c_int64(1), C.c_int64(bs), gdev._ptr(a), gdev._ptr(e), gdev._ptr(v), gdev._ptr(io),
         C.c_int64(int(a.numel())), gdev._ptr(pm), gdev._ptr(scratch), gdev._ptr(toff), C.c_int64(int(tlen.max())), gdev._stream_ptr())))
+    # the same painting through gvl_paint_tracks with the bucket index (what the drop-in layer's intervals_to_tracks calls since round 4)
+    ts_paint, _keep_ts = gdev.make_track_set(a, e, v, io, pm, ds._bkt[0], "cuda")
+    ts_paint.tile_complete = 1 if ds._tile_complete[0] else 0
+    t_paint_idx = timeit(lambda: _lib.check(lib.gvl_paint_tracks(
+        C.byref(ts_paint), gdev._ptr(idx0), gdev._ptr(qs), C.c_int64(1), C.c_int64(bs), gdev._ptr(scratch), gdev._ptr(toff),
+        C.c_int64(int(tlen.max())), gdev._stream_ptr())))
     ooff = torch.arange(K + 1, dtype=torch.int64, device="cuda") * L
     tbt = dev.prepare_batch(reg, sh, goi, -1, None, None, rc, ooff, max_row_len=L)
     tout = torch.empty(K * L, dtype=torch.float32, device="cuda")
@@ -230,6 +236,8 @@ def measure(args, init_dist=True):
                                           "frac": realign_bytes / (t_realign * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "intervals_to_tracks (tiled + per-value)": {"ms": t_paint, "algorithmic_bytes": paint_bytes,
                                                             "frac": paint_bytes / (t_paint * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "gvl_paint_tracks (bucket index: tiled + bitmap)": {"ms": t_paint_idx, "algorithmic_bytes": paint_bytes,
+                                                                    "frac": paint_bytes / (t_paint_idx * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "gvl_tracks_batch (scratch sizing + " + ("realignment straight from the intervals" if fused else "paint + realign") + ")": {
                     "ms": t_tracks, "algorithmic_bytes": realign_bytes + (0.0 if fused else paint_bytes),
                     "frac": (realign_bytes + (0.0 if fused else paint_bytes)) / (t_tracks * 1e-3) / 1e9 / HBM_PEAK_GBS},
