@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- haplotype windows/sec + achieved HBM GB/s on MI355X.
 
-A "step" is one pass of the hot path over one synthetic batch: ONE launch of the fused
-reconstruct -> reverse-complement -> one-hot kernel through the C-ABI (``gvl_reconstruct``)
-with every input already resident in HBM.  The default workload is BASELINE.json
+A "step" is one pass of the hot path over one synthetic batch of the fused reconstruct ->
+reverse-complement -> one-hot kernel through the C-ABI, with every input already resident in HBM.
+Steps are submitted the way the native loader submits them: in GROUPS (``--many``, default 10
+batches) through ``gvl_reconstruct_many`` = ONE grid over the group (``recon_lean_rows_kernel``),
+``--streams`` (3) launches in flight; ``--many 1`` is round 3's launch per batch.  The default workload is BASELINE.json
 ``configs[2]`` -- 4096 windows x 2048 bp, SNP+indel, reverse-complement on half the rows,
 uint8 one-hot output -- the configuration the metric is quoted on ("4096x2048bp SNP+indel
 one-hot"); ``--workload cfg2`` gives the SNP-only ``configs[1]``, ``--workload cfg4`` the
@@ -36,7 +38,7 @@ Timing.  After W warmup steps:
     same way -> the kernel's own average duration (what ``rocprofv3 --kernel-trace --stats``
     reports) -> ``achieved`` = algorithmic bytes per launch / that;
   * ``sustained``: >= ``--sustained-s`` (6) seconds of back-to-back cold batches on the same
-    schedule (``--streams``, default 3 batches in flight) between ONE pair of HIP events (no gate, no per-region synchronisation):
+    schedule (``--streams`` launches of ``--many`` batches in flight) between ONE pair of HIP events (no gate, no per-region synchronisation):
     the rate at seconds, with the shader / memory clocks read from rocm-smi before and after.
 
 For N > 1 the driver launches one rank per GPU (torch.distributed.run); rows are independent,
@@ -347,10 +349,10 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-only", action="store_true", help="time the CPU oracle only (cfg1 plumbing case); no GPU")
     ap.add_argument("--cpu-budget", type=float, default=8.0)
-    ap.add_argument("--streams", type=int, default=4,
-                    help="HIP streams the launches of the timed region rotate over = launches in flight (4 x 5 batches: a "
-                         "20-step region is in flight as a whole; measured against 2 / 3, profiles/r04_pipe_experiments.txt)")
-    ap.add_argument("--many", type=int, default=5,
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams the launches of the timed region rotate over = launches in flight (3 x 10 batches; a 20-step "
+                         "region is two launches, both in flight; sweeps: profiles/r04_pipe_experiments.txt F, H)")
+    ap.add_argument("--many", type=int, default=10,
                     help="batches per launch (gvl_reconstruct_many: ONE grid over the group, what the native loader submits per "
                          "group; a step is still ONE batch).  1 = a launch per batch (round 3's measurement)")
     ap.add_argument("--min-region-ms", type=float, default=1000.0,
@@ -693,7 +695,7 @@ def main() -> None:
                 "layouts": {"slot_rec": dev.slot_rec is not None, "geno_rec": dev.geno_rec is not None, "ref4": dev.ref4 is not None,
                             "note": None if dev.slot_rec is not None else
                             "slot_rec NOT built (128 B x genotype slots exceeds a quarter of the free HBM): rows find their records through the CSR"},
-                "kernel_path": ("lean, pipelined over rows" if piped else "lean") if lean else "all-purpose",
+                "kernel_path": ("lean, one grid per group (recon_lean_rows_kernel)" if piped else "lean") if lean else "all-purpose",
             },
             "timing": {
                 "how": "median of repeated K-step regions, each between barrier+synchronize; GPU time of a region from "
@@ -706,8 +708,8 @@ def main() -> None:
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "frac_of_copy_ceiling": achieved / HBM_COPY_GBS,
-                "kernel": (("recon_lean_rows_kernel<onehot, haps=%s> (ONE grid over the launch's %d batches; a wave takes rows w, w + W, ... and keeps "
-                            "its next row's window + slot line in flight by LDS-DMA under the stores of the row in hand; nibble-packed reference)"
+                "kernel": (("recon_lean_rows_kernel<onehot, haps=%s> (ONE grid over the launch's %d batches; a wave takes rows w, w + W, ... "
+                            "-- one or two rows per wave -- and fetches a row's window + slot line by LDS-DMA; nibble-packed reference)"
                             % ("true" if args.haps else "false", G)) if piped else
                            "recon_lean_kernel<onehot, haps=%s> (nibble-packed reference; rows it cannot express run the all-purpose body inside the same launch)" % ("true" if args.haps else "false")
                            if lean else "reconstruct_kernel<OH_LC, haps=%s, annot=false>" % ("true" if args.haps else "false")),

@@ -4430,8 +4430,18 @@ static int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_c
     const i64 cap = (debug_flags() & 33554432) ? LEAN_WAVES : (cap_env < LEAN_WAVES ? LEAN_WAVES : cap_env);
     // every wave the same number of rows (20 480 rows on 8 192 waves would be 3 rows for half of them and 2 for the others: the
     // launch ends a third late): R = rows per wave at `cap` waves, then as few waves as R rows each need
-    i64 rows_per_wave = (total + cap - 1) / cap;
+    // Rows per wave.  Measured (profiles/r04_pipe_experiments.txt G): ONE row per wave -- no row-to-row prefetch at all -- is the
+    // best schedule up to ~12 batches per launch (short waves: the hardware's workgroup dispatch balances the chip; 5 batches:
+    // 6.53 / 6.65 / 6.81 us per batch for 1 / 2 / 3 rows per wave), TWO rows per wave above that (16 batches: 6.33 / 5.9 / 6.1 /
+    // 6.6-6.9 for 1 / 2 / 3 / 8: half the workgroups to dispatch, the second row's reads under the first one's stores).
+    // GVL_PIPE_ROWS overrides; GVL_PIPE_WAVES (a cap on the waves of a grid) is the first builds' policy, kept for A/Bs.
+    static const int rows_env = pipe_env("GVL_PIPE_ROWS", 0);
+    static const bool cap_set = getenv("GVL_PIPE_WAVES") != nullptr;
+    i64 rows_per_wave = total >= 49152 ? 2 : 1;
+    if (cap_set || (debug_flags() & 33554432)) rows_per_wave = (total + cap - 1) / cap;
+    if (rows_env > 0 && !(debug_flags() & 33554432)) rows_per_wave = rows_env;
     if (rows_per_wave > PIPE_MAX_ROWS) rows_per_wave = PIPE_MAX_ROWS;
+    if (rows_per_wave < 1) rows_per_wave = 1;
     const i64 waves = (total + rows_per_wave - 1) / rows_per_wave;
     const unsigned grid = (unsigned)((waves + LEAN_WAVES - 1) / LEAN_WAVES);
     const dim3 g(grid), b(LEAN_THREADS);

@@ -46,7 +46,9 @@ def test_bench_contract_single_gpu():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
-    assert 0 < r["pipelined_frac"] < 1 and r["frac_of_copy_ceiling"] > r["frac"]
+    # (pipelined_frac counts SURVEY 8d's ALGORITHMIC bytes -- a byte per reference base, a window per haplotype --; the kernel reads half a
+    # byte per base once per query, so on this test's small, cache-warm dataset the fraction can pass 1: hot_small reads 1.05)
+    assert 0 < r["pipelined_frac"] < 1.25 and r["frac_of_copy_ceiling"] > r["frac"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and "1" in c["threads_sweep"] and c["cores"] >= 1
     assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
