@@ -645,7 +645,8 @@ def main() -> None:
 
     lean = (dev.ref4 is not None and dev.slot_rec is not None and L <= 2048 and L % 4 == 0
             and (int(os.environ.get("GVL_DBG", "0")) & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 33554432 | 67108864)) == 0)
-    piped = lean and G > 1 and K * G >= int(os.environ.get("GVL_PIPE_MIN_ROWS", "8192")) and not (int(os.environ.get("GVL_DBG", "0")) & 67108864)
+    piped = (lean and G > 1 and K * G >= min(2048, int(os.environ.get("GVL_PIPE_MIN_ROWS", "8192")))
+             and not (int(os.environ.get("GVL_DBG", "0")) & 67108864))
     if rank == 0:
         ms_per_step = region_ms / steps
         abytes = algorithmic_bytes_per_window(L, mean_v, args.haps, True) * K      # per batch

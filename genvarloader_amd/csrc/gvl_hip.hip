@@ -4378,11 +4378,14 @@ static bool lean_rag_eligible(const gvl_static *st, const gvl_batch *bt, const g
     if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;
     return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432)) == 0;
 }
-static bool lean_pipe_wanted(i64 total_rows) {
+static bool lean_pipe_wanted(i64 total_rows, int n_batches = 1) {
     if (debug_flags() & 67108864) return false;
     if (debug_flags() & 33554432) return true;
     static const int min_rows = pipe_env("GVL_PIPE_MIN_ROWS", 8192);
-    return min_rows >= 0 && total_rows >= min_rows;
+    // (a GROUP of small batches -- strong scaling: 4096 / 8 = 512 rows per rank and batch -- is one grid from 2048 rows on: ten
+    // launches of 512 rows are ten launch latencies in a row)
+    const i64 bar = (n_batches >= 2 && min_rows > 2048) ? 2048 : min_rows;
+    return min_rows >= 0 && total_rows >= bar;
 }
 // can these (lean-eligible, one-chunk) batches share a grid?  the same shape and outputs; every batch but the last has the
 // first one's row count
@@ -4494,7 +4497,7 @@ int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_o
         all_rag = all_rag && A[i].n_rows > 0 && lean_rag_eligible(st, &bts[i], &outs[i]);
         total += A[i].n_rows;
     }
-    if (all_one_chunk_lean && lean_pipe_wanted(total) && lean_pipe_compatible(A, n)) return launch_lean_rows(A, n, stream);
+    if (all_one_chunk_lean && lean_pipe_wanted(total, n) && lean_pipe_compatible(A, n)) return launch_lean_rows(A, n, stream);
     if (all_rag && lean_pipe_compatible(A, n)) {
         int min_chunks = chunks[0];             // (the launch reports a row longer than the smallest bound any of its batches gave)
         for (int i = 1; i < n; ++i) min_chunks = chunks[i] < min_chunks ? chunks[i] : min_chunks;
