@@ -280,6 +280,41 @@ def test_cfg3_full_with_properties(gpu, oracle, kpath):
     assert int(out.onehot.sum()) == n_acgt
 
 
+@pytest.mark.parametrize("P,per,n_b,last", [(1, 3, 16, 1), (3, 5, 9, 2), (2, 64, 4, 64)], ids=["16x3rows-P1", "9x15rows-P3", "4x128rows-P2"])
+def test_many_batches_grid_shapes(gpu, oracle, P, per, n_b, last):
+    """gvl_reconstruct_many over the shapes the row / batch arithmetic of the one-grid kernel has to get right: the maximum of 16
+    batches, batches of 3 rows, ploidy 3 (no shift for the query index), a last batch of one query; default path and one workgroup."""
+    from genvarloader_amd import _lib, synth
+
+    rng = np.random.default_rng(1234 + per)
+    st = synth.make_static(rng, (40_000,), density=1 / 50, indel_frac=0.3, af_beta=(0.6, 0.9), max_indel=12)
+    L = 300
+    nq = per * (n_b - 1) + last
+    full = synth.make_batch(rng, st, nq, P, L, rc_frac=0.5, random_shifts=True, edge_frac=0.1, permute_csr=True)
+    dev = make_dev(gpu, st, full)
+    cuts = [(i * per, min((i + 1) * per, nq)) for i in range(n_b)]
+    lib = _lib.load()
+    for flags in (0, 33554432, 67108864):
+        lib.gvl_set_debug_flags(flags)
+        try:
+            bts, outs, keep = [], [], []
+            for a, b in cuts:
+                dbt = dev.prepare_batch(full.regions[a:b], full.shifts[a:b], full.geno_offset_idx[a:b], L, to_rc=full.to_rc[a * P:b * P])
+                o, oc = dev.alloc_output(dbt, (b - a) * P * L, haps=True, onehot=True)
+                bts.append(dbt); outs.append(oc); keep.append(o)
+            dev.launch_many(dev.pack_many(bts, outs))
+            gpu.torch.cuda.synchronize()
+            for i, (a, b) in enumerate(cuts):
+                exp, exp_off, exp_oh = oracle.reconstruct_haplotypes_fused(
+                    full.regions[a:b], full.shifts[a:b], full.geno_offset_idx[a:b], full.geno_offsets, full.geno_v_idxs, st.v_starts,
+                    st.ilens, st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, L, None, None, full.to_rc[a * P:b * P], True,
+                    onehot=True, n_threads=4)
+                np.testing.assert_array_equal(keep[i].haps.cpu().numpy(), exp, err_msg=f"flags {flags} batch {i}")
+                np.testing.assert_array_equal(keep[i].onehot.cpu().numpy(), exp_oh, err_msg=f"flags {flags} batch {i}")
+        finally:
+            lib.gvl_set_debug_flags(-1)
+
+
 @pytest.mark.parametrize("want", ["onehot", "both", "haps"])
 def test_many_batches_in_one_grid(gpu, oracle, want, kpath):
     """gvl_reconstruct_many: batches of one shape share a grid (gvl_lean_pipe.inc: row k of the launch belongs to batch
