@@ -3,7 +3,7 @@
 
 A "step" is one pass of the hot path over one synthetic batch of the fused reconstruct ->
 reverse-complement -> one-hot kernel through the C-ABI, with every input already resident in HBM.
-Steps are submitted the way the native loader submits them: in GROUPS (``--many``, default 10
+Steps are submitted the way the native loader submits them: in GROUPS (``--many``, default 16
 batches) through ``gvl_reconstruct_many`` = ONE grid over the group (``recon_lean_rows_kernel``),
 ``--streams`` (3) launches in flight; ``--many 1`` is round 3's launch per batch.  The default workload is BASELINE.json
 ``configs[2]`` -- 4096 windows x 2048 bp, SNP+indel, reverse-complement on half the rows,
@@ -350,11 +350,12 @@ def main() -> None:
     ap.add_argument("--cpu-only", action="store_true", help="time the CPU oracle only (cfg1 plumbing case); no GPU")
     ap.add_argument("--cpu-budget", type=float, default=8.0)
     ap.add_argument("--streams", type=int, default=3,
-                    help="HIP streams the launches of the timed region rotate over = launches in flight (3 x 10 batches; a 20-step "
-                         "region is two launches, both in flight; sweeps: profiles/r04_pipe_experiments.txt F, H)")
-    ap.add_argument("--many", type=int, default=10,
-                    help="batches per launch (gvl_reconstruct_many: ONE grid over the group, what the native loader submits per "
-                         "group; a step is still ONE batch).  1 = a launch per batch (round 3's measurement)")
+                    help="HIP streams the launches of the timed region rotate over = launches in flight (3, the native loader's "
+                         "in_flight; sweeps: profiles/r04_pipe_experiments.txt F, I, J)")
+    ap.add_argument("--many", type=int, default=16,
+                    help="batches per launch (gvl_reconstruct_many: ONE grid over the group -- 16 = the native loader's default group; "
+                         "a step is still ONE batch; a 20-step region is a launch of 16 and one of 4, both in flight).  "
+                         "1 = a launch per batch (round 3's measurement)")
     ap.add_argument("--min-region-ms", type=float, default=1000.0,
                     help="GPU time to sample per timed leg (repeated K-step regions)")
     ap.add_argument("--max-regions", type=int, default=20000)

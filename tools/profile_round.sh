@@ -2,7 +2,8 @@
 # tools/profile_round.sh <tag>: the round's evidence, written under gpurun_out/<tag>/ (copy what is judged into profiles/)
 #  1. bench lines: default (cold hg38, with cpu_baseline), --steps 20 / 2000 three times each, hot (--scale small --rotate 1),
 #     cfg2, --haps, cfg4, cfg1 --cpu-only
-#  2. rocprofv3 --kernel-trace --stats of the default command and of --streams 1 (the kernel alone)
+#  2. rocprofv3 --kernel-trace --stats of the default command and of --streams 1 (the kernel alone); steps and warmup are multiples of
+#     the 16 batches per launch there, so that every launch of the profiled kernel is a full one and the average is per launch
 #  3. PMC passes (kernel-trace + pmc only, one counter per pass): FETCH_SIZE, WRITE_SIZE for the bench kernel cold and hot,
 #     and for tools/kbench.bin (known byte counts -> calibration); SQ instruction mix
 export TMPDIR=/tmp
@@ -36,15 +37,15 @@ GVL_DBG=134217728 RAGGED=1 SCALE=hg38 COMBOS=3x16 CHAIN=3 python3 tools/epoch_be
 GVL_DBG=67108864 RAGGED=1 SCALE=hg38 COMBOS=3x16 CHAIN=3 python3 tools/epoch_bench.py > $T/ragged_epoch_hg38_nopipe.txt 2>&1
 python3 tools/pipe_deferred.py hg38 16 > $T/deferred_rows.txt 2>&1
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats_default -- python3 $R/bench.py --no-cpu-baseline --sustained-s 0 --no-secondary --min-region-ms 100 > $T/stats_default.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats_1stream -- python3 $R/bench.py --no-cpu-baseline --streams 1 --no-hot --sustained-s 0 --no-secondary --min-region-ms 100 > $T/stats_1stream.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats_1stream_hot -- python3 $R/bench.py --no-cpu-baseline --streams 1 --no-hot --sustained-s 0 --no-secondary --min-region-ms 100 --scale small --rotate 1 > $T/stats_1stream_hot.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats_default -- python3 $R/bench.py --steps 192 --warmup 16 --no-cpu-baseline --sustained-s 0 --no-secondary --min-region-ms 100 > $T/stats_default.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats_1stream -- python3 $R/bench.py --steps 192 --warmup 16 --no-cpu-baseline --streams 1 --no-hot --sustained-s 0 --no-secondary --min-region-ms 100 > $T/stats_1stream.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats_1stream_hot -- python3 $R/bench.py --steps 192 --warmup 16 --no-cpu-baseline --streams 1 --no-hot --sustained-s 0 --no-secondary --min-region-ms 100 --scale small --rotate 1 > $T/stats_1stream_hot.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $T/pmc_cold_$c -- python3 $R/bench.py --no-cpu-baseline --no-hot --streams 1 --steps 30 --warmup 5 --min-region-ms 1 --sustained-s 0 --no-secondary > $T/pmc_cold_$c.log 2>&1
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $T/pmc_hot_$c -- python3 $R/bench.py --no-cpu-baseline --no-hot --streams 1 --steps 30 --warmup 5 --min-region-ms 1 --sustained-s 0 --no-secondary --scale small --rotate 1 > $T/pmc_hot_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $T/pmc_cold_$c -- python3 $R/bench.py --no-cpu-baseline --no-hot --streams 1 --steps 32 --warmup 16 --min-region-ms 1 --sustained-s 0 --no-secondary > $T/pmc_cold_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $T/pmc_hot_$c -- python3 $R/bench.py --no-cpu-baseline --no-hot --streams 1 --steps 32 --warmup 16 --min-region-ms 1 --sustained-s 0 --no-secondary --scale small --rotate 1 > $T/pmc_hot_$c.log 2>&1
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $T/pmc_kbench_$c -- $R/tools/kbench.bin > $T/pmc_kbench_$c.log 2>&1
 done
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAVES --output-format csv -d $T/pmc_cold_SQ -- python3 $R/bench.py --no-cpu-baseline --no-hot --streams 1 --steps 30 --warmup 5 --min-region-ms 1 --sustained-s 0 --no-secondary > $T/pmc_cold_SQ.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAVES --output-format csv -d $T/pmc_cold_SQ -- python3 $R/bench.py --no-cpu-baseline --no-hot --streams 1 --steps 32 --warmup 16 --min-region-ms 1 --sustained-s 0 --no-secondary > $T/pmc_cold_SQ.log 2>&1
 for d in stats_default stats_1stream stats_1stream_hot; do echo "== $d"; head -3 $(find $T/$d -name "*kernel_stats.csv" | head -1) | cut -c1-220; done
 python3 - $T <<'PY'
 import csv, sys, glob, collections, json
