@@ -59,7 +59,7 @@ SYMBOLS = (
     "gvl_loader_destroy",
 )
 
-ABI_VERSION = 7          # include/gvl_hip.h: GVL_ABI_VERSION
+ABI_VERSION = 8          # include/gvl_hip.h: GVL_ABI_VERSION
 GVL_ONEHOT_LC = 0
 GVL_ONEHOT_CL = 1
 
@@ -117,7 +117,7 @@ class GvlLoaderConfig(C.Structure):
 
 
 LOADER_SLOT_PARTS = 12       # GVL_LOADER_SLOT_PARTS
-LOADER_TABLE_PARTS = 7       # GVL_LOADER_TABLE_PARTS
+LOADER_TABLE_PARTS = 8       # GVL_LOADER_TABLE_PARTS
 
 
 class GvlLoaderBatch(C.Structure):

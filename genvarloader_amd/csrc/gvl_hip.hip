@@ -2668,7 +2668,11 @@ struct TrackArgs {
     const u64 *seed_ptr;        // non-NULL: base_seed is read from the device (the native loop's per-batch seeds)
     float *out;
     int dbg;
+    const struct TrackWalkState *ws;    // non-NULL: per (row, chunk) where the planned walk may start (track_walk_states_kernel)
 };
+// The planned walk's carries at the top of a 64-variant trip: a chunk whose state says `tb` starts its walk there instead of
+// at the row's first variant (everything in front of that trip ends at or in front of the chunk's first value).  tb < 0: none.
+struct TrackWalkState { int tb, rem, tidx0, pm_carry, x_carry, tidx_end, out_end, pad_; };
 enum : int { T_TRACK = 0, T_REPEAT = 1, T_FILL = 2, T_ZERO = 3 };
 struct TrackMirror { int out[SEG_CAP]; int kind[SEG_CAP]; int plo[SEG_CAP]; int phi[SEG_CAP]; int vlen[SEG_CAP]; };
 
@@ -2919,6 +2923,12 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
     const u64 rc_addr = (u64)A.to_rc + (u64)k;
     const int rc_word = A.to_rc ? ((KInt)(rc_addr & ~3ull))[0] : 0;
     i64 idx_raw = 0;                        // (the interval list's number)
+    // (the chunk's walk state, if the caller prepared them: eight scalars of the same round)
+    int ws_tb = -1, ws_rem = 0, ws_tidx0 = 0, ws_pm = 0, ws_x = 0, ws_tend = 0, ws_oend = 0;
+    if (A.ws) {
+        const KInt w = (KInt)(u64)(A.ws + (k * (i64)gridDim.y + (i64)blockIdx.y));
+        ws_tb = w[0]; ws_rem = w[1]; ws_tidx0 = w[2]; ws_pm = w[3]; ws_x = w[4]; ws_tend = w[5]; ws_oend = w[6];
+    }
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (PAINT) idx_raw = ((KI64)(u64)oi_ptr)[query];
     asm volatile("" :: "s"(row_base), "s"(row_end), "s"(t_s), "s"(t_e), "s"((int)q_start), "s"((int)shift), "s"(o_idx), "s"(keep_off),
@@ -2975,6 +2985,10 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
         bool ended = false, past_chunk = false;
         int tidx_end = 0, out_end = 0;
         int n_ent = 0;
+        int tb0 = 0;
+        if (ok && ws_tb > 0 && ws_tb < n_var && ws_oend <= lo_clip && !(A.dbg & 268435456)) {
+            tb0 = ws_tb; rem = ws_rem; tidx0 = ws_tidx0; pm_carry = ws_pm; x_carry = ws_x; tidx_end = ws_tend; out_end = ws_oend;
+        }
         const int qs = (int)(ok ? q_start : 0);
         auto put = [&](int q, int kind, int o_start, i64 pval, int vlen) {
             if (q < SEG_CAP) {
@@ -2985,11 +2999,11 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
         // (position and length delta sit next to the CSR entry, gvl_grec: one read, not three; a trip's records are
         // requested a trip ahead)
         int nxt_pos = 0, nxt_d = 0;
-        if (A.grec && lane < n_var) {
-            const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.grec + (o_s + lane));
+        if (A.grec && tb0 + lane < n_var) {
+            const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.grec + (o_s + tb0 + lane));
             nxt_pos = rec.x; nxt_d = rec.y;
         }
-        for (int tb = 0; tb < n_var && ok && !ended && !past_chunk; tb += WAVE) {
+        for (int tb = tb0; tb < n_var && ok && !ended && !past_chunk; tb += WAVE) {
             int pos = 0, d = 0;
             bool valid = tb + lane < n_var;
             const int rec_pos = nxt_pos, rec_d = nxt_d;
@@ -3478,6 +3492,146 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
             }
             M.out[lane] = s_out; M.kind[lane] = s_kind; M.plo[lane] = s_plo; M.phi[lane] = s_phi; M.vlen[lane] = s_vlen;
         }
+    }
+}
+
+// ---- walk states: realign_tracks_kernel's planned walk over a WHOLE row, once, no entries: the carries at the top of every
+// 64-variant trip, and for each chunk of the row the last trip whose top lies at or in front of the chunk's first value.
+// The kernel's chunk-waves then start there: one trip each (the one their variants are in) instead of every trip from the row's
+// first variant on (BASELINE config 4: 150 variants per row = 3 trips, 64 chunks: 2.2 trips per chunk-wave on average, a
+// fifth of the kernel's instructions).  One wave per row; a row the planned walk cannot express keeps the states in front of
+// where that shows (the chunk-waves find out for themselves).
+constexpr int WALK_TRIPS = 32;                  // trips whose tops are kept (rows with more variants: the later chunks start at the last kept one)
+__global__ __launch_bounds__(256) void track_walk_states_kernel(const TrackArgs A, TrackWalkState *ws, const int chunks, const i64 fixed_len) {
+    __shared__ int tops[4][7][WALK_TRIPS];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = rfl((int)(threadIdx.x >> 6));
+    const i64 k = (i64)blockIdx.x * 4 + wave;
+    if (k >= A.n_rows) return;
+    const i64 query = A.ploidy_shift >= 0 ? (k >> A.ploidy_shift) : (i64)((u32)k / (u32)A.ploidy);
+    // (fixed_len >= 0: every row has that length -- the loader's epoch table has no row offsets)
+    const i64 row_base = fixed_len >= 0 ? 0 : A.out_offsets[k], row_end = fixed_len >= 0 ? fixed_len : A.out_offsets[k + 1];
+    const i64 q_start = A.regions[query * A.regions_stride + 1];
+    const i64 shift = A.shifts[k];
+    const i64 o_idx = A.geno_offset_idx[k];
+    const bool has_keep = A.keep && A.keep_offsets;
+    const i64 keep_off = has_keep ? A.keep_offsets[k] : 0;
+    const i64 o_s = A.go_starts[o_idx];
+    const i64 nv64 = A.go_stops[o_idx] - o_s;
+    const int L = (int)(row_end - row_base);
+    const int n_var = nv64 < 0 ? 0 : (nv64 > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)nv64);
+    int n_tops = 0;
+    bool ok = q_start > -(1ll << 30) && q_start < (1ll << 30) && shift >= 0 && shift < (1ll << 30) && !(A.dbg & 8);
+    int rem = (int)(ok ? shift : 0);
+    int tidx0 = 0, pm_carry = 0, x_carry = 0;
+    bool ended = false;
+    int tidx_end = 0, out_end = 0;
+    const int qs = (int)(ok ? q_start : 0);
+    for (int tb = 0; tb < n_var && ok && !ended && n_tops < WALK_TRIPS; tb += WAVE) {
+        if (lane == 0) {
+            tops[wave][0][n_tops] = tb; tops[wave][1][n_tops] = rem; tops[wave][2][n_tops] = tidx0; tops[wave][3][n_tops] = pm_carry;
+            tops[wave][4][n_tops] = x_carry; tops[wave][5][n_tops] = tidx_end; tops[wave][6][n_tops] = out_end;
+        }
+        ++n_tops;
+        int pos = 0, d = 0;
+        bool valid = tb + lane < n_var;
+        if (valid) {
+            if (A.grec) {
+                const i32x4 rec = *reinterpret_cast<const i32x4 *>(A.grec + (o_s + tb + lane));
+                pos = rec.x; d = rec.y;
+            } else {
+                int v = A.geno_v_idxs[o_s + tb + lane];
+                v = v < 0 ? 0 : ((i64)v >= A.n_variants ? (int)(A.n_variants - 1) : v);
+                pos = A.v_starts[v]; d = A.ilens[v];
+            }
+            if (has_keep) valid = A.keep[keep_off + tb + lane] != 0;
+        }
+        const bool weird = valid && (pos <= -(1 << 30) || pos >= (1 << 30) || d <= -(1 << 30) || d >= (1 << 30));
+        ok = ok && __builtin_amdgcn_ballot_w64(weird) == 0;
+        const int vrp = pos - qs;
+        const int E = vrp - (d < 0 ? d : 0) + 1;
+        int v_len = (d > 0 ? d : 0) + 1;
+        const u64 m_span = __builtin_amdgcn_ballot_w64(valid && d < 0 && vrp < 0 && E >= 0);
+        if (m_span) { tidx0 = rdl(E, 63 - __builtin_clzll(m_span)); pm_carry = tidx0; tidx_end = tidx0; }
+        bool cand = valid && vrp >= 0;
+        if (rem > 0) {
+            const int base = tidx0;
+            const u64 m_t = __builtin_amdgcn_ballot_w64(cand && vrp >= base && (vrp - base) + v_len >= rem);
+            if (m_t == 0) {
+                cand = false;
+            } else {
+                const int f = __builtin_ctzll(m_t);
+                const int dist = rdl(vrp, f) - base;
+                if (dist >= rem) {
+                    tidx0 = base + rem;
+                    cand = cand && lane >= f;
+                } else {
+                    const int skip = rem - dist;
+                    if (skip == rdl(v_len, f)) {
+                        tidx0 = rdl(E, f);
+                        cand = cand && lane > f;
+                    } else {
+                        tidx0 = rdl(vrp, f);
+                        cand = cand && lane >= f;
+                        if (lane == f) v_len -= skip;
+                    }
+                }
+                rem = 0;
+                pm_carry = tidx0; tidx_end = tidx0;
+            }
+        }
+        cand = cand && d != 0;
+        bool inB = cand;
+        int PM = 0, pm_incl = 0;
+        {
+            u64 mB = __builtin_amdgcn_ballot_w64(inB);
+            bool stable = false;
+#pragma unroll 1
+            for (int it = 0; it < 4 && !stable; ++it) {
+                PM = wave_scan_exclusive<OpMaxU>(inB ? E : 0, pm_incl);
+                PM = PM > pm_carry ? PM : pm_carry;
+                inB = cand && vrp >= PM;
+                const u64 m2 = __builtin_amdgcn_ballot_w64(inB);
+                stable = m2 == mB;
+                mB = m2;
+            }
+            ok = ok && stable;
+        }
+        const int n_i = inB ? vrp - PM : 0;
+        const int S_i = inB ? OpSat::f(n_i, v_len) : 0;
+        int x_incl;
+        const int X = OpSat::f(x_carry, wave_scan_exclusive<OpSat>(S_i, x_incl));
+        const int fill_out = OpSat::f(X, n_i);
+        const bool applied = inB && fill_out < L;
+        const int w_i = applied ? ((v_len < L - fill_out) ? v_len : L - fill_out) : 0;
+        const u64 m_inB = __builtin_amdgcn_ballot_w64(inB);
+        const u64 m_app = __builtin_amdgcn_ballot_w64(applied);
+        if (m_inB != m_app) ended = true;
+        if (m_app) {
+            const int last = 63 - __builtin_clzll(m_app);
+            tidx_end = rdl(E, last);
+            out_end = rdl(fill_out, last) + rdl(w_i, last);
+        }
+        if (tb + WAVE < n_var) {
+            const int mx = rdl(pm_incl, 63);
+            pm_carry = mx > pm_carry ? mx : pm_carry;
+            x_carry = OpSat::f(x_carry, rdl(x_incl, 63));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int c = lane; c < chunks; c += WAVE) {
+        const i64 lo = (i64)c * A.chunk_len;
+        int t = -1;
+        for (int i = 0; i < n_tops; ++i)
+            if ((i64)tops[wave][6][i] <= lo) t = i;          // (out_end never decreases from trip to trip)
+        TrackWalkState S = {-1, 0, 0, 0, 0, 0, 0, 0};
+        if (t >= 0) {
+            S.tb = tops[wave][0][t]; S.rem = tops[wave][1][t]; S.tidx0 = tops[wave][2][t]; S.pm_carry = tops[wave][3][t];
+            S.x_carry = tops[wave][4][t]; S.tidx_end = tops[wave][5][t]; S.out_end = tops[wave][6][t];
+        }
+        ws[k * (i64)chunks + c] = S;
     }
 }
 
@@ -4319,7 +4473,7 @@ static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_o
     }
     if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;     // u32 positions in the kernel
     // (2097152 ... 16777216 concern the track kernels only)
-    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864)) == 0;
+    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 268435456)) == 0;
 }
 
 static int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
@@ -4376,7 +4530,7 @@ static bool lean_rag_eligible(const gvl_static *st, const gvl_batch *bt, const g
     const i64 n_rows = bt->batch * bt->ploidy;
     if (n_rows <= 0 || n_rows > 0x7FFFFFF0ll) return false;
     if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;
-    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432)) == 0;
+    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 268435456)) == 0;
 }
 static bool lean_pipe_wanted(i64 total_rows, int n_batches = 1) {
     if (debug_flags() & 67108864) return false;
@@ -4874,7 +5028,8 @@ int gvl_paint_tracks(const gvl_track_set *ts, const int64_t *offset_idxs, const 
 
 static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const float *tracks,
                                const int64_t *track_offsets, const double *params, int64_t strategy_id,
-                               uint64_t base_seed, const u64 *seed_ptr, float *out, void *stream, const PaintSrcArgs *ps = nullptr);
+                               uint64_t base_seed, const u64 *seed_ptr, float *out, void *stream, const PaintSrcArgs *ps = nullptr,
+                               TrackWalkState *ws = nullptr, i64 ws_bytes = 0, bool ws_make = false);
 int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *tracks,
                        const int64_t *track_offsets, const double *params, int64_t strategy_id,
                        uint64_t base_seed, float *out, void *stream) {
@@ -4882,7 +5037,8 @@ int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *t
 }
 static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const float *tracks,
                                const int64_t *track_offsets, const double *params, int64_t strategy_id,
-                               uint64_t base_seed, const u64 *seed_ptr, float *out, void *stream, const PaintSrcArgs *ps) {
+                               uint64_t base_seed, const u64 *seed_ptr, float *out, void *stream, const PaintSrcArgs *ps,
+                               TrackWalkState *ws, i64 ws_bytes, bool ws_make) {
     if (!st || !bt) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: NULL struct");
     if (bt->batch < 0 || bt->ploidy <= 0) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: bad batch/ploidy");
     if (bt->batch == 0) return GVL_OK;
@@ -4910,6 +5066,16 @@ static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const 
     A.dbg = debug_flags();
     if (A.n_rows > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: batch too large");
     const i64 grid = (A.n_rows + 3) / 4;
+    // rows of several chunks: the walk's state per (row, chunk), once per batch (the caller's scratch; every track of the batch
+    // reads the same ones -- the walk does not depend on the track)
+    if (ws && chunks > 1 && A.n_rows * (i64)chunks * (i64)sizeof(TrackWalkState) <= ws_bytes && !(A.dbg & (8 | 268435456))) {
+        if (ws_make) {
+            track_walk_states_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(A, ws, chunks, -1);
+            const int rc = check_launch("gvl_realign_tracks(walk states)");
+            if (rc) return rc;
+        }
+        A.ws = ws;
+    }
     // (GVL_TRACK_EXTRA_LDS: bytes of unused LDS per workgroup, to measure the kernel at fewer waves per SIMD)
     static const unsigned xl = [] { const char *e = getenv("GVL_TRACK_EXTRA_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
     if (ps) realign_tracks_kernel<true><<<dim3((unsigned)grid, (unsigned)chunks), dim3(256), xl, (hipStream_t)stream>>>(A, *ps);
@@ -4919,26 +5085,28 @@ static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const 
 
 
 // scratch layout of gvl_tracks_batch: track_offsets i64 (batch + 1) | out_offsets i64 (batch * ploidy + 1) |
-// chunk records (16 B x batch * chunks) | scratch tracks f32 (batch * stride)
-static void tracks_scratch_parts(i64 batch, i64 ploidy, i64 stride, i64 part[5]) {
+// chunk records (16 B x batch * chunks) | scratch tracks f32 (batch * stride) | walk states (32 B x batch * ploidy * chunks)
+static void tracks_scratch_parts(i64 batch, i64 ploidy, i64 stride, i64 part[6]) {
     const i64 n_chunks = (stride + 2047) / 2048;
-    const i64 sz[4] = {8 * (batch + 1), 8 * (batch * ploidy + 1), batch * n_chunks * (i64)sizeof(PaintTodo), 4 * batch * stride};
+    const i64 sz[5] = {8 * (batch + 1), 8 * (batch * ploidy + 1), batch * n_chunks * (i64)sizeof(PaintTodo), 4 * batch * stride,
+                       n_chunks > 1 ? batch * ploidy * n_chunks * (i64)sizeof(TrackWalkState) : 0};
     i64 off = 0;
-    for (int i = 0; i < 4; ++i) { part[i] = off; off += (sz[i] + 255) & ~255ll; }
-    part[4] = off;
+    for (int i = 0; i < 5; ++i) { part[i] = off; off += (sz[i] + 255) & ~255ll; }
+    part[5] = off;
 }
 
 int64_t gvl_tracks_scratch_bytes(int64_t batch, int64_t ploidy, int64_t scratch_stride) {
     if (batch < 0 || ploidy <= 0 || scratch_stride < 0) return -1;
-    i64 part[5];
+    i64 part[6];
     tracks_scratch_parts(batch, ploidy, scratch_stride, part);
-    return part[4] > 0 ? part[4] : 256;
+    return part[5] > 0 ? part[5] : 256;
 }
 
 static int tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const int64_t *offset_idxs, const gvl_track_set *tracks,
                              int32_t n_tracks, const double *params, int64_t strategy_id, uint64_t base_seed, const u64 *seed_ptr,
                              float *out, int64_t out_track_stride, void *scratch, int64_t scratch_stride, void *stream,
-                             const i64 *pre_track_offsets = nullptr, const i64 *pre_out_offsets = nullptr);
+                             const i64 *pre_track_offsets = nullptr, const i64 *pre_out_offsets = nullptr,
+                             const TrackWalkState *pre_ws = nullptr);
 int gvl_tracks_batch(const gvl_static *st, const gvl_batch *bt, const int64_t *offset_idxs, const gvl_track_set *tracks,
                      int32_t n_tracks, const double *params, int64_t strategy_id, uint64_t base_seed, float *out,
                      int64_t out_track_stride, void *scratch, int64_t scratch_stride, void *stream) {
@@ -4948,7 +5116,7 @@ int gvl_tracks_batch(const gvl_static *st, const gvl_batch *bt, const int64_t *o
 static int tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const int64_t *offset_idxs, const gvl_track_set *tracks,
                              int32_t n_tracks, const double *params, int64_t strategy_id, uint64_t base_seed, const u64 *seed_ptr,
                              float *out, int64_t out_track_stride, void *scratch, int64_t scratch_stride, void *stream,
-                             const i64 *pre_track_offsets, const i64 *pre_out_offsets) {
+                             const i64 *pre_track_offsets, const i64 *pre_out_offsets, const TrackWalkState *pre_ws) {
     if (!st || !bt || n_tracks < 0) return fail(GVL_ERR_INVALID, "%s", "gvl_tracks_batch: bad arguments");
     if (bt->batch < 0 || bt->ploidy <= 0 || bt->output_length < 0)
         return fail(GVL_ERR_INVALID, "%s", "gvl_tracks_batch: needs batch >= 0, ploidy > 0 and a fixed output_length");
@@ -4960,9 +5128,13 @@ static int tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const in
     const i64 B = bt->batch, P = bt->ploidy, L = bt->output_length;
     if (out_track_stride < B * P * L) return fail(GVL_ERR_INVALID, "%s", "gvl_tracks_batch: out_track_stride < batch * ploidy * output_length");
     hipStream_t s = (hipStream_t)stream;
-    i64 part[5];
+    i64 part[6];
     tracks_scratch_parts(B, P, scratch_stride, part);
     u8 *base = (u8 *)scratch;
+    // the walk's states: the caller's (the native loop prepares them with its epoch table) or made here, once per call
+    TrackWalkState *const ws = pre_ws ? const_cast<TrackWalkState *>(pre_ws) : (part[5] > part[4] ? (TrackWalkState *)(base + part[4]) : nullptr);
+    const i64 ws_bytes = pre_ws ? (1ll << 62) : part[5] - part[4];
+    bool ws_made = pre_ws != nullptr;
     i64 *track_offsets = (i64 *)(base + part[0]);
     i64 *out_offsets = (i64 *)(base + part[1]);
     PaintTodo *todo = (PaintTodo *)(base + part[2]);
@@ -5008,8 +5180,9 @@ static int tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const in
             PaintSrcArgs ps{(const i64 *)offset_idxs, T.list_div > 1 ? T.list_div : 1, T.itv_starts, T.itv_ends, T.itv_values,
                             (const i64 *)T.itv_offsets, T.itv_pmax_ends, X};
             rc = realign_tracks_impl(st, &rb, nullptr, (const int64_t *)track_offsets, T.has_fill ? t_par : params, t_strategy, base_seed,
-                                     seed_ptr, out + (i64)t * out_track_stride, stream, &ps);
+                                     seed_ptr, out + (i64)t * out_track_stride, stream, &ps, ws, ws_bytes, !ws_made);
             if (rc) return rc;
+            ws_made = true;
             continue;
         }
         rc = paint_launch(offset_idxs, bt->regions + 1, bt->regions_stride, B, T.itv_starts, T.itv_ends, T.itv_values, T.itv_offsets,
@@ -5018,8 +5191,9 @@ static int tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const in
                           T.list_div > 1 ? T.list_div : 1);
         if (rc) return rc;
         rc = realign_tracks_impl(st, &rb, scr, (const int64_t *)track_offsets, T.has_fill ? t_par : params, t_strategy, base_seed, seed_ptr,
-                                 out + (i64)t * out_track_stride, stream);
+                                 out + (i64)t * out_track_stride, stream, nullptr, ws, ws_bytes, !ws_made);
         if (rc) return rc;
+        ws_made = true;
     }
     return GVL_OK;
 }
@@ -5103,6 +5277,8 @@ struct gvl_loader {
     i64 submitted, consumed;      // submitted: GROUPS handed to the GPU; consumed: BATCHES handed to the caller
     i64 released_groups;          // groups whose release has been recorded on the consumer's stream
     int G, n_sets;
+    TrackWalkState *e_track_ws;             // tracks, rows of several chunks: the walk's state per (row, chunk) of the epoch (or NULL)
+    int e_chunks;
     i64 *e_track_offsets, *e_out_offsets;   // tracks: every batch's scratch-track offsets ((bs + 1) per batch) and the k * L output offsets
     u64 counter;                  // the running epoch's number + 1 (keys the random draws together with cfg.seed)
     bool epoch_set;               // gvl_loader_set_epoch named the next epoch (else: epochs started so far)
@@ -5130,6 +5306,16 @@ struct LoaderSync {
 };
 
 static i64 align256(i64 x) { return (x + 255) & ~255ll; }
+// walk states of an epoch's rows (rows of several chunks only; an epoch whose states would not fit GVL_WALK_STATE_MAX_MB,
+// default 512, goes without: its chunk-waves then replay the walk from the row's first variant)
+static i64 loader_walk_state_bytes(const gvl_loader_config *cfg, i64 n, i64 state_bytes) {
+    if (cfg->output_length <= 2048) return 0;
+    int chunks = 1, chunk_len = 0;
+    if (pick_chunk(cfg->output_length, &chunks, &chunk_len) || chunks <= 1) return 0;
+    static const i64 cap = [] { const char *e = getenv("GVL_WALK_STATE_MAX_MB"); return (i64)(e ? atoll(e) : 512) << 20; }();
+    const i64 b = n * cfg->ploidy * (i64)chunks * state_bytes;
+    return b <= cap ? b : 0;
+}
 
 static bool loader_ragged(const gvl_loader_config *c) { return c->output_length == -1; }
 // bases per row a slot reserves: the fixed length, or the ragged bound
@@ -5158,7 +5344,8 @@ int64_t gvl_loader_table_bytes(const gvl_loader_config *cfg, int64_t n, int64_t 
     const i64 nb = (n + cfg->batch_size - 1) / cfg->batch_size;
     const bool tr = cfg->n_tracks > 0;
     const i64 sizes[GVL_LOADER_TABLE_PARTS] = {16 * n, 8 * n * P, 4 * n * P, n * P, 8 * nb,
-                                               tr ? 8 * (n + nb) : 0, tr ? 8 * (cfg->batch_size * P + 1) : 0};
+                                               tr ? 8 * (n + nb) : 0, tr ? 8 * (cfg->batch_size * P + 1) : 0,
+                                               tr ? loader_walk_state_bytes(cfg, n, (i64)sizeof(TrackWalkState)) : 0};
     i64 off = 0;
     for (int i = 0; i < GVL_LOADER_TABLE_PARTS; ++i) {
         if (part_offsets) part_offsets[i] = off;
@@ -5261,8 +5448,8 @@ int gvl_loader_set_epoch(gvl_loader *ld, uint64_t epoch) {
 // into `table` on stream `s`
 static int loader_fill_table(gvl_loader *ld, const int64_t *order, i64 n, int32_t drop_last, void *table, u64 counter, hipStream_t s) {
     const gvl_loader_config &c = ld->cfg;
-    int64_t po[GVL_LOADER_TABLE_PARTS];
-    gvl_loader_table_bytes(&c, n, po);
+    int64_t po[GVL_LOADER_TABLE_PARTS + 1];
+    po[GVL_LOADER_TABLE_PARTS] = gvl_loader_table_bytes(&c, n, po);
     u8 *base = (u8 *)table;
     int *t_regions = (int *)(base + po[0]);
     i64 *t_goi = (i64 *)(base + po[1]);
@@ -5305,6 +5492,24 @@ static int loader_fill_table(gvl_loader *ld, const int64_t *order, i64 n, int32_
         track_scan_batches_kernel<<<dim3((unsigned)n_batches), dim3(256), 0, s>>>(t_track_offsets, n_used, bs);
         rc3 = check_launch("gvl_loader_start_epoch(track offsets)");
         if (rc3) return rc3;
+        // rows of several chunks: where each chunk's walk may start (track_walk_states_kernel), for every row of the epoch
+        if (po[8] > po[7] && !(debug_flags() & (8 | 268435456))) {
+            TrackArgs TA;
+            memset(&TA, 0, sizeof(TA));
+            TA.go_starts = (const i64 *)ld->st.geno_o_starts; TA.go_stops = (const i64 *)ld->st.geno_o_stops;
+            TA.geno_v_idxs = ld->st.geno_v_idxs; TA.v_starts = ld->st.v_starts; TA.ilens = ld->st.ilens; TA.n_variants = ld->st.n_variants;
+            TA.grec = (debug_flags() & 16) ? nullptr : ld->st.geno_rec;
+            TA.regions = t_regions; TA.regions_stride = 4; TA.shifts = t_shifts; TA.geno_offset_idx = t_goi;
+            TA.n_rows = n_used * c.ploidy; TA.ploidy = (int)c.ploidy; TA.ploidy_shift = log2_exact(c.ploidy);
+            int chunks = 1;
+            if (pick_chunk(c.output_length, &chunks, &TA.chunk_len)) return fail(GVL_ERR_INVALID, "%s", "gvl_loader_start_epoch: too many chunks");
+            TA.dbg = debug_flags();
+            const i64 wgrid = (TA.n_rows + 3) / 4;
+            if (wgrid > 0x7FFFFFFFll) return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_loader_start_epoch: too many rows for the walk states");
+            track_walk_states_kernel<<<dim3((unsigned)wgrid), dim3(256), 0, s>>>(TA, (TrackWalkState *)(base + po[7]), chunks, c.output_length);
+            rc3 = check_launch("gvl_loader_start_epoch(walk states)");
+            if (rc3) return rc3;
+        }
     }
     return GVL_OK;
 }
@@ -5375,6 +5580,11 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
         ld->e_seeds = (u64 *)(base + po[4]);
         ld->e_track_offsets = (i64 *)(base + po[5]);
         ld->e_out_offsets = (i64 *)(base + po[6]);
+        const i64 wsb = c.n_tracks > 0 ? loader_walk_state_bytes(&c, n, (i64)sizeof(TrackWalkState)) : 0;
+        ld->e_track_ws = (wsb > 0 && !(debug_flags() & (8 | 268435456))) ? (TrackWalkState *)(base + po[7]) : nullptr;
+        int cl = 0;
+        ld->e_chunks = 1;
+        if (wsb > 0) (void)pick_chunk(c.output_length, &ld->e_chunks, &cl);
     }
     const i64 bs = c.batch_size;
     ld->order = order; ld->n_order = n;
@@ -5505,7 +5715,8 @@ static int loader_submit(gvl_loader *ld, i64 g) {
                 rc = tracks_batch_impl(&ld->st, &bts[m], (const int64_t *)o.idx, ld->tracks, c.n_tracks, par, c.strategy_id, c.track_seed,
                                        (const u64 *)o.track_seed, o.tracks, K * c.output_length, base + ld->part[10], c.scratch_stride, s,
                                        (debug_flags() & 131072) ? nullptr : ld->e_track_offsets + j * (c.batch_size + 1),
-                                       (debug_flags() & 131072) ? nullptr : ld->e_out_offsets);
+                                       (debug_flags() & 131072) ? nullptr : ld->e_out_offsets,
+                                       ld->e_track_ws ? ld->e_track_ws + j * c.batch_size * c.ploidy * (i64)ld->e_chunks : nullptr);
                 return hipSuccess;
             });
             if (rc) return rc;

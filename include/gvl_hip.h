@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GVL_ABI_VERSION 7
+#define GVL_ABI_VERSION 8
 
 enum {
     GVL_OK = 0,
@@ -496,7 +496,7 @@ typedef struct gvl_loader_batch {
  * geno_offset_idx, shifts, to_rc, out_offsets, annot_v_idxs, annot_ref_pos, tracks, track scratch,
  * sizes), for a full batch.  (Parts 2-5 are unused since the request arrays live in the epoch table.) */
 #define GVL_LOADER_SLOT_PARTS 12
-#define GVL_LOADER_TABLE_PARTS 7
+#define GVL_LOADER_TABLE_PARTS 8
 int64_t gvl_loader_slot_bytes(const gvl_loader_config *cfg, int64_t *part_offsets);
 /* `st` is copied; the device arrays it points to must outlive the loader. */
 int gvl_loader_create(const gvl_static *st, const gvl_loader_config *cfg, gvl_loader **out);
@@ -533,7 +533,9 @@ int gvl_loader_set_epoch(gvl_loader *ld, uint64_t epoch);
 /* Bytes of the epoch table for n queries and the offsets of its GVL_LOADER_TABLE_PARTS parts (regions i32
  * (n, 4), geno_offset_idx i64 (n, ploidy), shifts i32 (n, ploidy), to_rc u8 (n * ploidy), per-batch track
  * seeds u64 (ceil(n / batch_size)), and -- with tracks -- every batch's scratch-track offsets i64 (batch_size + 1
- * per batch) and the k * output_length row offsets i64 (batch_size * ploidy + 1) the realignment reads).  The table is the
+ * per batch), the k * output_length row offsets i64 (batch_size * ploidy + 1) the realignment reads and, for rows of several
+ * 2048-value chunks, the realignment walk's state per (row, chunk) (32 B each; left out when an epoch's would exceed
+ * GVL_WALK_STATE_MAX_MB, default 512)).  The table is the
  * caller's device memory (256-byte aligned) and must stay alive until the epoch ends; batch j's
  * request arrays are rows [j * batch_size, ...) of its parts. */
 int64_t gvl_loader_table_bytes(const gvl_loader_config *cfg, int64_t n, int64_t *part_offsets);

@@ -488,6 +488,60 @@ def test_tracks_batch_long_rows_jitter_and_dense_lists(oracle, dbg):
         _lib.load().gvl_set_debug_flags(-1)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dbg", [0, 268435456], ids=["walk-states", "walk-from-the-first-variant"])
+@pytest.mark.parametrize("python_loop", [False, True], ids=["epoch-table-states", "per-call-states"])
+@pytest.mark.parametrize("strategy,param", [(0, 0.0), (4, 3.0)], ids=["repeat5p", "interpolate"])
+def test_tracks_walk_states_rows_of_many_trips(oracle, dbg, python_loop, strategy, param):
+    """Rows of 20 chunks with ~200 variants each (4 trips of the realignment's planned walk), random shifts and jitter: a chunk's
+    wave starts its walk at the trip its state names (track_walk_states_kernel: once per epoch with the native ring's table, once
+    per gvl_tracks_batch call otherwise) -- against the oracle, and with GVL_DBG = 268435456 (no states) the same."""
+    from genvarloader_amd import HapsDevice, _lib
+    from genvarloader_amd.loader import DeviceHapsTracksDataset
+
+    R, S, P, L = 2, 3, 2, 40000
+    st, full_regions, go, gv = _grid_dataset(311, R, S, P, L, contig=300_000, indel_frac=0.5, slack=120)
+    assert (go[1] - go[0]).max() > 130
+    rng = np.random.default_rng(12)
+    starts, ends, vals, offs = [], [], [], [0]
+    for r in range(R):
+        for s_ in range(S):
+            pos = int(full_regions[r, 1]) - 200
+            while pos < int(full_regions[r, 2]) + 400:
+                w, gap = int(rng.geometric(1 / 25)), int(rng.geometric(1 / 8))
+                starts.append(pos + gap); ends.append(pos + gap + w); vals.append(float(rng.random() * 5)); pos += gap + w
+            offs.append(len(starts))
+    tracks = {"t": (np.array(starts, np.int32), np.array(ends, np.int32), np.array(vals, np.float32), np.array(offs, np.int64))}
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+    _lib.load().gvl_set_debug_flags(dbg)
+    try:
+        ds = DeviceHapsTracksDataset(dev, full_regions, S, P, tracks=tracks, strategy_id=strategy, param=param, output_length=L,
+                                     jitter=53, deterministic=False, onehot=False, haps=True, seed=3)
+        n = 0
+        for batch in ds.to_dataloader(batch_size=4, shuffle=True, seed=2, in_flight=2, group=1, python_loop=python_loop):
+            idx = batch.idx.cpu().numpy()
+            regions, shifts = batch.regions.cpu().numpy(), batch.shifts.cpu().numpy()
+            goi = batch.geno_offset_idx.cpu().numpy()
+            to_rc = batch.to_rc.cpu().numpy().astype(bool)
+            n += int((shifts > 0).sum())
+            diffs = oracle.get_diffs_sparse(goi, gv, go, st.ilens, None, None, regions[:, 1], regions[:, 2], st.v_starts)
+            tlen = (regions[:, 2] - regions[:, 1]).astype(np.int64) - np.minimum(diffs.min(axis=1), 0)
+            track_offsets = np.concatenate([[0], np.cumsum(tlen)]).astype(np.int64)
+            out_offsets = np.arange(len(idx) * P + 1, dtype=np.int64) * L
+            a, e, v, io = tracks["t"]
+            exp = np.zeros(len(idx) * P * L, np.float32)
+            oracle.intervals_and_realign_track_fused(exp, out_offsets, regions, shifts, goi, gv, go, st.v_starts, st.ilens,
+                                                     idx.astype(np.int64), a, e, v, io, track_offsets, np.array([param]), strategy,
+                                                     0, None, None, to_rc)
+            got = batch.tracks[:, 0].contiguous().cpu().numpy().ravel()
+            np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32))
+        assert n > 0                      # (some rows start inside their shift)
+    finally:
+        _lib.load().gvl_set_debug_flags(-1)
+
+
 @pytest.fixture(params=[0, 134217728, 67108864, 33554432], ids=["default", "sizing-per-batch", "no-pipelined-kernel", "pipelined-one-workgroup"])
 def ragged_path(request):
     """Ragged rows reach their output through the lean kernel's pipelined form behind ONE sizing per group of batches (default), behind
