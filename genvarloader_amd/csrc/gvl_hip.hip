@@ -2668,11 +2668,16 @@ struct TrackArgs {
     const u64 *seed_ptr;        // non-NULL: base_seed is read from the device (the native loop's per-batch seeds)
     float *out;
     int dbg;
-    const struct TrackWalkState *ws;    // non-NULL: per (row, chunk) where the planned walk may start (track_walk_states_kernel)
+    const int2 *plan_hdr; const i32x4 *plan_ent;   // non-NULL: the rows' entry tables + per (row, chunk) which of them (track_plan_kernel)
+    u64 *stamps;                        // diagnostics (gvl_diag_set_stamps): words 8.. count the chunk-waves that leave the common path
 };
-// The planned walk's carries at the top of a 64-variant trip: a chunk whose state says `tb` starts its walk there instead of
-// at the row's first variant (everything in front of that trip ends at or in front of the chunk's first value).  tb < 0: none.
-struct TrackWalkState { int tb, rem, tidx0, pm_carry, x_carry, tidx_end, out_end, pad_; };
+// A row's plan (track_plan_kernel): the entries of the WHOLE row -- {first value, kind, delta / position, fill length}, in
+// output order, at most PLAN_MAXE -- and per chunk {first entry that reaches into it, how many do}; count < 0: not planned,
+// the chunk's wave walks the row's variants itself.
+constexpr int PLAN_MAXE = 128;
+static inline i64 track_plan_bytes(i64 n_rows, i64 chunks) {      // headers, 256-byte aligned, then the entry tables
+    return ((n_rows * chunks * (i64)sizeof(int2) + 255) & ~255ll) + n_rows * (i64)PLAN_MAXE * (i64)sizeof(i32x4);
+}
 enum : int { T_TRACK = 0, T_REPEAT = 1, T_FILL = 2, T_ZERO = 3 };
 struct TrackMirror { int out[SEG_CAP]; int kind[SEG_CAP]; int plo[SEG_CAP]; int phi[SEG_CAP]; int vlen[SEG_CAP]; };
 
@@ -2754,12 +2759,16 @@ struct SrcPainted {
     const PaintWin *W; i64 x_lo; int wlen; int base; bool win_ok;
     i64 tlen, qs, idx;
     u64 ps_kernarg;
+    u64 *stamps;
     __device__ __forceinline__ float in_win(const int r) const {
         const u32 wd = W->bm[r >> 5];
         const int ig = base + (int)W->pre[r >> 5] + __builtin_popcount(wd & (0xFFFFFFFFu >> (31 - (r & 31))));
         return (ig >= 0 && W->ce[ig] > r) ? W->cv[ig] : 0.0f;
     }
-    __device__ __forceinline__ float in_list(const i64 j) const { return paint_list_value(ps_kernarg, idx, qs, j); }
+    __device__ __forceinline__ float in_list(const i64 j) const {
+        if (stamps) atomicAdd((unsigned long long *)&stamps[14], 1ull);             // positions looked up in the list itself
+        return paint_list_value(ps_kernarg, idx, qs, j);
+    }
     __device__ __forceinline__ float at(const i64 x) const {
         if (x < 0 || x >= tlen) return 0.0f;
         const i64 r = x - x_lo;
@@ -2841,6 +2850,8 @@ struct SrcPainted {
     }
 };
 
+__device__ __forceinline__ bool S_win_ok(const SrcPainted &S) { return S.win_ok; }
+__device__ __forceinline__ bool S_win_ok(const SrcGlobal &) { return true; }
 // One value of an insertion-fill region: src/tracks/mod.rs:87-190, evaluated per position.
 // `i` = offset inside the region, `pp` = output index in the row.
 template <class Src>
@@ -2889,6 +2900,9 @@ template <bool PAINT>
 __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, const PaintSrcArgs PS_) {
     __shared__ TrackMirror mirror[4];
     __shared__ PaintWin wins[PAINT ? 4 : 1];
+    // a double trip's 512 values on their way from "eight consecutive ones per lane" (how they are looked up) to "four per lane,
+    // one contiguous KB per store instruction" (how they have to be stored, see the tight loop)
+    __shared__ __attribute__((aligned(16))) float xpose[4][2 * TRIP];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = rfl((int)(threadIdx.x >> 6));
     TrackMirror &M = mirror[wave];
@@ -2924,10 +2938,10 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
     const int rc_word = A.to_rc ? ((KInt)(rc_addr & ~3ull))[0] : 0;
     i64 idx_raw = 0;                        // (the interval list's number)
     // (the chunk's walk state, if the caller prepared them: eight scalars of the same round)
-    int ws_tb = -1, ws_rem = 0, ws_tidx0 = 0, ws_pm = 0, ws_x = 0, ws_tend = 0, ws_oend = 0;
-    if (A.ws) {
-        const KInt w = (KInt)(u64)(A.ws + (k * (i64)gridDim.y + (i64)blockIdx.y));
-        ws_tb = w[0]; ws_rem = w[1]; ws_tidx0 = w[2]; ws_pm = w[3]; ws_x = w[4]; ws_tend = w[5]; ws_oend = w[6];
+    int ph_first = 0, ph_count = -1;
+    if (A.plan_hdr) {
+        const KInt w = (KInt)(u64)(A.plan_hdr + (k * (i64)gridDim.y + (i64)blockIdx.y));
+        ph_first = w[0]; ph_count = w[1];
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (PAINT) idx_raw = ((KI64)(u64)oi_ptr)[query];
@@ -2972,6 +2986,19 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
         out_idx = L;
         walk_done = true;
     }
+    // The row was planned as a whole (track_plan_kernel: by the native loop with its epoch table, or once per gvl_tracks_batch
+    // call): the chunk's entries are `ph_count` consecutive ones of the row's table -- one read, no walk.
+    if (!walk_done && ph_count > 0 && ph_count <= SEG_CAP && !(A.dbg & (8 | 268435456))) {
+        if (lane < ph_count) {
+            const i32x4 e = A.plan_ent[k * (i64)PLAN_MAXE + ph_first + lane];
+            M.out[lane] = e.x; M.kind[lane] = (e.y == T_FILL && A.strategy == GVL_FILL_REPEAT_5P) ? (int)T_REPEAT : e.y;
+            M.plo[lane] = e.z; M.phi[lane] = e.z >> 31; M.vlen[lane] = e.w;
+        }
+        nseg = ph_count;
+        out_idx = L;
+        walk_done = true;
+        if (A.stamps && lane == 0) atomicAdd((unsigned long long *)&A.stamps[15], 1ull);       // chunk-waves that read their plan
+    }
 
     // Planned walk: the same restatement as reconstruct_kernel's P3 (lane j = variant j, wave
     // scans for "first ALT wins" and the output offsets), with the track rules: SNPs only take
@@ -2985,10 +3012,7 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
         bool ended = false, past_chunk = false;
         int tidx_end = 0, out_end = 0;
         int n_ent = 0;
-        int tb0 = 0;
-        if (ok && ws_tb > 0 && ws_tb < n_var && ws_oend <= lo_clip && !(A.dbg & 268435456)) {
-            tb0 = ws_tb; rem = ws_rem; tidx0 = ws_tidx0; pm_carry = ws_pm; x_carry = ws_x; tidx_end = ws_tend; out_end = ws_oend;
-        }
+        const int tb0 = 0;
         const int qs = (int)(ok ? q_start : 0);
         auto put = [&](int q, int kind, int o_start, i64 pval, int vlen) {
             if (q < SEG_CAP) {
@@ -3144,6 +3168,7 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
         S.W = &wins[wave]; S.x_lo = 0; S.wlen = 0; S.base = -1; S.win_ok = false;
         S.tlen = tlen; S.qs = q_start; S.idx = idx;
         S.ps_kernarg = (u64)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(TrackArgs);
+        S.stamps = A.stamps;
     } else {
         S.track = track; S.tlen = tlen;
     }
@@ -3261,6 +3286,10 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
         if constexpr (PAINT) { S.x_lo = x_lo; S.wlen = wlen; S.base = n_before - 1; S.win_ok = !(A.dbg & 2097152); }
     };
 
+    if (A.stamps && lane == 0) {
+        atomicAdd((unsigned long long *)&A.stamps[8], 1ull);                       // chunk-waves
+        if (!walk_done) atomicAdd((unsigned long long *)&A.stamps[9], 1ull);       // ... that replay the walk on the scalar unit
+    }
     for (;;) {
         while (!walk_done && nseg <= SEG_FLUSH) {
             bool stop = (vi >= n_var) || (out_idx >= hi_clip);
@@ -3347,136 +3376,144 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
             const i64 pv = (i64)(((u64)(u32)rfl(M.phi[0]) << 32) | (u32)rfl(M.plo[0]));
             build_window(rfl(M.kind[0]) == T_TRACK ? pv + emit_pos : pv);
         }
-        // a table of at most 4 entries (a chunk with one indel: run | fill | run) keeps its starts on the scalar side
-        const bool small_tab = nseg <= 4;
-        const int so1 = (small_tab && nseg > 1) ? rfl(M.out[1]) : 0x7FFFFFFF;
-        const int so2 = (small_tab && nseg > 2) ? rfl(M.out[2]) : 0x7FFFFFFF;
-        const int so3 = (small_tab && nseg > 3) ? rfl(M.out[3]) : 0x7FFFFFFF;
-        // ... and so do their kinds and deltas when those fit 32 bits (the planned walk's always do): a trip that lies
-        // inside ONE track run -- all of them in a chunk without an indel -- needs no per-lane entry lookup
-        int sk[4], sp[4];
-        bool tab32 = small_tab && tlen < 0x7FFFFF00ll;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            sk[t] = T_ZERO; sp[t] = 0;
-            if (small_tab && t < nseg) {
-                sk[t] = rfl(M.kind[t]); sp[t] = rfl(M.plo[t]);
-                tab32 = tab32 && rfl(M.phi[t]) == (sp[t] >> 31);
-            }
-        }
+        // The round's entries, lane t = entry t (they are few: a chunk with one indel is run | fill | run); what a trip needs of
+        // them is wave-uniform -- the entry its first position lies in (a ballot over the starts), that entry's kind, delta and
+        // end (readlanes) -- so a trip inside ONE track run, which is all of them in a chunk without an indel and most in any
+        // other, needs no per-lane lookup however long the table is.  (Until round 4 only tables of <= 4 entries were
+        // dispatched this way, with their starts held in scalar registers: a chunk with two indels took the per-lane path on all
+        // of its trips -- 6.5 % of BASELINE config 4's chunk-waves, two thirds of that path's trips.)
+        const bool ev = lane < nseg;
+        // (kind + 256: the entry's delta does not fit 32 bits -- its high word and a fill's length stay in LDS, read where needed)
+        const int e_out = ev ? M.out[lane] : 0x7FFFFFFF, e_plo = ev ? M.plo[lane] : 0;
+        const int e_kind = ev ? (M.kind[lane] | (M.phi[lane] == (e_plo >> 31) ? 0 : 256)) : T_ZERO;
+        const bool tl32 = tlen < 0x7FFFFF00ll;
         if (A.dbg & 16777216) return;             // (timing ablation: ... + the window)
-        // the track run the round begins in (the whole chunk, where no indel falls into it): its double trips in a tight
-        // loop -- position and output pointer advance by a constant, nothing is selected per trip
-        int p_begin = emit_pos;
-        if (tab32 && sk[0] == T_TRACK) {
-            int run_end = so1 < cov ? so1 : cov;
-            run_end = run_end < limit ? run_end : limit;
-            const i64 xs0 = (i64)sp[0] + emit_pos;
-            const int n2 = (run_end - emit_pos) / (2 * TRIP);
-            if (n2 > 0 && xs0 >= 0 && xs0 + (i64)n2 * (2 * TRIP) <= tlen) {
-                int x = (int)xs0 + 2 * GROUP * lane;
-                float *o = rc ? out_row + (L - 2 * GROUP - (emit_pos + 2 * GROUP * lane)) : out_row + (emit_pos + 2 * GROUP * lane);
-                const int ostep = rc ? -2 * TRIP : 2 * TRIP;
-#pragma unroll 1
-                for (int i = 0; i < n2; ++i) {
-                    float v8[2 * GROUP];
-                    S.at8i(x, v8);
-                    if (!rc) {
-                        store_f32x4(o, v8[0], v8[1], v8[2], v8[3]);
-                        store_f32x4(o + GROUP, v8[4], v8[5], v8[6], v8[7]);
-                    } else {
-                        store_f32x4(o, v8[7], v8[6], v8[5], v8[4]);
-                        store_f32x4(o + GROUP, v8[3], v8[2], v8[1], v8[0]);
-                    }
-                    x += 2 * TRIP; o += ostep;
-                }
-                p_begin = emit_pos + n2 * (2 * TRIP);
-            }
+        if (A.stamps && lane == 0) {
+            if (PAINT && !S_win_ok(S)) atomicAdd((unsigned long long *)&A.stamps[10], 1ull);     // ... without a window
+            if (nseg > 4) atomicAdd((unsigned long long *)&A.stamps[11], 1ull);                   // ... with more than 4 entries
+            atomicAdd((unsigned long long *)&A.stamps[12], (unsigned long long)nseg);
         }
-        for (int p0 = p_begin; p0 < limit; p0 += TRIP) {
-            if (tab32 && p0 + TRIP <= limit) {
-                const int fli = (p0 >= so1 ? 1 : 0) + (p0 >= so2 ? 1 : 0) + (p0 >= so3 ? 1 : 0);
-                {   // two trips at once, eight values per lane, when the run reaches that far (half the lookups per value)
-                    const int fnx2 = fli == 0 ? so1 : (fli == 1 ? so2 : (fli == 2 ? so3 : 0x7FFFFFFF));
-                    const int fk2 = fli == 0 ? sk[0] : (fli == 1 ? sk[1] : (fli == 2 ? sk[2] : sk[3]));
-                    const int fp2 = fli == 0 ? sp[0] : (fli == 1 ? sp[1] : (fli == 2 ? sp[2] : sp[3]));
-                    const i64 xs2 = (i64)fp2 + p0;
-                    if (fk2 == T_TRACK && p0 + 2 * TRIP <= limit && p0 + 2 * TRIP <= (fnx2 < cov ? fnx2 : cov) && xs2 >= 0 &&
-                        xs2 + 2 * TRIP <= tlen) {
-                        float v8[2 * GROUP];
-                        const int p = p0 + 2 * GROUP * lane;
-                        S.at8i((int)xs2 + 2 * GROUP * lane, v8);
-                        if (!rc) {
-                            store_f32x4(out_row + p, v8[0], v8[1], v8[2], v8[3]);
-                            store_f32x4(out_row + p + GROUP, v8[4], v8[5], v8[6], v8[7]);
-                        } else {
-                            store_f32x4(out_row + (L - 2 * GROUP - p), v8[7], v8[6], v8[5], v8[4]);
-                            store_f32x4(out_row + (L - GROUP - p), v8[3], v8[2], v8[1], v8[0]);
+        int p0 = emit_pos;
+        while (p0 < limit) {
+            // the entry p0 lies in: the last one that starts at or in front of it
+            int li = __builtin_popcountll(__builtin_amdgcn_ballot_w64(ev && e_out <= p0)) - 1;
+            li = li < 0 ? 0 : li;
+            {
+                const int kd = rdl(e_kind, li), plo = rdl(e_plo, li);
+                int nx = li + 1 < nseg ? rdl(e_out, li + 1) : cov;
+                nx = nx < cov ? nx : cov;
+                const int run_end = nx < limit ? nx : limit;
+                if (nseg > 0 && kd == T_TRACK && tl32 && run_end - p0 >= TRIP) {
+                    const i64 xs0 = (i64)plo + p0;
+                    const int n2 = (run_end - p0) / (2 * TRIP);
+                    // the run's double trips in a tight loop -- position and output pointer advance by a constant, nothing is
+                    // selected per trip, eight values per lane (half the lookups per value)
+                    if (n2 > 0 && xs0 >= 0 && xs0 + (i64)n2 * (2 * TRIP) <= tlen) {
+                        // Stored as they are looked up -- two 16-byte stores per lane, 32 bytes from lane to lane -- every store
+                        // instruction would write 64 half-lines: measured, that pattern costs the kernel 10 of its 49 us, and
+                        // with one contiguous KB per instruction the stores cost nothing (same time as no stores at all).  So
+                        // the eight values go through LDS: written as looked up, read back four per lane.
+                        int x = (int)xs0 + 2 * GROUP * lane;
+                        float *const xp = xpose[wave];
+                        float *o = rc ? out_row + (L - GROUP - (p0 + GROUP * lane)) : out_row + (p0 + GROUP * lane);
+                        const int ostep = rc ? -2 * TRIP : 2 * TRIP;
+#pragma unroll 1
+                        for (int i = 0; i < n2; ++i) {
+                            float v8[2 * GROUP];
+                            S.at8i(x, v8);
+                            {
+                                const v4f_t a = {v8[0], v8[1], v8[2], v8[3]}, b = {v8[4], v8[5], v8[6], v8[7]};
+                                *reinterpret_cast<v4f_t *>(xp + 2 * GROUP * lane) = a;
+                                *reinterpret_cast<v4f_t *>(xp + 2 * GROUP * lane + GROUP) = b;
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            const v4f_t q1 = *reinterpret_cast<const v4f_t *>(xp + GROUP * lane);
+                            const v4f_t q2 = *reinterpret_cast<const v4f_t *>(xp + TRIP + GROUP * lane);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            if (!rc) {
+                                store_f32x4(o, q1[0], q1[1], q1[2], q1[3]);
+                                store_f32x4(o + TRIP, q2[0], q2[1], q2[2], q2[3]);
+                            } else {
+                                store_f32x4(o, q1[3], q1[2], q1[1], q1[0]);
+                                store_f32x4(o - TRIP, q2[3], q2[2], q2[1], q2[0]);
+                            }
+                            x += 2 * TRIP; o += ostep;
                         }
-                        p0 += TRIP;                   // (the loop adds the other one)
+                        p0 += n2 * (2 * TRIP);
+                        continue;
+                    }
+                    if (xs0 >= 0 && xs0 + TRIP <= tlen) {       // one trip of the run
+                        float v4[GROUP];
+                        const int p = p0 + GROUP * lane;
+                        S.at4i((int)xs0 + GROUP * lane, v4);
+                        if (!rc) store_f32x4(out_row + p, v4[0], v4[1], v4[2], v4[3]);
+                        else store_f32x4(out_row + (L - GROUP - p), v4[3], v4[2], v4[1], v4[0]);
+                        p0 += TRIP;
                         continue;
                     }
                 }
-                const int fnx = fli == 0 ? so1 : (fli == 1 ? so2 : (fli == 2 ? so3 : 0x7FFFFFFF));
-                const int fk = fli == 0 ? sk[0] : (fli == 1 ? sk[1] : (fli == 2 ? sk[2] : sk[3]));
-                const int fp = fli == 0 ? sp[0] : (fli == 1 ? sp[1] : (fli == 2 ? sp[2] : sp[3]));
-                const i64 xs = (i64)fp + p0;
-                if (fk == T_TRACK && p0 + TRIP <= (fnx < cov ? fnx : cov) && xs >= 0 && xs + TRIP <= tlen) {
-                    float v4[GROUP];
-                    const int p = p0 + GROUP * lane;
-                    S.at4i((int)xs + GROUP * lane, v4);
-                    if (!rc) store_f32x4(out_row + p, v4[0], v4[1], v4[2], v4[3]);
-                    else store_f32x4(out_row + (L - GROUP - p), v4[3], v4[2], v4[1], v4[0]);
-                    continue;
-                }
             }
+            // A trip that crosses entries (or reaches the row's end, or a track's): entry by entry, each wave-uniform -- its
+            // kind, delta and range are scalars, a lane takes from it the positions of its group that lie inside.
+            if (A.stamps && lane == 0) atomicAdd((unsigned long long *)&A.stamps[13], 1ull);    // trips on this path
             const int p = p0 + GROUP * lane;
-            if (p < limit) {
-                // segment holding p (three compares, or a binary search in the LDS mirror; nseg <= 64)
-                int li = 0;
-                if (small_tab) {
-                    li = (p >= so1 ? 1 : 0) + (p >= so2 ? 1 : 0) + (p >= so3 ? 1 : 0);
-                } else {
+            float v4[GROUP];
 #pragma unroll
-                    for (int step = 32; step > 0; step >>= 1) {
-                        const int t = li + step;
-                        if (t < nseg && M.out[t] <= p) li = t;
-                    }
-                }
-                const int nx = li + 1 < nseg ? M.out[li + 1] : cov;
-                float v4[GROUP];
-                const i64 pv0 = (i64)(((u64)(u32)M.phi[li] << 32) | (u32)M.plo[li]);
-                if (M.kind[li] == T_TRACK && p + GROUP <= nx && p + GROUP <= limit && pv0 + p >= 0 &&
-                    pv0 + p + GROUP <= tlen) {
-                    S.at4(pv0 + p, v4);
-                } else {
+            for (int g = 0; g < GROUP; ++g) v4[g] = 0.0f;
+            const int trip_end = (limit - p0 > TRIP) ? p0 + TRIP : limit;
+            if (nseg > 0) {
+#pragma unroll 1
+                for (;;) {
+                    const int st_e = rdl(e_out, li), kd = rdl(e_kind, li) & 255;
+                    const i64 pv = (i64)(((u64)(u32)rfl(M.phi[li]) << 32) | (u32)rdl(e_plo, li));
+                    int nx = li + 1 < nseg ? rdl(e_out, li + 1) : cov;
+                    nx = nx < trip_end ? nx : trip_end;
+                    const bool mine = p + GROUP > st_e && p < nx;              // some position of the lane's group is this entry's
+                    float t4[GROUP];
 #pragma unroll
-                    for (int i = 0; i < GROUP; ++i) {
-                        const int pp = p + i;
-                        float v = 0.0f;
-                        if (pp < limit) {
-                            while (li + 1 < nseg && M.out[li + 1] <= pp) ++li;
-                            const int kd = M.kind[li];
-                            const i64 pv = (i64)(((u64)(u32)M.phi[li] << 32) | (u32)M.plo[li]);
-                            if (kd == T_TRACK) v = S.at(pv + pp);
-                            else if (kd == T_REPEAT) v = S.at(pv);
-                            else if (kd == T_FILL) v = fill_value(A, S, pv, (i64)M.vlen[li], (i64)(pp - M.out[li]), (i64)pp, (u64)query, (u64)hap);
+                    for (int g = 0; g < GROUP; ++g) t4[g] = 0.0f;
+                    if (kd == T_TRACK) {
+                        if (mine) {
+                            const i64 x = pv + p;
+                            if (x >= 0 && x + GROUP <= tlen) {
+                                S.at4(x, t4);
+                            } else {
+#pragma unroll
+                                for (int g = 0; g < GROUP; ++g) t4[g] = S.at(x + g);
+                            }
                         }
-                        v4[i] = v;
-                    }
-                }
-                if (p + GROUP <= limit) {
-                    if (!rc) {
-                        store_f32x4(out_row + p, v4[0], v4[1], v4[2], v4[3]);
-                    } else {
-                        store_f32x4(out_row + (L - GROUP - p), v4[3], v4[2], v4[1], v4[0]);
-                    }
-                } else {
+                    } else if (kd == T_REPEAT) {
+                        const float v = S.at(pv);                               // (one position for the whole entry)
 #pragma unroll
-                    for (int i = 0; i < GROUP; ++i)
-                        if (p + i < limit) out_row[rc ? (L - 1 - (p + i)) : (p + i)] = v4[i];
+                        for (int g = 0; g < GROUP; ++g) t4[g] = v;
+                    } else if (kd == T_FILL) {
+                        const i64 vl = (i64)rfl(M.vlen[li]);
+#pragma unroll
+                        for (int g = 0; g < GROUP; ++g) {
+                            const int pp = p + g;
+                            if (pp >= st_e && pp < nx) t4[g] = fill_value(A, S, pv, vl, (i64)(pp - st_e), (i64)pp, (u64)query, (u64)hap);
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < GROUP; ++g)
+                        if (p + g >= st_e && p + g < nx) v4[g] = t4[g];
+                    if (nx >= trip_end || li + 1 >= nseg) break;
+                    ++li;
                 }
             }
+            if (p + GROUP <= limit) {
+                if (!rc) store_f32x4(out_row + p, v4[0], v4[1], v4[2], v4[3]);
+                else store_f32x4(out_row + (L - GROUP - p), v4[3], v4[2], v4[1], v4[0]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < GROUP; ++i)
+                    if (p + i < limit) out_row[rc ? (L - 1 - (p + i)) : (p + i)] = v4[i];
+            }
+            p0 += TRIP;
         }
         emit_pos = limit;
         if (walk_done || emit_pos >= hi_clip) break;
@@ -3495,15 +3532,15 @@ __global__ __launch_bounds__(256) void realign_tracks_kernel(const TrackArgs A, 
     }
 }
 
-// ---- walk states: realign_tracks_kernel's planned walk over a WHOLE row, once, no entries: the carries at the top of every
-// 64-variant trip, and for each chunk of the row the last trip whose top lies at or in front of the chunk's first value.
-// The kernel's chunk-waves then start there: one trip each (the one their variants are in) instead of every trip from the row's
-// first variant on (BASELINE config 4: 150 variants per row = 3 trips, 64 chunks: 2.2 trips per chunk-wave on average, a
-// fifth of the kernel's instructions).  One wave per row; a row the planned walk cannot express keeps the states in front of
-// where that shows (the chunk-waves find out for themselves).
-constexpr int WALK_TRIPS = 32;                  // trips whose tops are kept (rows with more variants: the later chunks start at the last kept one)
-__global__ __launch_bounds__(256) void track_walk_states_kernel(const TrackArgs A, TrackWalkState *ws, const int chunks, const i64 fixed_len) {
-    __shared__ int tops[4][7][WALK_TRIPS];
+// ---- row plans: realign_tracks_kernel's planned walk over a WHOLE row, once: every entry of the row into a table in memory
+// (at most PLAN_MAXE; 32-bit deltas), and per chunk of the row which of them reach into it.  The kernel's chunk-waves then read
+// their entries instead of walking: BASELINE config 4 has 176 variants per row = 3 trips of 64, of which a chunk-wave ran 2.2 on
+// average (wave scans, ballots, the records' loads: a quarter of the kernel's instructions) to find the 1.8 entries it
+// needs.  One wave per row; a row the planned walk cannot express, with more entries than the table holds or with a delta
+// beyond 32 bits is marked unplanned (count -1): its chunk-waves walk as before.
+__global__ __launch_bounds__(256) void track_plan_kernel(const TrackArgs A, int2 *hdr, i32x4 *ent_all, const int chunks, const i64 fixed_len,
+                                                          const i64 tl_bs) {
+    __shared__ int outs[4][PLAN_MAXE];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = rfl((int)(threadIdx.x >> 6));
     const i64 k = (i64)blockIdx.x * 4 + wave;
@@ -3518,21 +3555,29 @@ __global__ __launch_bounds__(256) void track_walk_states_kernel(const TrackArgs 
     const i64 keep_off = has_keep ? A.keep_offsets[k] : 0;
     const i64 o_s = A.go_starts[o_idx];
     const i64 nv64 = A.go_stops[o_idx] - o_s;
-    const int L = (int)(row_end - row_base);
+    const i64 L64 = row_end - row_base;
+    const int L = (int)L64;
     const int n_var = nv64 < 0 ? 0 : (nv64 > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)nv64);
-    int n_tops = 0;
-    bool ok = q_start > -(1ll << 30) && q_start < (1ll << 30) && shift >= 0 && shift < (1ll << 30) && !(A.dbg & 8);
+    // (tl_bs > 0: the loader's epoch table -- every batch of tl_bs queries has its own tl_bs + 1 offsets)
+    const i64 tq = tl_bs > 0 ? query + query / tl_bs : query;
+    const i64 tlen = A.track_offsets[tq + 1] - A.track_offsets[tq];
+    i32x4 *const ent = ent_all + k * (i64)PLAN_MAXE;
+    bool ok = q_start > -(1ll << 30) && q_start < (1ll << 30) && shift >= 0 && shift < (1ll << 30) && !(A.dbg & 8) && n_var > 0 &&
+              L64 > 0 && L64 < 0x7FFFFF00ll;
     int rem = (int)(ok ? shift : 0);
     int tidx0 = 0, pm_carry = 0, x_carry = 0;
     bool ended = false;
     int tidx_end = 0, out_end = 0;
+    int n_ent = 0;
     const int qs = (int)(ok ? q_start : 0);
-    for (int tb = 0; tb < n_var && ok && !ended && n_tops < WALK_TRIPS; tb += WAVE) {
-        if (lane == 0) {
-            tops[wave][0][n_tops] = tb; tops[wave][1][n_tops] = rem; tops[wave][2][n_tops] = tidx0; tops[wave][3][n_tops] = pm_carry;
-            tops[wave][4][n_tops] = x_carry; tops[wave][5][n_tops] = tidx_end; tops[wave][6][n_tops] = out_end;
+    auto put = [&](int q, int kind, int o_start, i64 pval, int vlen) {
+        if (q < PLAN_MAXE) {
+            const i32x4 e = {o_start, kind, (int)pval, vlen};
+            ent[q] = e;
+            outs[wave][q] = o_start;
         }
-        ++n_tops;
+    };
+    for (int tb = 0; tb < n_var && ok && !ended; tb += WAVE) {
         int pos = 0, d = 0;
         bool valid = tb + lane < n_var;
         if (valid) {
@@ -3612,26 +3657,67 @@ __global__ __launch_bounds__(256) void track_walk_states_kernel(const TrackArgs 
             tidx_end = rdl(E, last);
             out_end = rdl(fill_out, last) + rdl(w_i, last);
         }
+        // (the whole row is "the chunk": every run in front of an applied variant, every fill)
+        const bool e_trk = applied && n_i > 0 && fill_out > 0;
+        const bool e_fil = applied && w_i > 0;
+        const int slot0 = n_ent + wave_scan_exclusive<OpAdd>((e_trk ? 1 : 0) + (e_fil ? 1 : 0));
+        const int add_ent = __builtin_popcountll(__builtin_amdgcn_ballot_w64(e_trk)) +
+                            __builtin_popcountll(__builtin_amdgcn_ballot_w64(e_fil));
+        if (n_ent + add_ent + 2 > PLAN_MAXE) ok = false;
+        if (ok) {
+            int q = slot0;
+            if (e_trk) { put(q, T_TRACK, X, (i64)PM - X, 0); ++q; }
+            // (an insertion is T_FILL here whatever the fill: the plan serves every track of the batch, and a track may have
+            // its own strategy -- the reader turns it into T_REPEAT for Repeat5p)
+            if (e_fil) put(q, d > 0 ? T_FILL : T_REPEAT, fill_out, (i64)vrp, v_len);
+        }
         if (tb + WAVE < n_var) {
             const int mx = rdl(pm_incl, 63);
             pm_carry = mx > pm_carry ? mx : pm_carry;
             x_carry = OpSat::f(x_carry, rdl(x_incl, 63));
         }
+        n_ent += add_ent;
+    }
+    if (ok) {      // src/tracks/mod.rs:365-392: the tail
+        i64 t_idx = tidx_end;
+        if (rem > 0) t_idx = imin((i64)tidx0 + rem, tlen);
+        const int u = L - out_end;
+        if (u > 0 && lane == 0) {
+            const i64 avail = tlen - t_idx;
+            const int w = (int)imin((i64)u, avail);
+            int end = out_end;
+            int q = n_ent;
+            if (w > 0) {
+                end += w;
+                const i64 delta = t_idx - out_end;
+                if (delta < -(1ll << 30) || delta > (1ll << 30)) q = PLAN_MAXE + 1;
+                else { put(q, T_TRACK, out_end, delta, 0); ++q; }
+            }
+            if (end < L && q <= PLAN_MAXE) { put(q, T_ZERO, end, 0, 0); ++q; }
+            n_ent = q;
+        }
+        n_ent = rfl(n_ent);
+        if (n_ent > PLAN_MAXE) ok = false;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int2 *const h = hdr + k * (i64)chunks;
     for (int c = lane; c < chunks; c += WAVE) {
-        const i64 lo = (i64)c * A.chunk_len;
-        int t = -1;
-        for (int i = 0; i < n_tops; ++i)
-            if ((i64)tops[wave][6][i] <= lo) t = i;          // (out_end never decreases from trip to trip)
-        TrackWalkState S = {-1, 0, 0, 0, 0, 0, 0, 0};
-        if (t >= 0) {
-            S.tb = tops[wave][0][t]; S.rem = tops[wave][1][t]; S.tidx0 = tops[wave][2][t]; S.pm_carry = tops[wave][3][t];
-            S.x_carry = tops[wave][4][t]; S.tidx_end = tops[wave][5][t]; S.out_end = tops[wave][6][t];
+        int2 v = {0, -1};
+        const i64 lo = (i64)c * A.chunk_len, hi = lo + A.chunk_len;
+        if (ok && n_ent > 0 && lo < L64) {
+            // entries are in output order, the first one starts at 0: [first, last] = the last that starts at or in front of
+            // the chunk's first value ... the last that starts in front of its end
+            int first = 0, last = 0;
+            for (int i = 0; i < n_ent; ++i) {
+                const i64 o = outs[wave][i];
+                if (o <= lo) first = i;
+                if (o < hi) last = i;
+            }
+            v.x = first; v.y = last - first + 1;
         }
-        ws[k * (i64)chunks + c] = S;
+        h[c] = v;
     }
 }
 
@@ -5029,7 +5115,7 @@ int gvl_paint_tracks(const gvl_track_set *ts, const int64_t *offset_idxs, const 
 static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const float *tracks,
                                const int64_t *track_offsets, const double *params, int64_t strategy_id,
                                uint64_t base_seed, const u64 *seed_ptr, float *out, void *stream, const PaintSrcArgs *ps = nullptr,
-                               TrackWalkState *ws = nullptr, i64 ws_bytes = 0, bool ws_make = false);
+                               int2 *plan_hdr = nullptr, i32x4 *plan_ent = nullptr, bool plan_make = false);
 int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *tracks,
                        const int64_t *track_offsets, const double *params, int64_t strategy_id,
                        uint64_t base_seed, float *out, void *stream) {
@@ -5038,7 +5124,7 @@ int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *t
 static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const float *tracks,
                                const int64_t *track_offsets, const double *params, int64_t strategy_id,
                                uint64_t base_seed, const u64 *seed_ptr, float *out, void *stream, const PaintSrcArgs *ps,
-                               TrackWalkState *ws, i64 ws_bytes, bool ws_make) {
+                               int2 *plan_hdr, i32x4 *plan_ent, bool plan_make) {
     if (!st || !bt) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: NULL struct");
     if (bt->batch < 0 || bt->ploidy <= 0) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: bad batch/ploidy");
     if (bt->batch == 0) return GVL_OK;
@@ -5064,17 +5150,19 @@ static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const 
     A.param = params[0]; A.strategy = strategy_id; A.base_seed = base_seed; A.seed_ptr = seed_ptr;
     A.out = out;
     A.dbg = debug_flags();
+    A.stamps = g_stamps;
     if (A.n_rows > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: batch too large");
     const i64 grid = (A.n_rows + 3) / 4;
-    // rows of several chunks: the walk's state per (row, chunk), once per batch (the caller's scratch; every track of the batch
-    // reads the same ones -- the walk does not depend on the track)
-    if (ws && chunks > 1 && A.n_rows * (i64)chunks * (i64)sizeof(TrackWalkState) <= ws_bytes && !(A.dbg & (8 | 268435456))) {
-        if (ws_make) {
-            track_walk_states_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(A, ws, chunks, -1);
-            const int rc = check_launch("gvl_realign_tracks(walk states)");
+    // rows of several chunks: the rows' plans, once per batch (the caller's scratch; every track of the batch reads the same
+    // ones -- the walk does not depend on the track): headers (int2 per (row, chunk)), then the entry tables
+    // (int2 per (row, chunk) + PLAN_MAXE entries per row: the caller has made sure both fit)
+    if (plan_hdr && plan_ent && chunks > 1 && !(A.dbg & (8 | 268435456))) {
+        if (plan_make) {
+            track_plan_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(A, plan_hdr, plan_ent, chunks, -1, 0);
+            const int rc = check_launch("gvl_realign_tracks(row plans)");
             if (rc) return rc;
         }
-        A.ws = ws;
+        A.plan_hdr = plan_hdr; A.plan_ent = plan_ent;
     }
     // (GVL_TRACK_EXTRA_LDS: bytes of unused LDS per workgroup, to measure the kernel at fewer waves per SIMD)
     static const unsigned xl = [] { const char *e = getenv("GVL_TRACK_EXTRA_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
@@ -5085,11 +5173,11 @@ static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const 
 
 
 // scratch layout of gvl_tracks_batch: track_offsets i64 (batch + 1) | out_offsets i64 (batch * ploidy + 1) |
-// chunk records (16 B x batch * chunks) | scratch tracks f32 (batch * stride) | walk states (32 B x batch * ploidy * chunks)
+// chunk records (16 B x batch * chunks) | scratch tracks f32 (batch * stride) | row plans (track_plan_bytes)
 static void tracks_scratch_parts(i64 batch, i64 ploidy, i64 stride, i64 part[6]) {
     const i64 n_chunks = (stride + 2047) / 2048;
     const i64 sz[5] = {8 * (batch + 1), 8 * (batch * ploidy + 1), batch * n_chunks * (i64)sizeof(PaintTodo), 4 * batch * stride,
-                       n_chunks > 1 ? batch * ploidy * n_chunks * (i64)sizeof(TrackWalkState) : 0};
+                       n_chunks > 1 ? track_plan_bytes(batch * ploidy, n_chunks) : 0};
     i64 off = 0;
     for (int i = 0; i < 5; ++i) { part[i] = off; off += (sz[i] + 255) & ~255ll; }
     part[5] = off;
@@ -5106,7 +5194,7 @@ static int tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const in
                              int32_t n_tracks, const double *params, int64_t strategy_id, uint64_t base_seed, const u64 *seed_ptr,
                              float *out, int64_t out_track_stride, void *scratch, int64_t scratch_stride, void *stream,
                              const i64 *pre_track_offsets = nullptr, const i64 *pre_out_offsets = nullptr,
-                             const TrackWalkState *pre_ws = nullptr);
+                             const int2 *pre_plan_hdr = nullptr, const i32x4 *pre_plan_ent = nullptr);
 int gvl_tracks_batch(const gvl_static *st, const gvl_batch *bt, const int64_t *offset_idxs, const gvl_track_set *tracks,
                      int32_t n_tracks, const double *params, int64_t strategy_id, uint64_t base_seed, float *out,
                      int64_t out_track_stride, void *scratch, int64_t scratch_stride, void *stream) {
@@ -5116,7 +5204,7 @@ int gvl_tracks_batch(const gvl_static *st, const gvl_batch *bt, const int64_t *o
 static int tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const int64_t *offset_idxs, const gvl_track_set *tracks,
                              int32_t n_tracks, const double *params, int64_t strategy_id, uint64_t base_seed, const u64 *seed_ptr,
                              float *out, int64_t out_track_stride, void *scratch, int64_t scratch_stride, void *stream,
-                             const i64 *pre_track_offsets, const i64 *pre_out_offsets, const TrackWalkState *pre_ws) {
+                             const i64 *pre_track_offsets, const i64 *pre_out_offsets, const int2 *pre_plan_hdr, const i32x4 *pre_plan_ent) {
     if (!st || !bt || n_tracks < 0) return fail(GVL_ERR_INVALID, "%s", "gvl_tracks_batch: bad arguments");
     if (bt->batch < 0 || bt->ploidy <= 0 || bt->output_length < 0)
         return fail(GVL_ERR_INVALID, "%s", "gvl_tracks_batch: needs batch >= 0, ploidy > 0 and a fixed output_length");
@@ -5131,10 +5219,18 @@ static int tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const in
     i64 part[6];
     tracks_scratch_parts(B, P, scratch_stride, part);
     u8 *base = (u8 *)scratch;
-    // the walk's states: the caller's (the native loop prepares them with its epoch table) or made here, once per call
-    TrackWalkState *const ws = pre_ws ? const_cast<TrackWalkState *>(pre_ws) : (part[5] > part[4] ? (TrackWalkState *)(base + part[4]) : nullptr);
-    const i64 ws_bytes = pre_ws ? (1ll << 62) : part[5] - part[4];
-    bool ws_made = pre_ws != nullptr;
+    // the rows' plans: the caller's (the native loop prepares them with its epoch table) or made here, once per call
+    int2 *plan_hdr = const_cast<int2 *>(pre_plan_hdr);
+    i32x4 *plan_ent = const_cast<i32x4 *>(pre_plan_ent);
+    bool plan_made = plan_hdr != nullptr && plan_ent != nullptr;
+    if (!plan_made) {
+        plan_hdr = nullptr; plan_ent = nullptr;
+        int pc = 1, pcl = 0;
+        if (!pick_chunk(L, &pc, &pcl) && pc > 1 && track_plan_bytes(B * P, pc) <= part[5] - part[4]) {
+            plan_hdr = (int2 *)(base + part[4]);
+            plan_ent = (i32x4 *)(base + part[4] + ((B * P * (i64)pc * (i64)sizeof(int2) + 255) & ~255ll));
+        }
+    }
     i64 *track_offsets = (i64 *)(base + part[0]);
     i64 *out_offsets = (i64 *)(base + part[1]);
     PaintTodo *todo = (PaintTodo *)(base + part[2]);
@@ -5180,9 +5276,9 @@ static int tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const in
             PaintSrcArgs ps{(const i64 *)offset_idxs, T.list_div > 1 ? T.list_div : 1, T.itv_starts, T.itv_ends, T.itv_values,
                             (const i64 *)T.itv_offsets, T.itv_pmax_ends, X};
             rc = realign_tracks_impl(st, &rb, nullptr, (const int64_t *)track_offsets, T.has_fill ? t_par : params, t_strategy, base_seed,
-                                     seed_ptr, out + (i64)t * out_track_stride, stream, &ps, ws, ws_bytes, !ws_made);
+                                     seed_ptr, out + (i64)t * out_track_stride, stream, &ps, plan_hdr, plan_ent, !plan_made);
             if (rc) return rc;
-            ws_made = true;
+            plan_made = true;
             continue;
         }
         rc = paint_launch(offset_idxs, bt->regions + 1, bt->regions_stride, B, T.itv_starts, T.itv_ends, T.itv_values, T.itv_offsets,
@@ -5191,9 +5287,9 @@ static int tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const in
                           T.list_div > 1 ? T.list_div : 1);
         if (rc) return rc;
         rc = realign_tracks_impl(st, &rb, scr, (const int64_t *)track_offsets, T.has_fill ? t_par : params, t_strategy, base_seed, seed_ptr,
-                                 out + (i64)t * out_track_stride, stream, nullptr, ws, ws_bytes, !ws_made);
+                                 out + (i64)t * out_track_stride, stream, nullptr, plan_hdr, plan_ent, !plan_made);
         if (rc) return rc;
-        ws_made = true;
+        plan_made = true;
     }
     return GVL_OK;
 }
@@ -5277,7 +5373,7 @@ struct gvl_loader {
     i64 submitted, consumed;      // submitted: GROUPS handed to the GPU; consumed: BATCHES handed to the caller
     i64 released_groups;          // groups whose release has been recorded on the consumer's stream
     int G, n_sets;
-    TrackWalkState *e_track_ws;             // tracks, rows of several chunks: the walk's state per (row, chunk) of the epoch (or NULL)
+    int2 *e_plan_hdr; i32x4 *e_plan_ent;    // tracks, rows of several chunks: the rows' plans (track_plan_kernel) of the epoch (or NULL)
     int e_chunks;
     i64 *e_track_offsets, *e_out_offsets;   // tracks: every batch's scratch-track offsets ((bs + 1) per batch) and the k * L output offsets
     u64 counter;                  // the running epoch's number + 1 (keys the random draws together with cfg.seed)
@@ -5306,14 +5402,14 @@ struct LoaderSync {
 };
 
 static i64 align256(i64 x) { return (x + 255) & ~255ll; }
-// walk states of an epoch's rows (rows of several chunks only; an epoch whose states would not fit GVL_WALK_STATE_MAX_MB,
-// default 512, goes without: its chunk-waves then replay the walk from the row's first variant)
-static i64 loader_walk_state_bytes(const gvl_loader_config *cfg, i64 n, i64 state_bytes) {
+// the track plans of an epoch's rows (rows of several chunks only; an epoch whose plans would not fit GVL_TRACK_PLAN_MAX_MB,
+// default 512, goes without: its chunk-waves then walk their rows' variants themselves)
+static i64 loader_track_plan_bytes(const gvl_loader_config *cfg, i64 n) {
     if (cfg->output_length <= 2048) return 0;
     int chunks = 1, chunk_len = 0;
     if (pick_chunk(cfg->output_length, &chunks, &chunk_len) || chunks <= 1) return 0;
-    static const i64 cap = [] { const char *e = getenv("GVL_WALK_STATE_MAX_MB"); return (i64)(e ? atoll(e) : 512) << 20; }();
-    const i64 b = n * cfg->ploidy * (i64)chunks * state_bytes;
+    static const i64 cap = [] { const char *e = getenv("GVL_TRACK_PLAN_MAX_MB"); return (i64)(e ? atoll(e) : 512) << 20; }();
+    const i64 b = track_plan_bytes(n * cfg->ploidy, chunks);
     return b <= cap ? b : 0;
 }
 
@@ -5345,7 +5441,7 @@ int64_t gvl_loader_table_bytes(const gvl_loader_config *cfg, int64_t n, int64_t 
     const bool tr = cfg->n_tracks > 0;
     const i64 sizes[GVL_LOADER_TABLE_PARTS] = {16 * n, 8 * n * P, 4 * n * P, n * P, 8 * nb,
                                                tr ? 8 * (n + nb) : 0, tr ? 8 * (cfg->batch_size * P + 1) : 0,
-                                               tr ? loader_walk_state_bytes(cfg, n, (i64)sizeof(TrackWalkState)) : 0};
+                                               tr ? loader_track_plan_bytes(cfg, n) : 0};
     i64 off = 0;
     for (int i = 0; i < GVL_LOADER_TABLE_PARTS; ++i) {
         if (part_offsets) part_offsets[i] = off;
@@ -5492,7 +5588,7 @@ static int loader_fill_table(gvl_loader *ld, const int64_t *order, i64 n, int32_
         track_scan_batches_kernel<<<dim3((unsigned)n_batches), dim3(256), 0, s>>>(t_track_offsets, n_used, bs);
         rc3 = check_launch("gvl_loader_start_epoch(track offsets)");
         if (rc3) return rc3;
-        // rows of several chunks: where each chunk's walk may start (track_walk_states_kernel), for every row of the epoch
+        // rows of several chunks: the rows' plans (track_plan_kernel), for every row of the epoch
         if (po[8] > po[7] && !(debug_flags() & (8 | 268435456))) {
             TrackArgs TA;
             memset(&TA, 0, sizeof(TA));
@@ -5506,8 +5602,11 @@ static int loader_fill_table(gvl_loader *ld, const int64_t *order, i64 n, int32_
             TA.dbg = debug_flags();
             const i64 wgrid = (TA.n_rows + 3) / 4;
             if (wgrid > 0x7FFFFFFFll) return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_loader_start_epoch: too many rows for the walk states");
-            track_walk_states_kernel<<<dim3((unsigned)wgrid), dim3(256), 0, s>>>(TA, (TrackWalkState *)(base + po[7]), chunks, c.output_length);
-            rc3 = check_launch("gvl_loader_start_epoch(walk states)");
+            TA.track_offsets = t_track_offsets;
+            int2 *const ph = (int2 *)(base + po[7]);
+            i32x4 *const pe = (i32x4 *)(base + po[7] + align256(TA.n_rows * (i64)chunks * (i64)sizeof(int2)));
+            track_plan_kernel<<<dim3((unsigned)wgrid), dim3(256), 0, s>>>(TA, ph, pe, chunks, c.output_length, bs);
+            rc3 = check_launch("gvl_loader_start_epoch(row plans)");
             if (rc3) return rc3;
         }
     }
@@ -5580,11 +5679,15 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
         ld->e_seeds = (u64 *)(base + po[4]);
         ld->e_track_offsets = (i64 *)(base + po[5]);
         ld->e_out_offsets = (i64 *)(base + po[6]);
-        const i64 wsb = c.n_tracks > 0 ? loader_walk_state_bytes(&c, n, (i64)sizeof(TrackWalkState)) : 0;
-        ld->e_track_ws = (wsb > 0 && !(debug_flags() & (8 | 268435456))) ? (TrackWalkState *)(base + po[7]) : nullptr;
+        const i64 wsb = c.n_tracks > 0 ? loader_track_plan_bytes(&c, n) : 0;
         int cl = 0;
         ld->e_chunks = 1;
         if (wsb > 0) (void)pick_chunk(c.output_length, &ld->e_chunks, &cl);
+        const bool planned = wsb > 0 && !(debug_flags() & (8 | 268435456));
+        // (the table was filled for n_used = every query of a whole batch, or all n: the plan's two parts are laid out for that many rows)
+        const i64 n_used_rows = (drop_last ? (n / c.batch_size) * c.batch_size : n) * c.ploidy;
+        ld->e_plan_hdr = planned ? (int2 *)(base + po[7]) : nullptr;
+        ld->e_plan_ent = planned ? (i32x4 *)(base + po[7] + align256(n_used_rows * (i64)ld->e_chunks * (i64)sizeof(int2))) : nullptr;
     }
     const i64 bs = c.batch_size;
     ld->order = order; ld->n_order = n;
@@ -5716,7 +5819,8 @@ static int loader_submit(gvl_loader *ld, i64 g) {
                                        (const u64 *)o.track_seed, o.tracks, K * c.output_length, base + ld->part[10], c.scratch_stride, s,
                                        (debug_flags() & 131072) ? nullptr : ld->e_track_offsets + j * (c.batch_size + 1),
                                        (debug_flags() & 131072) ? nullptr : ld->e_out_offsets,
-                                       ld->e_track_ws ? ld->e_track_ws + j * c.batch_size * c.ploidy * (i64)ld->e_chunks : nullptr);
+                                       ld->e_plan_hdr ? ld->e_plan_hdr + j * c.batch_size * c.ploidy * (i64)ld->e_chunks : nullptr,
+                                       ld->e_plan_ent ? ld->e_plan_ent + j * c.batch_size * c.ploidy * (i64)PLAN_MAXE : nullptr);
                 return hipSuccess;
             });
             if (rc) return rc;

@@ -23,6 +23,7 @@ from __future__ import annotations
 from collections import deque
 from dataclasses import dataclass
 
+import os
 import numpy as np
 import torch
 
@@ -682,7 +683,12 @@ class DeviceLoader:
                 if (self.in_flight + 1) * g <= 64 and (self.in_flight + 1) * g * self._slot_bytes(g) <= (4 << 30):
                     self.group = g
                     break
-        n_slots = (self.in_flight + 1) * self.group
+        # slot sets: one per group in flight + the one the consumer holds; GVL_LOADER_EXTRA_SETS adds spare ones (a set's release
+        # -- consumer stream -> submit stream, two event hops -- then is off the critical path of the group that reuses it)
+        extra = max(1, int(os.environ.get("GVL_LOADER_EXTRA_SETS", "1")))
+        while extra > 1 and (self.in_flight + extra) * self.group > 64:
+            extra -= 1
+        n_slots = (self.in_flight + extra) * self.group
         cfg = GvlLoaderConfig(
             full_regions=ds.full_regions.data_ptr(), n_regions=ds.n_regions, n_samples=ds.n_samples, ploidy=ds.ploidy,
             batch_size=self.batch_size, output_length=ds.output_length, jitter=ds.jitter, rc_neg=int(ds.rc_neg),
@@ -859,12 +865,29 @@ class DeviceLoader:
                 # have switched streams since): the order's randperm and the table fill are then ordered on ONE stream, and that
                 # stream is the one gvl_loader_next sees in the same iteration
                 live = torch.cuda.current_stream(d)
-                norder = make_order(next_epoch)
-                nn = int(norder.numel())
-                ntab, _ = self._epoch_table(nn, 1 - which)
-                _lib.check(lib.gvl_loader_prefetch_epoch(handle, C.c_uint64(next_epoch & 0xFFFFFFFFFFFFFFFF),
-                                                         C.c_void_p(norder.data_ptr()), C.c_int64(nn), C.c_int32(int(self.drop_last)),
-                                                         C.c_void_p(ntab.data_ptr()), C.c_void_p(live.cuda_stream)))
+                # ... but not ON that stream: the consumer's stream carries the ring's release chain (wait for batch j, release the
+                # slot of batch j - 1, ...), and a dozen small kernels in the middle of it hold every release behind them up (BASELINE
+                # config 4, 8 batches per epoch: the ring stood still for ~100 us per epoch).  A side stream, ordered behind the point
+                # the consumer's stream has reached -- behind this epoch's first batch, hence behind every batch of the epoch that
+                # last used the other table -- fills it; the next epoch's batches wait for the fill through the loader's own event.
+                side = nat.get("side_stream")
+                if side is None:
+                    side = nat["side_stream"] = torch.cuda.Stream(device=d)
+                mark = nat.get("side_mark")
+                if mark is None:
+                    mark = nat["side_mark"] = torch.cuda.Event()
+                if os.environ.get("GVL_PREFETCH_ON_CONSUMER_STREAM"):
+                    side = live
+                else:
+                    mark.record(live)
+                    side.wait_event(mark)
+                with torch.cuda.stream(side):
+                    norder = make_order(next_epoch)
+                    nn = int(norder.numel())
+                    ntab, _ = self._epoch_table(nn, 1 - which)
+                    _lib.check(lib.gvl_loader_prefetch_epoch(handle, C.c_uint64(next_epoch & 0xFFFFFFFFFFFFFFFF),
+                                                             C.c_void_p(norder.data_ptr()), C.c_int64(nn), C.c_int32(int(self.drop_last)),
+                                                             C.c_void_p(ntab.data_ptr()), C.c_void_p(side.cuda_stream)))
                 nat["prefetch"] = (nkey, norder, 1 - which)
             nxt, ref_out, bs = lib.gvl_loader_next, C.byref(out), self.batch_size
             nxt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]          # plain ints in, no wrapper objects per call

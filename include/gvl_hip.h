@@ -520,9 +520,13 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
  * never started costs its kernels only.  `order` and `table` must stay alive until that epoch has ended.
  * Contract: call it from the CONSUMER's thread (the one that calls gvl_loader_next / gvl_loader_start_epoch; with
  * cfg.threaded the library's producer thread may be submitting meanwhile: the fill touches only the OTHER table and
- * state that only the consumer's thread reads; error strings are per thread), and `stream` must be the stream the later
- * gvl_loader_start_epoch for that epoch is called with (the prepared start does not wait for anything: it relies on
- * stream order between this fill and the epoch's first batches, which it makes wait for `stream` through an event). */
+ * state that only the consumer's thread reads; error strings are per thread).  `stream` is the stream `order` was produced
+ * on; it must be ordered BEHIND the last batch of the epoch that used `table` before (the prepared start waits for nothing:
+ * the epoch's first batches wait for this fill through an event recorded on `stream`, but nothing else orders the fill
+ * behind the batches that still read the table's previous contents): the consumer's stream once a batch of the running
+ * epoch has been waited for there, or -- better, because the consumer's stream also carries the ring's slot releases and the
+ * fill's kernels would hold them up -- a side stream that waits for an event recorded at that point of the consumer's
+ * stream (what genvarloader_amd/loader.py does). */
 int gvl_loader_prefetch_epoch(gvl_loader *ld, uint64_t epoch, const int64_t *order, int64_t n, int32_t drop_last,
                               void *table, void *stream);
 /* Name the epoch the next gvl_loader_start_epoch begins (like DistributedSampler.set_epoch).  The jitter /
@@ -534,8 +538,8 @@ int gvl_loader_set_epoch(gvl_loader *ld, uint64_t epoch);
  * (n, 4), geno_offset_idx i64 (n, ploidy), shifts i32 (n, ploidy), to_rc u8 (n * ploidy), per-batch track
  * seeds u64 (ceil(n / batch_size)), and -- with tracks -- every batch's scratch-track offsets i64 (batch_size + 1
  * per batch), the k * output_length row offsets i64 (batch_size * ploidy + 1) the realignment reads and, for rows of several
- * 2048-value chunks, the realignment walk's state per (row, chunk) (32 B each; left out when an epoch's would exceed
- * GVL_WALK_STATE_MAX_MB, default 512)).  The table is the
+ * 2048-value chunks, the rows' realignment plans (the row's entries, 2 KB per row, + 8 B per (row, chunk); left out when an
+ * epoch's would exceed GVL_TRACK_PLAN_MAX_MB, default 512)).  The table is the
  * caller's device memory (256-byte aligned) and must stay alive until the epoch ends; batch j's
  * request arrays are rows [j * batch_size, ...) of its parts. */
 int64_t gvl_loader_table_bytes(const gvl_loader_config *cfg, int64_t n, int64_t *part_offsets);

@@ -489,13 +489,14 @@ def test_tracks_batch_long_rows_jitter_and_dense_lists(oracle, dbg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dbg", [0, 268435456], ids=["walk-states", "walk-from-the-first-variant"])
-@pytest.mark.parametrize("python_loop", [False, True], ids=["epoch-table-states", "per-call-states"])
+@pytest.mark.parametrize("dbg", [0, 268435456], ids=["row-plans", "every-chunk-walks"])
+@pytest.mark.parametrize("python_loop", [False, True], ids=["epoch-table-plans", "per-call-plans"])
 @pytest.mark.parametrize("strategy,param", [(0, 0.0), (4, 3.0)], ids=["repeat5p", "interpolate"])
-def test_tracks_walk_states_rows_of_many_trips(oracle, dbg, python_loop, strategy, param):
+def test_tracks_row_plans_rows_of_many_trips(oracle, dbg, python_loop, strategy, param):
     """Rows of 20 chunks with ~200 variants each (4 trips of the realignment's planned walk), random shifts and jitter: a chunk's
-    wave starts its walk at the trip its state names (track_walk_states_kernel: once per epoch with the native ring's table, once
-    per gvl_tracks_batch call otherwise) -- against the oracle, and with GVL_DBG = 268435456 (no states) the same."""
+    wave reads its entries from the row's plan (track_plan_kernel: once per epoch with the native ring's table, once per
+    gvl_tracks_batch call otherwise) instead of walking the row's variants -- against the oracle, and with GVL_DBG = 268435456
+    (no plans: every chunk walks) the same."""
     from genvarloader_amd import HapsDevice, _lib
     from genvarloader_amd.loader import DeviceHapsTracksDataset
 

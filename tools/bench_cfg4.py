@@ -39,7 +39,7 @@ def build(device, R=16, S=64, P=2, L=131072, seed=20260802 + 4, contig=256 << 20
     from genvarloader_amd.loader import DeviceHapsTracksDataset
 
     rng = np.random.default_rng(seed)
-    st = synth.make_static(rng, (contig,), indel_frac=0.15)
+    st = synth.make_static(rng, (contig,), indel_frac=float(os.environ.get("GVL_CFG4_INDEL_FRAC", 0.15)))     # (0: what the chunks with indels cost)
     full_regions, go, gv = synth.make_grid(rng, st, R, S, P, L)
     starts, ends, vals, offs = [], [], [], [0]
     for r in range(R):
