@@ -4562,6 +4562,18 @@ static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_o
     return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 268435456)) == 0;
 }
 
+// ragged rows (out_offsets) longer than the pipelined form's 2560 bases: the chunked lean kernel's ragged form (<.., LONG, RAGL>)
+static bool lean_long_rag_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_out *out, int chunks, int chunk_len) {
+    if (!st->ref4 || !st->geno_rec || (!out->onehot && !out->haps) || !bt->out_offsets) return false;
+    if (out->annot_v_idxs || out->annot_ref_pos || (out->onehot && out->onehot_layout != GVL_ONEHOT_LC)) return false;
+    if (bt->keep || bt->keep_offsets) return false;
+    if (chunks < 2 || chunk_len != LEAN_MAX_TRIPS * TRIP || (debug_flags() & (1048576 | 16))) return false;
+    const i64 n_rows = bt->batch * bt->ploidy;
+    if (n_rows <= 0 || n_rows * chunks > 0x7FFFFFF0ll) return false;
+    if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;
+    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 268435456)) == 0;
+}
+
 static int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
     LeanArgs A;
     memset(&A, 0, sizeof(A));
@@ -4583,7 +4595,14 @@ static int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
     const dim3 g(grid), b(LEAN_THREADS);
     hipStream_t s = (hipStream_t)stream;
     static const unsigned xl = [] { const char *e = getenv("GVL_LEAN_EXTRA_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
-    if (chunks > 1) {
+    if (chunks > 1 && RA.out_offsets) {         // ragged long rows (lean_long_rag_eligible)
+        A.out_offsets = RA.out_offsets;
+        A.out_offsets_w = nullptr;
+        A.L = 0;
+        if (A.onehot && A.haps) recon_lean_kernel<true, true, true, true><<<g, b, 0, s>>>(A, RA);
+        else if (A.onehot) recon_lean_kernel<true, false, true, true><<<g, b, 0, s>>>(A, RA);
+        else recon_lean_kernel<false, true, true, true><<<g, b, 0, s>>>(A, RA);
+    } else if (chunks > 1) {
         if (A.onehot && A.haps) recon_lean_kernel<true, true, true><<<g, b, 0, s>>>(A, RA);
         else if (A.onehot) recon_lean_kernel<true, false, true><<<g, b, 0, s>>>(A, RA);
         else recon_lean_kernel<false, true, true><<<g, b, 0, s>>>(A, RA);
@@ -4718,6 +4737,7 @@ int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *ou
     }
     if (A.n_rows > 0 && !(debug_flags() & 67108864) && lean_rag_eligible(st, bt, out) && lean_pipe_compatible(&A, 1))
         return launch_lean_rows(&A, 1, stream, chunks);
+    if (A.n_rows > 0 && lean_long_rag_eligible(st, bt, out, chunks, A.chunk_len)) return launch_lean(A, chunks, stream);
     return launch_recon(A, chunks, variant, stream);
 }
 
@@ -4738,7 +4758,8 @@ int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_o
         chunks[i] = 1; variant[i] = 0;
         const int rc = fill_recon_args(st, &bts[i], &outs[i], A[i], &chunks[i], &variant[i]);
         if (rc) return rc;
-        lean[i] = A[i].n_rows > 0 && lean_eligible(st, &bts[i], &outs[i], chunks[i], A[i].chunk_len);
+        lean[i] = A[i].n_rows > 0 && (lean_eligible(st, &bts[i], &outs[i], chunks[i], A[i].chunk_len) ||
+                                      (!lean_rag_eligible(st, &bts[i], &outs[i]) && lean_long_rag_eligible(st, &bts[i], &outs[i], chunks[i], A[i].chunk_len)));
         all_one_chunk_lean = all_one_chunk_lean && lean[i] && chunks[i] == 1;
         all_rag = all_rag && A[i].n_rows > 0 && lean_rag_eligible(st, &bts[i], &outs[i]);
         total += A[i].n_rows;

@@ -105,3 +105,15 @@ def test_fuzz_tracks_straight_from_intervals(dbg):
     """tools/fuzz_fused_tracks.py: realign_tracks_kernel<PAINT> (BASELINE config 4's track kernel): a batch's tracks realigned
     straight from their intervals, `tile_complete` interval sets."""
     _run("fuzz_fused_tracks.py", 150, 220, dbg=dbg)
+
+
+@pytest.mark.parametrize("dbg,sub", [(0, 2), (32768, 2), (65536, 2), (0, 1), (1048576, 2)],
+                         ids=["default", "every-chunk-solo", "rereads", "one-chunk-per-wave", "all-purpose-kernel"])
+def test_fuzz_lean_kernel_ragged_long_rows(dbg, sub):
+    """FUZZ_LONG=1 FUZZ_RAGGED=1: ragged rows (output_length = -1) of 2 052 ... 40 000 bases = recon_lean_kernel<.., LONG, RAGL>."""
+    _run("fuzz_lean.py", 120, 230 + sub + (dbg >> 15), dbg=dbg, FUZZ_LONG=1, FUZZ_RAGGED=1, GVL_LEAN_SUB=sub)
+
+
+def test_fuzz_lean_kernel_ragged_short_rows():
+    """FUZZ_RAGGED=1: ragged rows of at most 2 048 + 6 bases = recon_lean_rows_kernel's ragged form."""
+    _run("fuzz_lean.py", 300, 240, FUZZ_RAGGED=1)

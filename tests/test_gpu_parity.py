@@ -417,6 +417,30 @@ def test_ragged_mode(gpu, oracle, seed, kpath):
     assert tm.cpu().tolist() == [int(exp_off[-1]), int(np.diff(exp_off).max())]
 
 
+@pytest.mark.parametrize("outputs", ["onehot+haps", "onehot", "haps"])
+def test_ragged_long_rows(gpu, oracle, outputs, kpath):
+    """Ragged rows (output_length = -1, the reference's default output) of 3-6 chunks each, lengths that end in 0-3 bases
+    beyond a group of four, half of them reverse-complemented, regions over the contigs' edges: the chunked lean kernel's ragged
+    form (recon_lean_kernel<.., LONG, RAGL>) by default; down the suite's paths also every chunk SOLO (32768), the re-reading
+    form (65536) and the all-purpose kernel (16384 / the scalar paths)."""
+    st, bt = _synth(41, (90_000, 60_000), 24, 9_000, indel_frac=0.4, density=1 / 40, rc_frac=0.5, edge_frac=0.2, output_length=-1,
+                    random_shifts=True)
+    rng = np.random.default_rng(5)
+    bt.regions = bt.regions.copy()
+    bt.regions[:, 2] += rng.integers(0, 5000, len(bt.regions)).astype(np.int32)        # (rows of 9 000 ... 14 000 bases)
+    dev = make_dev(gpu, st, bt)
+    oh, hp = "onehot" in outputs, "haps" in outputs
+    out = dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, -1, to_rc=bt.to_rc, haps=hp, onehot=oh)
+    exp, exp_off, exp_oh = oracle_fused(oracle, st, bt, onehot=True)
+    lens = np.diff(exp_off)
+    assert lens.min() > 2560 and len(set(lens % 4)) == 4 and len(set(lens)) > 10
+    np.testing.assert_array_equal(out.out_offsets.cpu().numpy(), exp_off)
+    if hp:
+        np.testing.assert_array_equal(out.haps.cpu().numpy(), exp)
+    if oh:
+        np.testing.assert_array_equal(out.onehot.cpu().numpy(), exp_oh)
+
+
 def test_offsets_scan_many_rows(gpu, oracle):
     st, bt = _synth(31, (100_000,), 3000, 64, indel_frac=0.5, density=1 / 10, output_length=-1, slack=0)
     dev = make_dev(gpu, st, bt)

@@ -3,7 +3,8 @@ what gvl_reconstruct sends to recon_lean_kernel) against the oracle.  Dense rows
 meet indels, windows over contig edges, overflowing slots: every row the lean path hands to its solo general path
 is checked the same way.  python tools/fuzz_lean.py [n_cases] [seed]
 FUZZ_LONG=1: rows of several 2048-base chunks (the kernel's LONG form: one wave per chunk, the row's walk replayed from
-the CSR records) -- chunk borders inside alleles, behind deletions, rows with hundreds of variants."""
+the CSR records) -- chunk borders inside alleles, behind deletions, rows with hundreds of variants.
+FUZZ_RAGGED=1: output_length = -1 (rows at out_offsets, any length): the pipelined kernel's ragged form, with FUZZ_LONG the chunked one's."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,6 +13,7 @@ from oracle import oracle
 
 
 LONG = bool(int(os.environ.get("FUZZ_LONG", "0")))
+RAGGED = bool(int(os.environ.get("FUZZ_RAGGED", "0")))     # output_length = -1: rows at out_offsets (with FUZZ_LONG: the chunked kernel's ragged form)
 
 
 def one_case(rng):
@@ -47,6 +49,10 @@ def one_case(rng):
         bt.shifts = rng.integers(0, hi + 1, bt.shifts.shape).astype(np.int32)
     if rng.random() < 0.3:
         bt.regions = np.ascontiguousarray(bt.regions[:, :3])            # stride 3 like the goldens
+    if RAGGED:
+        bt.regions = bt.regions.copy()
+        bt.regions[:, 2] += rng.integers(0, 7, len(bt.regions)).astype(bt.regions.dtype)      # (lengths of every residue mod 4)
+        bt.output_length = -1
     return st, bt
 
 
