@@ -634,6 +634,44 @@ def test_loader_ragged_and_annotated_modes(oracle, python_loop, ragged_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dbg", [0, 1048576], ids=["chunked-lean-kernel-ragged-form", "all-purpose-kernel"])
+@pytest.mark.parametrize("python_loop", [False, True], ids=["native-ring", "python-loop"])
+def test_loader_ragged_long_rows(oracle, python_loop, dbg):
+    """Ragged rows (output_length = -1) of ~6 000 bases -- longer than the pipelined kernel's ragged form takes -- from dataset
+    indices: the chunked lean kernel's ragged form (recon_lean_kernel<.., LONG, RAGL>) behind the loader's sizing, against the
+    oracle; GVL_DBG = 1048576: the all-purpose kernel, as before round 4."""
+    from genvarloader_amd import HapsDevice, _lib
+    from genvarloader_amd.loader import DeviceHapsDataset
+
+    R, S, P, L = 4, 5, 2, 6000
+    st, full_regions, go, gv = _grid_dataset(23, R, S, P, L, contig=120_000, indel_frac=0.5)
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+    _lib.load().gvl_set_debug_flags(dbg)
+    try:
+        ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=-1, onehot=True, haps=True)
+        seen, lens = [], []
+        for batch in ds.to_dataloader(batch_size=6, shuffle=True, seed=4, python_loop=python_loop, group=2):
+            idx = batch.idx.cpu().numpy()
+            r_idx, s_idx = np.unravel_index(idx, (R, S))
+            regions = full_regions[r_idx]
+            goi = np.ravel_multi_index((r_idx[:, None], s_idx[:, None], np.arange(P)), (R, S, P))
+            to_rc, shifts = np.repeat(regions[:, 3] == -1, P), np.zeros_like(goi, dtype=np.int32)
+            exp, exp_off, exp_oh = oracle.reconstruct_haplotypes_fused(
+                regions, shifts, goi, go, gv, st.v_starts, st.ilens, st.alt_alleles, st.alt_offsets, st.ref,
+                st.ref_offsets, st.pad_char, -1, None, None, to_rc, False, onehot=True)
+            tot = len(exp)
+            np.testing.assert_array_equal(batch.out_offsets.cpu().numpy(), exp_off)
+            np.testing.assert_array_equal(batch.haps[:tot].cpu().numpy(), exp)
+            np.testing.assert_array_equal(batch.onehot[:tot].cpu().numpy(), exp_oh.reshape(-1, 4))
+            seen.extend(idx.tolist()); lens.extend(np.diff(exp_off).tolist())
+        assert sorted(seen) == list(range(R * S)) and min(lens) > 2560 and len(set(x % 4 for x in lens)) > 1
+    finally:
+        _lib.load().gvl_set_debug_flags(-1)
+
+
+@pytest.mark.gpu
 def test_native_ragged_rows_longer_than_the_slot_bound_are_reported(oracle):
     """A ragged slot reserves max_row_len bases per row.  With a bound that is too small the rows are cut
     to it (nothing is written outside the slot) and the cut is reported like a sticky HIP error."""
