@@ -8,8 +8,13 @@ for d in 0 65536 32768 33554432 33619968 33587200 67108864; do run tools/fuzz_le
 echo "== fuzz_lean.py FUZZ_LONG=1 (rows of 2 052 ... 40 000 bases: the chunked form)"
 for d in 0 32768 65536; do run tools/fuzz_lean.py $d "FUZZ_LONG=1" $((N / 8)) 4002; done
 run tools/fuzz_lean.py 0 "FUZZ_LONG=1 GVL_LEAN_SUB=1" $((N / 8)) 4003; run tools/fuzz_lean.py 0 "FUZZ_LONG=1 GVL_LEAN_SUB=4" $((N / 8)) 4004
+echo "== fuzz_lean.py FUZZ_RAGGED=1 (output_length -1: the pipelined kernel's ragged form; with FUZZ_LONG=1 the chunked kernel's)"
+for d in 0 33554432 67108864; do run tools/fuzz_lean.py $d "FUZZ_RAGGED=1" $N 4010; done
+for d in 0 32768 65536 1048576; do run tools/fuzz_lean.py $d "FUZZ_LONG=1 FUZZ_RAGGED=1" $((N / 8)) 4011; done
+run tools/fuzz_lean.py 0 "FUZZ_LONG=1 FUZZ_RAGGED=1 GVL_LEAN_SUB=1" $((N / 8)) 4012
 echo "== fuzz.py (ragged / fixed, keep masks, annotations, both layouts: ragged + no keep + row-major now takes the pipelined RAG kernel)"
 for d in 0 33554432 67108864 8 134217728; do run tools/fuzz.py $d "" $N 4005; done
 echo "== fuzz_tracks.py, fuzz_fused_tracks.py"
 run tools/fuzz_tracks.py 0 "" $((N / 4)) 4006; run tools/fuzz_tracks.py 8 "" $((N / 8)) 4007
 run tools/fuzz_fused_tracks.py 0 "" $((N / 10)) 4008; run tools/fuzz_fused_tracks.py 2097152 "" $((N / 10)) 4009
+run tools/fuzz_fused_tracks.py 268435456 "" $((N / 10)) 4013      # (no row plans: every chunk walks)
