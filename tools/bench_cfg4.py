@@ -166,6 +166,12 @@ def measure(args, init_dist=True):
         e1.record(cur); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
 
+    def bound(fn, *args):
+        # the ctypes arguments are built ONCE: built per call (a dozen pointer conversions) the call costs the host ~ 40 us and
+        # a 20 us kernel's back-to-back launches measure the host (round 3 and the first round-4 passes reported the painter at
+        # 38-54 us = 0.18-0.24 of peak that way; rocprofv3 has its kernel at 21 us)
+        return lambda: _lib.check(fn(*args))
+
     t_recon = timeit(lambda: dev.launch(dbt, slot[1]))
     a, e, v, io, pm = ds._itv[0]
     qs, qe = reg[:, 1].contiguous(), reg[:, 2].contiguous()
@@ -174,21 +180,21 @@ def measure(args, init_dist=True):
     toff = torch.zeros(bs + 1, dtype=torch.int64, device="cuda"); torch.cumsum(tlen, 0, out=toff[1:])
     scratch = torch.empty(int(toff[-1]), dtype=torch.float32, device="cuda")
     n_itv_batch = int((io[idx0 + 1] - io[idx0]).sum())
-    t_paint = timeit(lambda: _lib.check(lib.gvl_intervals_to_tracks(
+    t_paint = timeit(bound(lib.gvl_intervals_to_tracks,
         gdev._ptr(idx0), gdev._ptr(qs), C.c_int64(1), C.c_int64(bs), gdev._ptr(a), gdev._ptr(e), gdev._ptr(v), gdev._ptr(io),
-        C.c_int64(int(a.numel())), gdev._ptr(pm), gdev._ptr(scratch), gdev._ptr(toff), C.c_int64(int(tlen.max())), gdev._stream_ptr())))
+        C.c_int64(int(a.numel())), gdev._ptr(pm), gdev._ptr(scratch), gdev._ptr(toff), C.c_int64(int(tlen.max())), gdev._stream_ptr()))
     # the same painting through gvl_paint_tracks with the bucket index (what the drop-in layer's intervals_to_tracks calls since round 4)
     ts_paint, _keep_ts = gdev.make_track_set(a, e, v, io, pm, ds._bkt[0], "cuda")
     ts_paint.tile_complete = 1 if ds._tile_complete[0] else 0
-    t_paint_idx = timeit(lambda: _lib.check(lib.gvl_paint_tracks(
+    t_paint_idx = timeit(bound(lib.gvl_paint_tracks,
         C.byref(ts_paint), gdev._ptr(idx0), gdev._ptr(qs), C.c_int64(1), C.c_int64(bs), gdev._ptr(scratch), gdev._ptr(toff),
-        C.c_int64(int(tlen.max())), gdev._stream_ptr())))
+        C.c_int64(int(tlen.max())), gdev._stream_ptr()))
     ooff = torch.arange(K + 1, dtype=torch.int64, device="cuda") * L
     tbt = dev.prepare_batch(reg, sh, goi, -1, None, None, rc, ooff, max_row_len=L)
     tout = torch.empty(K * L, dtype=torch.float32, device="cuda")
     par = (C.c_double * 1)(0.0)
-    t_realign = timeit(lambda: _lib.check(lib.gvl_realign_tracks(C.byref(dev.c), C.byref(tbt.c), gdev._ptr(scratch), gdev._ptr(toff), par,
-                                                                 C.c_int64(0), C.c_uint64(0), gdev._ptr(tout), gdev._stream_ptr())))
+    t_realign = timeit(bound(lib.gvl_realign_tracks, C.byref(dev.c), C.byref(tbt.c), gdev._ptr(scratch), gdev._ptr(toff), par,
+                             C.c_int64(0), C.c_uint64(0), gdev._ptr(tout), gdev._stream_ptr()))
     dbg = int(os.environ.get("GVL_DBG", "0") or 0)
     lean_long = dev.ref4 is not None and dev.geno_rec is not None and not (dbg & (16384 | 1048576 | 16))
     kernel_name = ("recon_lean_kernel<onehot, haps, long> (one wave per 2048-base chunk)" if lean_long
@@ -201,10 +207,10 @@ def measure(args, init_dist=True):
     from genvarloader_amd._lib import GvlBatch
     gbt = GvlBatch(regions=reg.data_ptr(), regions_stride=4, shifts=sh.data_ptr(), geno_offset_idx=goi.data_ptr(), batch=bs, ploidy=P,
                    keep=None, keep_offsets=None, to_rc=None if rc is None else rc.data_ptr(), output_length=L, out_offsets=None, max_row_len=L)
-    t_tracks = timeit(lambda: _lib.check(lib.gvl_tracks_batch(
+    t_tracks = timeit(bound(lib.gvl_tracks_batch,
         C.byref(dev.c), C.byref(gbt), C.c_void_p(idx0.data_ptr()), ds._track_sets, C.c_int32(1), par, C.c_int64(0), C.c_uint64(0),
         C.c_void_p(arena.data_ptr()), C.c_int64(K * L), C.c_void_p(arena.data_ptr() + ((4 * K * L + 255) & ~255)), C.c_int64(ds._stride),
-        gdev._stream_ptr())))
+        gdev._stream_ptr()))
     if rank == 0:
         hap_bytes = (L * 6 + 28.0 * mean_v + 61.0) * K
         realign_bytes = 4.0 * float(toff[-1]) + 4.0 * K * L
