@@ -333,6 +333,45 @@ def secondary_ragged(torch, dev, ds, budget_s: float = 2.5) -> dict:
     }
 
 
+def secondary_random_shifts(torch, dev, ds, budget_s: float = 2.5) -> dict:
+    """cfg3 in TRAINING mode (SURVEY 8d's cfg3 variant; _haps.py:678-768, _query.py:160-187): ``deterministic=False`` -- every haplotype's
+    shift drawn from U[0, max_shift], max_shift from its query-mode length delta -- and ``jitter=16``, fixed-length one-hot rows, from
+    dataset indices through the native loader (request prep incl. the diffs pass once per epoch, groups of 16 batches = one grid),
+    next to the same loader with ``deterministic=True`` on the same box.  -> us per 4096-window batch over chained epochs."""
+    from genvarloader_amd.loader import DeviceHapsDataset
+
+    P, bs, L = ds.ploidy, 2048, ds.length
+    out = {}
+    for name, kw in (("deterministic", dict(deterministic=True, jitter=0)), ("random", dict(deterministic=False, jitter=16))):
+        hds = DeviceHapsDataset(dev, ds.full_regions.cpu().numpy(), 1, P, output_length=L, seed=1, **kw)
+        dl = hds.to_dataloader(batch_size=bs, shuffle=True, in_flight=3, group=16)
+        n_b = 0
+        for batch in dl:
+            n_b += 1
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_ep = 0
+        while time.perf_counter() - t0 < budget_s / 2 or n_ep < 2:
+            for batch in dl:
+                pass
+            n_ep += 1
+        torch.cuda.synchronize()
+        out[name] = (time.perf_counter() - t0) / (n_ep * n_b) * 1e3, n_ep, n_b
+        del dl, hds
+    K = bs * P
+    mean_v = float((dev.geno_offsets[1] - dev.geno_offsets[0])[:1 << 20].double().mean())
+    abytes = algorithmic_bytes_per_window(L, mean_v, False, True) * K
+    ms = out["random"][0]
+    return {
+        "workload": f"cfg3 training mode: {K} windows x {L} bp per batch, deterministic=False (shifts ~ U[0, max_shift] per haplotype) + jitter 16, "
+                    f"one-hot (K, L, 4), from dataset indices through the native loader (in_flight 3, groups of 16), {out['random'][2]} batches per epoch",
+        "ms_per_step": ms, "windows_per_s": K / (ms * 1e-3), "epochs_timed": out["random"][1],
+        "deterministic_ms_per_step": out["deterministic"][0], "vs_deterministic": ms / out["deterministic"][0],
+        "algorithmic_bytes_per_step": abytes, "step_frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "how": "host clock over chained epochs (no synchronisation between them), steady state; the deterministic loader the same way just before",
+    }
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -372,8 +411,21 @@ def main() -> None:
     if args.cpu_only:
         cpu_only(args)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start one rank per GPU under torch.distributed.run as a CHILD process --
+        # before this process has imported torch or touched the GPU (never a re-exec of a process that has) --, relay its output
+        # and exit with its code.  (Started under the launcher -- WORLD_SIZE set -- a mismatch with --gpus is still refused below.)
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+        raise SystemExit(subprocess.run(cmd).returncode)
     if args.workload == "cfg4":
-        from tools import bench_cfg4  # haplotypes + tracks: its own step definition
+        import bench_cfg4  # haplotypes + tracks: its own step definition
 
         bench_cfg4.main(args)
         return
@@ -463,22 +515,28 @@ def main() -> None:
         """--many G: steps are gathered into launches of G batches (gvl_reconstruct_many: one grid over the group), launch g on
         stream g % streams; flush() sends the partial last group of a region.  hot: every launch re-reads the first G batches."""
 
-        def __init__(self, use_streams, hot=False):
+        def __init__(self, use_streams, hot=False, bl=None, sl=None):
             self.pending, self.g, self.cache, self.group = 0, 0, {}, G
             self.streams, self.hot = use_streams, hot
             self.sp = [_C.c_void_p(s_.cuda_stream) for s_ in use_streams]
+            self.bl = batches if bl is None else bl          # (the secondary legs bring their own batches and output slots)
+            self.sl = slots if sl is None else sl
+            self.nb = len(self.bl)
+
+        def key(self, g, size):
+            return (0 if self.hot else g % (self.nb // G if self.nb >= G else 1), size, g % (len(streams) + 1))
 
         def pack(self, g, size):
-            key = (0 if self.hot else g % (n_rot // G if n_rot >= G else 1), size, g % (len(streams) + 1))
+            key = self.key(g, size)
             p = self.cache.get(key)
             if p is None:
                 b0, s0 = key[0] * G, key[2] * G
-                p = self.cache[key] = dev.pack_many([batches[(b0 + i) % n_rot] for i in range(size)],
-                                                    [slots[s0 + i][1] for i in range(size)])
+                p = self.cache[key] = dev.pack_many([self.bl[(b0 + i) % self.nb] for i in range(size)],
+                                                    [self.sl[s0 + i][1] for i in range(size)])
             return p
 
         def prebuild(self, sizes):
-            for g in range(max(1, n_rot // G) * (len(streams) + 1)):     # the argument arrays, ahead of the timed code
+            for g in range(max(1, self.nb // G) * (len(streams) + 1)):     # the argument arrays, ahead of the timed code
                 for size in sizes:
                     if size:
                         self.pack(g, size)
@@ -547,6 +605,7 @@ def main() -> None:
         hot_ms = tm.measure(step_hot_k, steps, [stream])[0] * G / steps
     # ---- sustained: seconds of back-to-back cold batches, the timed region's schedule, ONE event pair ----
     sustained = None
+    last_call = None
     if args.sustained_s > 0:
         import ctypes as C
         import math
@@ -567,6 +626,7 @@ def main() -> None:
             sus_fn = dev.lib.gvl_reconstruct
         clk0 = gpu_clocks(dev_index)
         sus_ms, sus_n, sus_host, sus_launch = tm.sustained(calls, sus_fn, streams, args.sustained_s, region_ms / steps * G)
+        last_call = (sus_n - 1) % period              # (the leg's last launch: its outputs are what `verified` reads below)
         sus_ms /= G                                   # (a call = G steps)
         sus_n *= G
         tm.last_thirds = [t / G for t in tm.last_thirds]
@@ -584,6 +644,69 @@ def main() -> None:
                              "back-to-back gvl_reconstruct launches, step i on stream i % streams")
                             + ", rotating cold batches, one HIP event pair around all of them (no gate kernel, no synchronisation in between)",
                      "clocks_before": clk0, "clocks_after": clk1}
+    # ---- verified: batches of the LAST TIMED LAUNCH against the oracle (rank 0; the oracle is the checker here, never the thing
+    # measured).  The launch = the sustained leg's last gvl_reconstruct_many call (or, without that leg, the timed region's packed
+    # arguments launched once more); two of its batches, one at an in-group position >= 11 -- where the second rows of the two-row
+    # waves live -- are rebuilt on the host and compared byte for byte with what the kernel left in the output slots.
+    verified = None
+    if rank == 0 and not args.no_cpu_baseline and not args.strong:
+        from oracle import oracle as _orc
+
+        if G > 1:
+            g_v = last_call if last_call is not None else 0
+            if last_call is None:
+                b_, o_, n_ = step_pipelined.pack(g_v, G)
+                if _many(_dref, b_, o_, n_, _sptr[0]):
+                    raise RuntimeError("gvl_reconstruct_many failed")
+            key = step_pipelined.key(g_v, G)
+            b0, s0 = key[0] * G, key[2] * G
+            positions = sorted({0, min(G - 1, 13)})
+            what = "gvl_reconstruct_many, %d batches in one grid" % G
+        else:
+            step_single(0)
+            j_ = counter[0] - 1
+            b0, s0, positions = j_ % n_rot, j_ % n_slots, [0]
+            what = "gvl_reconstruct, one batch"
+        torch.cuda.synchronize()
+        hs_ = ds.host_static()
+        exp_ = []
+        for i_ in positions:
+            hb_ = ds.host_batch(qsets[(b0 + i_) % n_rot], rc=rc_on)
+            e_h, _, e_oh = _orc.reconstruct_haplotypes_fused(
+                hb_.regions, hb_.shifts, hb_.geno_offset_idx, hb_.geno_offsets, hb_.geno_v_idxs, hs_.v_starts, hs_.ilens,
+                hs_.alt_alleles, hs_.alt_offsets, hs_.ref, hs_.ref_offsets, hs_.pad_char, L, None, None, hb_.to_rc, True,
+                onehot=True, n_threads=min(32, _orc.default_threads()))
+            exp_.append((e_h, e_oh, hb_.n_windows))
+
+        def _mismatches():
+            n_bad = 0
+            for i_, (e_h, e_oh, _) in zip(positions, exp_):
+                got = slots[s0 + i_][0]
+                ok_ = np.array_equal(got.onehot.cpu().numpy(), e_oh)
+                if args.haps:
+                    ok_ = ok_ and np.array_equal(got.haps.cpu().numpy(), e_h)
+                n_bad += 0 if ok_ else 1
+            return n_bad
+
+        bad, relaunched = _mismatches(), False
+        if bad and G > 1 and last_call is not None:
+            # (the leg's launches rotate over streams + 1 output sets WITHOUT an event between the launch that last wrote a set and
+            # the one that writes it next -- they sit on different streams; should the older one ever have finished last, its
+            # bytes are what the set holds: launch the same arguments once more, alone, before calling it a mismatch)
+            b_, o_, n_ = step_pipelined.pack(g_v, G)
+            if _many(_dref, b_, o_, n_, _sptr[0]):
+                raise RuntimeError("gvl_reconstruct_many failed")
+            torch.cuda.synchronize()
+            bad, relaunched = _mismatches(), True
+        rows_v = sum(e[2] for e in exp_)
+        verified = {"batches": len(positions), "mismatches": bad, "rows": rows_v, "in_group_positions": positions, "relaunched": relaunched,
+                    "launch": ("the sustained leg's last launch" if last_call is not None else "the timed region's packed arguments, launched once more")
+                              + " (" + what + ")",
+                    "against": "oracle.reconstruct_haplotypes_fused (C restatement of the reference), one-hot"
+                               + (" + haplotype bytes" if args.haps else "") + ", byte for byte"}
+        if bad:
+            raise SystemExit(f"bench.py: the timed launch does NOT equal the oracle: {verified}")
+
     # ---- single-batch latency, host wall clock: launch -> synchronize --------
     lat = []
     for i in range(50):
@@ -628,7 +751,7 @@ def main() -> None:
         try:
             if "cfg4" in skip:
                 raise RuntimeError("skipped (GVL_BENCH_SKIP)")
-            from tools import bench_cfg4
+            import bench_cfg4
 
             class _A:
                 gpus, steps, warmup, min_region_ms, max_regions = 1, 20, 5, 1200.0, 400
@@ -643,6 +766,105 @@ def main() -> None:
         except Exception as exc:
             secondary["cfg4"] = {"error": repr(exc)}
         secondary["cfg4_s"] = round(time.perf_counter() - t_s, 2)
+        # ---- the reference's other output modes on cfg3's rows, each under the same schedule as the headline (groups of G batches
+        # per gvl_reconstruct_many call, `--streams` calls in flight, rotating cold batches): annotated haplotypes (a11,
+        # src/ffi/mod.rs:2237-2397), rows under an exonic keep mask (src/genotypes/mod.rs:132-176: the spliced path's every batch),
+        # channel-major one-hot (K, 4, L) (docs/source/index.md:114-115), the reference-only fetch (a9, src/reference/mod.rs:56-120),
+        # and training mode through the native loader (shifts + jitter)
+        tm2 = Timer(torch, dist, backend, streams, 250.0, 2000, 2.0)
+        nb2 = max(G, min(64, n_rot) // G * G)
+        bl2 = batches[:nb2] if nb2 <= n_rot else batches
+
+        def mode_leg(bl, make_out, bytes_per_window, kernel):
+            sl = [make_out(bl[0]) for _ in range((len(streams) + 1) * G)]
+            stp = ManyStepper(streams, bl=bl, sl=sl)
+            stp.prebuild((G,))
+            k2 = 2 * G
+            for i_ in range(k2):
+                stp(i_)
+            stp.flush()
+            torch.cuda.synchronize()
+            _lib_mod.check_async()
+            ms_, n_, _ = tm2.measure(stp, k2, streams)
+            per = ms_ / k2
+            ab = bytes_per_window * K
+            del sl
+            return {"ms_per_step": per, "windows_per_s": K / (per * 1e-3), "algorithmic_bytes_per_step": ab,
+                    "step_frac": ab / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, "regions": n_, "kernel": kernel,
+                    "how": "median of %d-step regions: gvl_reconstruct_many calls of %d batches on %d streams, %d rotating cold batches, HIP events"
+                           % (k2, G, len(streams), len(bl))}
+
+        def leg(name, fn):
+            t_l = time.perf_counter()
+            try:
+                if name in skip or G < 2:
+                    raise RuntimeError("skipped (GVL_BENCH_SKIP or --many 1)")
+                secondary[name] = fn()
+            except Exception as exc:
+                secondary[name] = {"error": repr(exc)}
+            secondary[name + "_s"] = round(time.perf_counter() - t_l, 2)
+            torch.cuda.empty_cache()
+
+        from genvarloader_amd import _lib as _lib_mod
+
+        leg("onehot_cl", lambda: dict(mode_leg(
+            bl2, lambda b: dev.alloc_output(b, K * L, haps=False, onehot=True, layout="cl"),
+            algorithmic_bytes_per_window(L, mean_v, False, True), "one-hot (K, 4, L)"),
+            workload=f"cfg3 rows, channel-major one-hot (K, 4, L): {K} windows x {L} bp"))
+        leg("annotated", lambda: dict(mode_leg(
+            bl2, lambda b: dev.alloc_output(b, K * L, haps=True, onehot=False, annotate=True),
+            L * (1 + 1 + 8) + 28.0 * mean_v + 61.0, "haplotype bytes + annot_v_idxs + annot_ref_pos"),
+            workload=f"cfg3 rows, annotated haplotypes (bytes + 2 x i32 per base = 9 B per base out): {K} windows x {L} bp"))
+
+        def keep_leg():
+            bl = []
+            for b in bl2[:min(len(bl2), 2 * G)]:
+                kp, ko = dev.choose_exonic_variants(b.regions[:, 1].contiguous(), b.regions[:, 2].contiguous(), b.geno_offset_idx)
+                bl.append(dev.prepare_batch(b.regions, b.shifts, b.geno_offset_idx, L, keep=kp, keep_offsets=ko, to_rc=b.to_rc))
+            return dict(mode_leg(bl, lambda b: dev.alloc_output(b, K * L, haps=False, onehot=True),
+                                 algorithmic_bytes_per_window(L, mean_v, False, True) + mean_v, "one-hot (K, L, 4) under a keep mask"),
+                        workload=f"cfg3 rows under the exonic keep mask (choose_exonic_variants on the rows' own regions), one-hot (K, L, 4): {K} windows x {L} bp")
+        leg("keep_mask", keep_leg)
+
+        def reference_leg():
+            import ctypes as C_
+
+            n_sets = max(2, min(32, n_rot // 2))
+            regs, rcs, outs_, calls_ = [], [], [], []
+            oo = (torch.arange(K + 1, dtype=torch.int64, device=dev.device) * L).contiguous()
+            for i_ in range(n_sets):
+                rg = torch.cat([batches[(2 * i_) % n_rot].regions, batches[(2 * i_ + 1) % n_rot].regions])[:K].contiguous()
+                regs.append(rg)
+                rcs.append((rg[:, 3] == -1).to(torch.uint8).contiguous() if rc_on else None)
+            for j_ in range(len(streams) + 1):
+                outs_.append((torch.empty(K * L, dtype=torch.uint8, device=dev.device), torch.empty((K * L, 4), dtype=torch.uint8, device=dev.device)))
+            n_call = n_sets * (len(streams) + 1)
+            for c_ in range(n_call):
+                rg, rc_ = regs[c_ % n_sets], rcs[c_ % n_sets]
+                o_b, o_h = outs_[c_ % len(outs_)]
+                calls_.append((_dref, C_.c_void_p(rg.data_ptr()), C_.c_int64(4), C_.c_int64(K), C_.c_void_p(oo.data_ptr()), C_.c_int64(L),
+                               None if rc_ is None else C_.c_void_p(rc_.data_ptr()), C_.c_void_p(o_b.data_ptr()), C_.c_void_p(o_h.data_ptr())))
+            fn_ = dev.lib.gvl_get_reference
+            cnt = [0]
+
+            def stp(i_):
+                c_ = cnt[0]
+                cnt[0] += 1
+                if fn_(*calls_[c_ % n_call], _sptr[i_ % len(_sptr)]):
+                    raise RuntimeError("gvl_get_reference failed")
+            for i_ in range(8):
+                stp(i_)
+            torch.cuda.synchronize()
+            k2 = 2 * G
+            ms_, n_, _ = tm2.measure(stp, k2, streams)
+            per = ms_ / k2
+            ab = (L * (1 + 1 + 4) + 16 + 8 + 1) * K
+            return {"workload": f"reference-only fetch (get_reference): {K} rows x {L} bp, reverse-complement on half the rows, bytes + one-hot (K, L, 4)",
+                    "ms_per_step": per, "windows_per_s": K / (per * 1e-3), "algorithmic_bytes_per_step": ab,
+                    "step_frac": ab / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, "regions": n_,
+                    "how": "median of %d-step regions: gvl_get_reference calls on %d streams, %d rotating region sets, HIP events" % (k2, len(streams), n_sets)}
+        leg("reference", reference_leg)
+        leg("random_shifts", lambda: secondary_random_shifts(torch, dev, ds))
 
     lean = (dev.ref4 is not None and dev.slot_rec is not None and L <= 2048 and L % 4 == 0
             and (int(os.environ.get("GVL_DBG", "0")) & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 33554432 | 67108864)) == 0)
@@ -709,7 +931,11 @@ def main() -> None:
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "frac_of_copy_ceiling": achieved / HBM_COPY_GBS,
+                # fractions of the part's measured float4-copy rate are taken on the bytes actually MOVED (the PMC passes' `traffic`;
+                # the algorithmic bytes when there is no PMC figure for this configuration): a fraction of a measured ceiling above 1
+                # would be a units mismatch
+                "frac_of_copy_ceiling": (traffic if traffic is not None else lbytes) / (kern_ms * 1e-3) / 1e9 / HBM_COPY_GBS,
+                "copy_ceiling_bytes": "moved (profiles/traffic.json)" if traffic is not None else "algorithmic",
                 "kernel": (("recon_lean_rows_kernel<onehot, haps=%s> (ONE grid over the launch's %d batches; a wave takes rows w, w + W, ... "
                             "-- one or two rows per wave -- and fetches a row's window + slot line by LDS-DMA; nibble-packed reference)"
                             % ("true" if args.haps else "false", G)) if piped else
@@ -721,10 +947,12 @@ def main() -> None:
                 "kernel_ms_hot": hot_ms, "hot_frac": None if hot_ms is None else lbytes / (hot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": lbytes, "algorithmic_bytes_per_batch": abytes,
                 "pipelined_GBps": pipelined, "pipelined_frac": pipelined / HBM_PEAK_GBS,
-                "pipelined_frac_of_copy_ceiling": pipelined / HBM_COPY_GBS,
+                "pipelined_frac_of_copy_ceiling": ((traffic / G) if traffic is not None else abytes) / (ms_per_step * 1e-3) / 1e9 / HBM_COPY_GBS,
                 "single_batch_wall_ms": single_ms,
             },
         }
+        if verified is not None:
+            res["verified"] = verified
         if sustained is not None:
             res["sustained"] = sustained
             res["sustained_ms_per_step"] = sustained["ms_per_step"]

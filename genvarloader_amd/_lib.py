@@ -20,6 +20,7 @@ LIB_NAME = "libgvl_hip.so"
 SYMBOLS = (
     "gvl_abi_version",
     "gvl_set_debug_flags",
+    "gvl_set_tuning",
     "gvl_last_error",
     "gvl_async_error",
     "gvl_static_upload",
@@ -59,7 +60,8 @@ SYMBOLS = (
     "gvl_loader_destroy",
 )
 
-ABI_VERSION = 8          # include/gvl_hip.h: GVL_ABI_VERSION
+ABI_VERSION = 9          # include/gvl_hip.h: GVL_ABI_VERSION
+TUNE_PIPE_ROWS_X100, TUNE_PIPE_MIN_ROWS, TUNE_LEAN_SUB, TUNE_TRACK_PLAN_MAX_MB = 0, 1, 2, 3     # GVL_TUNE_*
 GVL_ONEHOT_LC = 0
 GVL_ONEHOT_CL = 1
 
@@ -202,8 +204,14 @@ def load() -> C.CDLL:
     lib.gvl_tracks_scratch_bytes.restype = C.c_int64
     lib.gvl_ref4_bytes.restype = C.c_int64
     lib.gvl_ref4_bytes.argtypes = [C.c_int64]
+    lib.gvl_set_tuning.argtypes = [C.c_int32, C.c_int64]
     _LIB = lib
     return lib
+
+
+def set_tuning(key: int, value: int) -> None:
+    """``gvl_set_tuning``: a launch-policy override (``TUNE_*``; 0 = the built-in policy).  Results never depend on it."""
+    check(load().gvl_set_tuning(int(key), int(value)))
 
 
 def check(rc: int) -> None:

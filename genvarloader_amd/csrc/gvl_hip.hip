@@ -4296,6 +4296,12 @@ int debug_flags() {
     return g_debug_override >= 0 ? g_debug_override : flags;
 }
 
+// Launch-policy overrides (gvl_set_tuning): A/B measurements, and tests that must force a schedule.  0 = the built-in policy.
+// (Round 4's environment knobs GVL_PIPE_WAVES / _ROWS / _RPW_X100 / _MIN_ROWS, GVL_LEAN_SUB, GVL_*_EXTRA_LDS and
+// GVL_TRACK_PLAN_MAX_MB are gone: their experiments concluded -- LABNOTES.md -- and what is left of them is this table.)
+i64 g_tune[GVL_TUNE_COUNT] = {0};
+i64 tune(int key) { return __atomic_load_n(&g_tune[key], __ATOMIC_RELAXED); }
+
 int log2_exact(i64 v) {
     for (int s = 0; s < 31; ++s) if ((1ll << s) == v) return s;
     return -1;
@@ -4338,6 +4344,11 @@ extern "C" {
 
 int gvl_abi_version(void) { return GVL_ABI_VERSION; }
 int gvl_set_debug_flags(int flags) { g_debug_override = flags; return GVL_OK; }
+int gvl_set_tuning(int32_t key, int64_t value) {
+    if (key < 0 || key >= GVL_TUNE_COUNT) return fail(GVL_ERR_INVALID, "%s", "gvl_set_tuning: unknown key");
+    __atomic_store_n(&g_tune[key], value < 0 ? 0 : value, __ATOMIC_RELAXED);
+    return GVL_OK;
+}
 // diagnostics (not in gvl_hip.h): a device buffer the kernels may leave counters / time stamps in.  Phase stamps need a
 // -DGVL_DIAG build; lean_solo_rows counts the rows and waves that reach it in words 0 and 1 in every build (tools/pipe_deferred.py).
 void gvl_diag_set_stamps(void *buf) { g_stamps = (u64 *)buf; }
@@ -4350,6 +4361,7 @@ int gvl_async_error(int clear) {
     if (clear) *(volatile int *)w = 0;
     if (e == 1) return fail(GVL_ERR_INVALID, "%s", "a launch found a row longer than its batch's max_row_len hint: that row was left partly unwritten");
     if (e == 2) return fail(GVL_ERR_INVALID, "%s", "an interval set marked tile_complete has a chunk with overlapping intervals, equal starts or more than 256 candidates: that chunk was left unpainted");
+    if (e == 3) return fail(GVL_ERR_INVALID, "%s", "a pipelined launch gave a wave more rows than it can take (grid mis-sized): the surplus rows were left unwritten");
     return e ? fail(GVL_ERR_INVALID, "%s", "asynchronous device-side error") : GVL_OK;
 }
 
@@ -4534,9 +4546,7 @@ static int launch_recon(const ReconArgs &A, int chunks, int variant, void *strea
     const i64 grid = (A.n_rows + WG_WAVES - 1) / WG_WAVES;
     if (grid <= 0) return GVL_OK;
     recon_fn fn = recon_table(variant & 3, (variant & 4) != 0, (variant & 8) != 0);
-    // GVL_EXTRA_LDS=<bytes>: occupancy experiments (unused dynamic LDS caps the workgroups per CU)
-    static const unsigned extra_lds = [] { const char *e = getenv("GVL_EXTRA_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
-    fn<<<dim3((unsigned)grid, (unsigned)chunks), dim3(WG_THREADS), extra_lds, (hipStream_t)stream>>>(A);
+    fn<<<dim3((unsigned)grid, (unsigned)chunks), dim3(WG_THREADS), 0, (hipStream_t)stream>>>(A);
     return check_launch("gvl_reconstruct");
 }
 
@@ -4587,14 +4597,14 @@ static int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
     A.chunks = chunks;
     // rows of several chunks: a wave takes `sub` consecutive chunks, the second and later ones resume the first one's walk.
     // 2 by default -- BASELINE config 4's 256 rows x 64 chunks are then 8 192 waves, every wave slot of the part once;
-    // GVL_LEAN_SUB overrides (1 = every chunk its own wave and its own walk)
-    static const int sub_env = [] { const char *e = getenv("GVL_LEAN_SUB"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
-    A.sub = chunks > 1 ? (sub_env > 0 ? sub_env : 2) : 1;
+    // gvl_set_tuning(GVL_TUNE_LEAN_SUB) overrides (1 = every chunk its own wave and its own walk)
+    const i64 sub_t = tune(GVL_TUNE_LEAN_SUB);
+    A.sub = chunks > 1 ? (sub_t > 0 ? (int)(sub_t > 64 ? 64 : sub_t) : 2) : 1;
     const i64 per_row = (chunks + A.sub - 1) / A.sub;
     const unsigned grid = (unsigned)(((i64)A.n_rows * per_row + LEAN_WAVES - 1) / LEAN_WAVES);
     const dim3 g(grid), b(LEAN_THREADS);
     hipStream_t s = (hipStream_t)stream;
-    static const unsigned xl = [] { const char *e = getenv("GVL_LEAN_EXTRA_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
+    const unsigned xl = 0;
     if (chunks > 1 && RA.out_offsets) {         // ragged long rows (lean_long_rag_eligible)
         A.out_offsets = RA.out_offsets;
         A.out_offsets_w = nullptr;
@@ -4615,14 +4625,9 @@ static int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
 }
 
 // ---- the pipelined form (gvl_lean_pipe.inc): rows of one chunk, `n` batches of the same shape in ONE grid ----------
-// GVL_PIPE_MIN_ROWS (default 8192): launches with fewer rows keep recon_lean_kernel (a wave per row: with one row per wave
-// there is nothing to pipeline); GVL_PIPE_WAVES (default 8192 = every wave slot of the part): waves in the grid, each takes
-// rows w, w + waves, ...; GVL_DBG & 33554432: always, with ONE workgroup (the suite's small batches then run many rows per
-// wave); GVL_DBG & 67108864: never.
-static int pipe_env(const char *name, int dflt) {
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
+// Launches with fewer than 8192 rows keep recon_lean_kernel (a wave per row: with one row per wave there is nothing to
+// pipeline; gvl_set_tuning(GVL_TUNE_PIPE_MIN_ROWS) overrides); GVL_DBG & 33554432: always, with as few workgroups as 32 rows
+// per wave allow (the suite's small batches then run many rows per wave on ONE workgroup); GVL_DBG & 67108864: never.
 // RAG: rows at out_offsets (ragged output, output_length = -1, or a caller's plan): row-major one-hot and / or bytes, no keep
 // mask, no annotations, the slot-major records and the packed reference present, and the caller's bound on the longest row
 // within the pipelined kernel's 10 trips.  There is no wave-per-row lean kernel for these: pipelined form or the all-purpose kernel.
@@ -4640,11 +4645,12 @@ static bool lean_rag_eligible(const gvl_static *st, const gvl_batch *bt, const g
 static bool lean_pipe_wanted(i64 total_rows, int n_batches = 1) {
     if (debug_flags() & 67108864) return false;
     if (debug_flags() & 33554432) return true;
-    static const int min_rows = pipe_env("GVL_PIPE_MIN_ROWS", 8192);
+    const i64 min_t = tune(GVL_TUNE_PIPE_MIN_ROWS);
+    const i64 min_rows = min_t > 0 ? min_t : 8192;
     // (a GROUP of small batches -- strong scaling: 4096 / 8 = 512 rows per rank and batch -- is one grid from 2048 rows on: ten
     // launches of 512 rows are ten launch latencies in a row)
     const i64 bar = (n_batches >= 2 && min_rows > 2048) ? 2048 : min_rows;
-    return min_rows >= 0 && total_rows >= bar;
+    return total_rows >= bar;
 }
 // can these (lean-eligible, one-chunk) batches share a grid?  the same shape and outputs; every batch but the last has the
 // first one's row count
@@ -4688,29 +4694,20 @@ static int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_c
         total += RAs[i].n_rows;
     }
     A.n_rows = (int)total;
-    static const int cap_env = pipe_env("GVL_PIPE_WAVES", 8192);
-    const i64 cap = (debug_flags() & 33554432) ? LEAN_WAVES : (cap_env < LEAN_WAVES ? LEAN_WAVES : cap_env);
-    // every wave the same number of rows (20 480 rows on 8 192 waves would be 3 rows for half of them and 2 for the others: the
-    // launch ends a third late): R = rows per wave at `cap` waves, then as few waves as R rows each need
-    // Rows per wave.  Measured (profiles/r04_pipe_experiments.txt G): ONE row per wave -- no row-to-row prefetch at all -- is the
-    // best schedule up to ~12 batches per launch (short waves: the hardware's workgroup dispatch balances the chip; 5 batches:
-    // 6.53 / 6.65 / 6.81 us per batch for 1 / 2 / 3 rows per wave), TWO rows per wave above that (16 batches: 6.33 / 5.9 / 6.1 /
-    // 6.6-6.9 for 1 / 2 / 3 / 8: half the workgroups to dispatch, the second row's reads under the first one's stores).
-    // GVL_PIPE_ROWS overrides; GVL_PIPE_WAVES (a cap on the waves of a grid) is the first builds' policy, kept for A/Bs.
-    static const int rows_env = pipe_env("GVL_PIPE_ROWS", 0);
-    static const bool cap_set = getenv("GVL_PIPE_WAVES") != nullptr;
-    i64 rows_per_wave = total >= 49152 ? 2 : 1;
-    if (cap_set || (debug_flags() & 33554432)) rows_per_wave = (total + cap - 1) / cap;
-    if (rows_env > 0 && !(debug_flags() & 33554432)) rows_per_wave = rows_env;
-    if (rows_per_wave > PIPE_MAX_ROWS) rows_per_wave = PIPE_MAX_ROWS;
-    if (rows_per_wave < 1) rows_per_wave = 1;
-    i64 waves = (total + rows_per_wave - 1) / rows_per_wave;
-    // "Two rows per wave" is 1.5 on average: the first half of the waves take two rows (w, w + W), the second half --
-    // dispatched last -- one, so the grid drains in short waves (profiles/r04_pipe_experiments.txt K: the launch alone 7.84 ->
-    // 7.71 us per batch, 20-step regions 7.30 -> 7.21, steady state unchanged; 125 / 175 measure like 150).
-    // GVL_PIPE_RPW_X100 overrides (200 = exactly two).
-    static const int rpw_x100 = pipe_env("GVL_PIPE_RPW_X100", 150);
-    if (rpw_x100 >= 100 && rows_per_wave == 2 && !(debug_flags() & 33554432)) waves = (total * 100 + rpw_x100 - 1) / rpw_x100;
+    // Rows per wave (x 100).  Measured (profiles/r04_pipe_experiments.txt G, K): ONE row per wave -- no row-to-row prefetch at
+    // all -- is the best schedule up to ~12 batches per launch (short waves: the hardware's workgroup dispatch balances the chip);
+    // above that "two rows per wave", which is 1.5 on average: the first half of the waves take two rows (w, w + W), the second
+    // half -- dispatched last -- one, so the grid drains in short waves (125 / 175 measure like 150; exactly 2, or 3, are slower).
+    // gvl_set_tuning(GVL_TUNE_PIPE_ROWS_X100) overrides (200 = exactly two rows for every wave, 300 = three, ...).
+    i64 x100 = tune(GVL_TUNE_PIPE_ROWS_X100);
+    if (x100 < 100) x100 = total >= 49152 ? 150 : 100;
+    if (x100 > 100 * (i64)PIPE_MAX_ROWS) x100 = 100 * (i64)PIPE_MAX_ROWS;      // (a wave's deferred-rows mask has a bit per row)
+    i64 waves = (total * 100 + x100 - 1) / x100;
+    if (debug_flags() & 33554432) {
+        i64 rpw = (total + LEAN_WAVES - 1) / LEAN_WAVES;
+        rpw = rpw > PIPE_MAX_ROWS ? PIPE_MAX_ROWS : (rpw < 1 ? 1 : rpw);
+        waves = (total + rpw - 1) / rpw;
+    }
     const unsigned grid = (unsigned)((waves + LEAN_WAVES - 1) / LEAN_WAVES);
     const dim3 g(grid), b(LEAN_THREADS);
     hipStream_t s = (hipStream_t)stream;
@@ -5033,21 +5030,37 @@ static int paint_launch(const int64_t *offset_idxs, const int32_t *starts, int64
     }
     return check_launch("gvl_intervals_to_tracks");
 }
-// The painter's stream-ordered scratch (hipMallocAsync): keep what the library has allocated in the device's default pool instead
-// of handing it back to the driver at the next synchronisation (the pool's default release threshold is 0: every call then
-// paid a driver allocation, 25 of the 45 us of a stand-alone painting of BASELINE config 4's batch).  Once per process.
-static void paint_keep_pool() {
-    static const bool once = [] {
-        int dev = 0;
-        hipMemPool_t pool = nullptr;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
-            uint64_t thr = UINT64_MAX;
-            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+// The painter's stream-ordered scratch comes from a pool the LIBRARY owns, one per device (created at the first use on that device):
+// with the device's default pool every call paid a driver allocation (the default release threshold is 0: 25 of the 45 us of a
+// stand-alone painting of BASELINE config 4's batch), and raising THAT pool's threshold would change the allocator for every other
+// hipMallocAsync user of the process.  The library's pools keep up to 256 MiB each across synchronisations.
+static hipError_t paint_alloc(void **p, size_t bytes, hipStream_t s) {
+    static std::mutex mu;
+    static hipMemPool_t pools[64] = {nullptr};
+    static bool tried[64] = {false};
+    int dev = 0;
+    hipMemPool_t pool = nullptr;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!tried[dev]) {
+            tried[dev] = true;
+            hipMemPoolProps props;
+            memset(&props, 0, sizeof(props));
+            props.allocType = hipMemAllocationTypePinned;
+            props.location.type = hipMemLocationTypeDevice;
+            props.location.id = dev;
+            hipMemPool_t np = nullptr;
+            if (hipMemPoolCreate(&np, &props) == hipSuccess && np) {
+                uint64_t thr = 256ull << 20;
+                (void)hipMemPoolSetAttribute(np, hipMemPoolAttrReleaseThreshold, &thr);
+                pools[dev] = np;
+            }
+            (void)hipGetLastError();
         }
-        (void)hipGetLastError();
-        return true;
-    }();
-    (void)once;
+        pool = pools[dev];
+    }
+    if (pool) return hipMallocFromPoolAsync(p, bytes, pool, s);
+    return hipMallocAsync(p, bytes, s);          // (no pool of our own: the device's default pool, untouched)
 }
 static bool paint_can_tile(const int32_t *pmax, int64_t max_row_len) {
     return pmax && max_row_len < 0x7FFFFF00ll && (max_row_len + 2047) / 2048 <= 0x7FFFFFFFll / 4;
@@ -5066,11 +5079,10 @@ int gvl_intervals_to_tracks(const int64_t *offset_idxs, const int32_t *starts, i
         return fail(GVL_ERR_INVALID, "%s", "gvl_intervals_to_tracks: NULL interval array");
     if (n_queries > 65535) return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_intervals_to_tracks: more than 65535 queries per call");
     hipStream_t s = (hipStream_t)stream;
-    paint_keep_pool();
     int *scratch = nullptr;
     if (!itv_pmax_ends && n_intervals > 0) {
         // no precomputed prefix maxima: build them for the queried lists in stream-ordered scratch
-        if (hipMallocAsync((void **)&scratch, (size_t)n_intervals * sizeof(int), s) != hipSuccess) {
+        if (paint_alloc((void **)&scratch, (size_t)n_intervals * sizeof(int), s) != hipSuccess) {
             (void)hipGetLastError();
             return fail(GVL_ERR_HIP, "%s", "gvl_intervals_to_tracks: scratch allocation failed (pass itv_pmax_ends)");
         }
@@ -5085,7 +5097,7 @@ int gvl_intervals_to_tracks(const int64_t *offset_idxs, const int32_t *starts, i
     const i64 n_chunks = (max_row_len + 2047) / 2048;
     PaintTodo *todo = nullptr;
     if (paint_can_tile(itv_pmax_ends, max_row_len) &&
-        hipMallocAsync((void **)&todo, (size_t)(n_queries * n_chunks) * sizeof(PaintTodo), s) != hipSuccess) {
+        paint_alloc((void **)&todo, (size_t)(n_queries * n_chunks) * sizeof(PaintTodo), s) != hipSuccess) {
         (void)hipGetLastError();
         todo = nullptr;
     }
@@ -5112,7 +5124,6 @@ int gvl_paint_tracks(const gvl_track_set *ts, const int64_t *offset_idxs, const 
         return gvl_intervals_to_tracks(offset_idxs, starts, starts_stride, n_queries, ts->itv_starts, ts->itv_ends, ts->itv_values,
                                        ts->itv_offsets, ts->n_intervals, nullptr, out, out_offsets, max_row_len, stream);
     hipStream_t s = (hipStream_t)stream;
-    paint_keep_pool();
     PaintIndex X{nullptr, nullptr, nullptr, nullptr};
     if (ts->bkt_offsets && ts->bkt_base && ts->bkt_lo && ts->bkt_hi && !(debug_flags() & 1024))
         X = PaintIndex{(const i64 *)ts->bkt_offsets, ts->bkt_base, ts->bkt_lo, ts->bkt_hi};
@@ -5122,7 +5133,7 @@ int gvl_paint_tracks(const gvl_track_set *ts, const int64_t *offset_idxs, const 
     // malloc + free pair cost more than the painting itself)
     const bool complete = ts->tile_complete != 0 && X.offsets && !(debug_flags() & (8192 | 1024));
     if (!complete && paint_can_tile(ts->itv_pmax_ends, max_row_len) &&
-        hipMallocAsync((void **)&todo, (size_t)(n_queries * n_chunks) * sizeof(PaintTodo), s) != hipSuccess) {
+        paint_alloc((void **)&todo, (size_t)(n_queries * n_chunks) * sizeof(PaintTodo), s) != hipSuccess) {
         (void)hipGetLastError();
         todo = nullptr;
     }
@@ -5186,7 +5197,7 @@ static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const 
         A.plan_hdr = plan_hdr; A.plan_ent = plan_ent;
     }
     // (GVL_TRACK_EXTRA_LDS: bytes of unused LDS per workgroup, to measure the kernel at fewer waves per SIMD)
-    static const unsigned xl = [] { const char *e = getenv("GVL_TRACK_EXTRA_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
+    const unsigned xl = 0;
     if (ps) realign_tracks_kernel<true><<<dim3((unsigned)grid, (unsigned)chunks), dim3(256), xl, (hipStream_t)stream>>>(A, *ps);
     else realign_tracks_kernel<false><<<dim3((unsigned)grid, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream>>>(A, PaintSrcArgs());
     return check_launch("gvl_realign_tracks");
@@ -5429,7 +5440,8 @@ static i64 loader_track_plan_bytes(const gvl_loader_config *cfg, i64 n) {
     if (cfg->output_length <= 2048) return 0;
     int chunks = 1, chunk_len = 0;
     if (pick_chunk(cfg->output_length, &chunks, &chunk_len) || chunks <= 1) return 0;
-    static const i64 cap = [] { const char *e = getenv("GVL_TRACK_PLAN_MAX_MB"); return (i64)(e ? atoll(e) : 512) << 20; }();
+    const i64 cap_t = tune(GVL_TUNE_TRACK_PLAN_MAX_MB);
+    const i64 cap = (cap_t > 0 ? cap_t : 512) << 20;
     const i64 b = track_plan_bytes(n * cfg->ploidy, chunks);
     return b <= cap ? b : 0;
 }

@@ -389,6 +389,7 @@ def intervals_to_tracks(offset_idxs, starts, itv_starts, itv_ends, itv_values, i
     res = _device.intervals_to_tracks(offset_idxs, starts, a, b, v, io, _req(out_offsets, np.int64, "out_offsets", 1),
                                       itv_pmax_ends=pm, track_set=ts)
     out[...] = _np(res)
+    _lib.check_async()       # (a tile_complete set whose chunk the tiled kernel could not finish is reported, never returned half painted)
 
 
 def shift_and_realign_tracks_sparse(out, out_offsets, regions, shifts, geno_offset_idx, geno_v_idxs, geno_offsets,
@@ -415,3 +416,4 @@ def intervals_and_realign_track_fused(out, out_offsets, regions, shifts, geno_of
     res = _device.realign_tracks(dev, regions, shifts, geno_offset_idx, _req(out_offsets, np.int64, "out_offsets", 1),
                                  scratch, track_offsets, params, strategy_id, base_seed, keep, keep_offsets, to_rc)
     out[...] = _np(res)
+    _lib.check_async()

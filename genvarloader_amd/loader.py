@@ -785,6 +785,9 @@ class DeviceLoader:
         tabs = nat.setdefault("tables", [None, None])
         tab = tabs[which]
         if tab is None or tab.numel() < nbytes:
+            # (a table that is replaced by a larger one stays alive until the NEXT replacement: batches of the epoch that used it may
+            # still be in flight on the loader's own streams, which torch's allocator knows nothing about)
+            nat["table_replaced"] = tab
             tab = tabs[which] = torch.empty(nbytes + nbytes // 4, dtype=torch.uint8, device=d)
         P, bs = ds.ploidy, self.batch_size
 
@@ -888,6 +891,12 @@ class DeviceLoader:
                     _lib.check(lib.gvl_loader_prefetch_epoch(handle, C.c_uint64(next_epoch & 0xFFFFFFFFFFFFFFFF),
                                                              C.c_void_p(norder.data_ptr()), C.c_int64(nn), C.c_int32(int(self.drop_last)),
                                                              C.c_void_p(ntab.data_ptr()), C.c_void_p(side.cuda_stream)))
+                # allocated under the side stream, read by the consumer's stream (and by the loader's submit streams, which the
+                # consumer's stream is ordered behind): tell the caching allocator, or a block freed later could be handed out again
+                # on the side stream while those reads are still queued
+                if side is not live:
+                    norder.record_stream(live)
+                    ntab.record_stream(live)
                 nat["prefetch"] = (nkey, norder, 1 - which)
             nxt, ref_out, bs = lib.gvl_loader_next, C.byref(out), self.batch_size
             nxt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]          # plain ints in, no wrapper objects per call

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GVL_ABI_VERSION 8
+#define GVL_ABI_VERSION 9
 
 enum {
     GVL_OK = 0,
@@ -164,6 +164,15 @@ int gvl_abi_version(void);
 /* Test / diagnostic switches (the bits of the GVL_DBG environment variable, see
  * debug_flags() in gvl_hip.hip); flags < 0 returns to the environment's value. */
 int gvl_set_debug_flags(int flags);
+/* Launch-policy overrides, process-wide: for A/B measurements and for tests that must force a schedule the built-in policy
+ * would not pick at their sizes.  value <= 0 returns the key to the built-in policy.  Results never depend on them.
+ *   GVL_TUNE_PIPE_ROWS_X100      rows per wave of the pipelined kernel, times 100 (100 = one, 150 = two for the first half of
+ *                                the waves, 200 = exactly two, 300 = three ...; at most 3200).  Built in: 150 from 49 152 rows.
+ *   GVL_TUNE_PIPE_MIN_ROWS       launches with fewer rows keep the wave-per-row kernel (built in: 8192; 2048 for groups).
+ *   GVL_TUNE_LEAN_SUB            consecutive chunks of a long row one wave takes (built in: 2).
+ *   GVL_TUNE_TRACK_PLAN_MAX_MB   row plans of an epoch larger than this are not kept (built in: 512). */
+enum { GVL_TUNE_PIPE_ROWS_X100 = 0, GVL_TUNE_PIPE_MIN_ROWS = 1, GVL_TUNE_LEAN_SUB = 2, GVL_TUNE_TRACK_PLAN_MAX_MB = 3, GVL_TUNE_COUNT = 4 };
+int gvl_set_tuning(int32_t key, int64_t value);
 const char *gvl_last_error(void);
 /* (The flag behind gvl_async_error is PROCESS-global: it says that some launch of this process met the
  * condition, not which one.)

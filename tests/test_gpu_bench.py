@@ -53,6 +53,9 @@ def test_bench_contract_single_gpu():
     assert c["kind"] == "port" and c["value"] > 0 and "1" in c["threads_sweep"] and c["cores"] >= 1
     assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "workload" in d["config"] and "model" not in d["config"]
+    # the line checks what it timed: two batches of the last timed launch (one at an in-group position >= 11 when the rotation allows)
+    v = d["verified"]
+    assert v["batches"] >= 1 and v["mismatches"] == 0 and v["rows"] == 4096 * v["batches"]
 
 
 def test_bench_secondary_legs():
@@ -67,6 +70,12 @@ def test_bench_secondary_legs():
     assert rg["ms_per_step"] > 0 and 0 < rg["step_frac"] < 1 and rg["epochs_timed"] >= 2 and rg["batches_per_epoch"] == 8
     assert c4["ms_per_step"] > 0 and 0 < c4["step_frac"] < 1 and c4["kernel_ms"] > 0 and "131072" in c4["workload"]
     assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]          # the headline is cfg3's
+    # the reference's other output modes + the reference-only fetch + training mode, each a driver-timed leg
+    for name in ("onehot_cl", "annotated", "keep_mask", "reference", "random_shifts"):
+        leg = sec[name]
+        assert "error" not in leg, (name, leg)
+        assert leg["ms_per_step"] > 0 and 0 < leg["step_frac"] < 1.3 and leg["algorithmic_bytes_per_step"] > 4096 * 2048 * 4, (name, leg)
+    assert sec["random_shifts"]["deterministic_ms_per_step"] > 0
 
 
 @pytest.mark.parametrize("extra", [["--gather"], ["--strong", "--gather"]], ids=["weak+gather", "strong+gather"])
@@ -97,6 +106,20 @@ def test_bench_two_gpus_rccl():
 
 
 def test_bench_refuses_world_size_mismatch():
+    """Started under a launcher (WORLD_SIZE set) with another --gpus: refused."""
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5", *SMALL], capture_output=True, text=True,
-                       cwd=REPO, timeout=300)
+                       cwd=REPO, timeout=300, env={**os.environ, "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (how the driver runs --gpus 1): the parent starts torch.distributed.run as a
+    child before it has touched the GPU, relays the line and exits with the child's code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"GVL_BENCH_DEVICE": "0", "GVL_BENCH_BACKEND": "gloo"})
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--gather", *SMALL],
+                       capture_output=True, text=True, cwd=REPO, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["gather_ms"] > 0 and d["scaling"] == "weak"
+    assert abs(d["value"] - 8192 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]

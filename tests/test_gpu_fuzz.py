@@ -96,8 +96,8 @@ def test_fuzz_lean_kernel_pipelined(dbg):
                          ids=["default", "every-chunk-solo", "rereads", "one-chunk-per-wave", "four-chunks-per-wave"])
 def test_fuzz_lean_kernel_long_rows(dbg, sub):
     """FUZZ_LONG=1: rows of 2 052 ... 40 000 bases = the lean kernel's chunked form (BASELINE config 4's haplotype kernel),
-    with 1 / 2 / 4 consecutive chunks per wave (GVL_LEAN_SUB)."""
-    _run("fuzz_lean.py", 120, 210 + sub + (dbg >> 15), dbg=dbg, FUZZ_LONG=1, GVL_LEAN_SUB=sub)
+    with 1 / 2 / 4 consecutive chunks per wave (FUZZ_SUB -> gvl_set_tuning)."""
+    _run("fuzz_lean.py", 120, 210 + sub + (dbg >> 15), dbg=dbg, FUZZ_LONG=1, FUZZ_SUB=sub)
 
 
 @pytest.mark.parametrize("dbg", [0, 2097152], ids=["default", "no-window"])
@@ -111,9 +111,16 @@ def test_fuzz_tracks_straight_from_intervals(dbg):
                          ids=["default", "every-chunk-solo", "rereads", "one-chunk-per-wave", "all-purpose-kernel"])
 def test_fuzz_lean_kernel_ragged_long_rows(dbg, sub):
     """FUZZ_LONG=1 FUZZ_RAGGED=1: ragged rows (output_length = -1) of 2 052 ... 40 000 bases = recon_lean_kernel<.., LONG, RAGL>."""
-    _run("fuzz_lean.py", 120, 230 + sub + (dbg >> 15), dbg=dbg, FUZZ_LONG=1, FUZZ_RAGGED=1, GVL_LEAN_SUB=sub)
+    _run("fuzz_lean.py", 120, 230 + sub + (dbg >> 15), dbg=dbg, FUZZ_LONG=1, FUZZ_RAGGED=1, FUZZ_SUB=sub)
 
 
 def test_fuzz_lean_kernel_ragged_short_rows():
     """FUZZ_RAGGED=1: ragged rows of at most 2 048 + 6 bases = recon_lean_rows_kernel's ragged form."""
     _run("fuzz_lean.py", 300, 240, FUZZ_RAGGED=1)
+
+
+@pytest.mark.parametrize("ragged", [0, 1], ids=["fixed", "ragged"])
+def test_fuzz_lean_kernel_many_batches_one_grid(ragged):
+    """FUZZ_MANY=1: 4-16 batches of 1 500-6 000 queries in ONE multi-workgroup grid on default flags (what bench.py times and the
+    native loader launches), 1 / 1.5 / 2 / 3 / 8 rows per wave, every batch of every launch against the oracle."""
+    _run("fuzz_lean.py", 24, 250 + ragged, FUZZ_MANY=1, FUZZ_RAGGED=ragged)

@@ -695,6 +695,64 @@ def test_genome_dataset_batches(gpu, oracle, kpath, scale_kw):
         np.testing.assert_array_equal(out.onehot.cpu().numpy(), exp_oh)
 
 
+@pytest.mark.parametrize("x100", [0, 200, 300], ids=["default-1.5-rows-per-wave", "exactly-2", "exactly-3"])
+@pytest.mark.parametrize("want", ["onehot", "both", "ragged-onehot", "ragged-both"])
+def test_bench_launch_every_row_vs_oracle(gpu, oracle, want, x100):
+    """The launch bench.py times and the native loader submits, at its full size and on DEFAULT flags: 16 batches of 4096 x 2048
+    (BASELINE config 3) of one dataset through pack_many / launch_many = ONE grid of recon_lean_rows_kernel over 65 536 rows on
+    10 923 workgroups, the first half of the waves taking rows w and w + W.  EVERY batch against the oracle -- the second rows of the
+    two-row waves live in batches 10-15: their window + slot line arrive by LDS-DMA under the first row's stores, behind a counted
+    vmcnt, and their (batch, row) comes from advance() with W > rows_per_batch.  Also with exactly two and exactly three rows per wave
+    (gvl_set_tuning), one-hot only (what the bench's headline launches) and one-hot + bytes, fixed-length and ragged rows
+    (output_length = -1: offsets from gvl_hap_offsets, the RAG form)."""
+    from genvarloader_amd import HapsDevice, _lib, synth
+
+    ds = synth.GenomeDataset(device="cuda", contigs=(6_000_000, 3_000_000, 2_000_000), n_queries=40_000, seed=20260805)
+    dev = HapsDevice(**ds.static_kwargs())
+    assert dev.slot_rec is not None and dev.ref4 is not None
+    hs = ds.host_static()
+    ragged, haps = want.startswith("ragged"), want.endswith("both")
+    L = -1 if ragged else ds.length
+    qsets = ds.draw_batches(16, 2048, seed=3)
+    bts, outs, keep = [], [], []
+    for q in qsets:
+        r = ds.request(q)
+        if ragged:
+            d0 = dev.prepare_batch(r["regions"], r["shifts"], r["geno_offset_idx"], -1, to_rc=r["to_rc"])
+            oo, tm, _ = dev.hap_offsets(d0)
+            total, mx = (int(v) for v in tm.cpu().tolist())
+            dbt = dev.prepare_batch(d0.regions, d0.shifts, d0.geno_offset_idx, -1, to_rc=d0.to_rc, out_offsets=oo, max_row_len=mx)
+        else:
+            dbt = dev.prepare_batch(r["regions"], r["shifts"], r["geno_offset_idx"], L, to_rc=r["to_rc"])
+            total = dbt.n_rows * L
+        o, oc = dev.alloc_output(dbt, total, haps=haps, onehot=True)
+        bts.append(dbt); outs.append(oc); keep.append(o)
+    assert sum(b.n_rows for b in bts) == 65_536
+    _lib.check_async()
+    _lib.set_tuning(_lib.TUNE_PIPE_ROWS_X100, x100)
+    try:
+        dev.launch_many(dev.pack_many(bts, outs))
+        gpu.torch.cuda.synchronize()
+        _lib.check_async()
+    finally:
+        _lib.set_tuning(_lib.TUNE_PIPE_ROWS_X100, 0)
+    n_rc = 0
+    for i, q in enumerate(qsets):
+        hb = ds.host_batch(q)
+        n_rc += int(hb.to_rc.sum())
+        exp, exp_off, exp_oh = oracle.reconstruct_haplotypes_fused(
+            hb.regions, hb.shifts, hb.geno_offset_idx, hb.geno_offsets, hb.geno_v_idxs, hs.v_starts, hs.ilens,
+            hs.alt_alleles, hs.alt_offsets, hs.ref, hs.ref_offsets, hs.pad_char, L, None, None, hb.to_rc, True,
+            onehot=True, n_threads=8)
+        np.testing.assert_array_equal(keep[i].out_offsets.cpu().numpy(), exp_off, err_msg=f"batch {i}")
+        np.testing.assert_array_equal(keep[i].onehot.cpu().numpy(), exp_oh, err_msg=f"batch {i}")
+        if haps:
+            np.testing.assert_array_equal(keep[i].haps.cpu().numpy(), exp, err_msg=f"batch {i}")
+        if ragged:
+            assert len(set(np.diff(exp_off).tolist())) > 20
+    assert 0.4 < n_rc / 65_536 < 0.6
+
+
 def test_slot_records_layout(gpu):
     """gvl_pack_slots: 8 records per slot, EMPTY padding, OVERFLOW for slots with more than 8 variants."""
     st, bt = _synth(41, (60_000,), 300, 600, indel_frac=0.3, density=1 / 60)

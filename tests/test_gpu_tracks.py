@@ -178,7 +178,7 @@ def test_cfg4_full_size_batch_through_the_native_ring(oracle):
     from its intervals) -- against the haplotype oracle and the oracle's fused paint + realign."""
     import torch
 
-    from tools import bench_cfg4
+    import bench_cfg4
 
     R, S, P, L = 2, 64, 2, 131072
     st, dev, ds, tracks, _ = bench_cfg4.build("cuda:0", R, S, P, L, seed=99, contig=48 << 20)

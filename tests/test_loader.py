@@ -257,10 +257,11 @@ def test_cfg5_epoch_full_size_properties_and_sampled_parity(oracle):
         assert int(zero_rows) == int(non_acgt)
         return int(total), samples
 
-    t_shuffled, samples = epoch(True, {0, 97, 244})
+    # (groups of 16 batches = one grid: in-group positions 0, 13, 15, 15, 4 -- positions 10-15 hold the SECOND rows of the two-row waves)
+    t_shuffled, samples = epoch(True, {0, 13, 111, 239, 244})
     t_ordered, _ = epoch(False, set())
     assert t_shuffled == t_ordered
-    assert len(samples) == 3
+    assert len(samples) == 5
     for idx, hp, oh in samples:
         r_idx, s_idx = np.unravel_index(idx, (R, S))
         regions = full_regions[r_idx]

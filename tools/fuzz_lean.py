@@ -4,7 +4,13 @@ meet indels, windows over contig edges, overflowing slots: every row the lean pa
 is checked the same way.  python tools/fuzz_lean.py [n_cases] [seed]
 FUZZ_LONG=1: rows of several 2048-base chunks (the kernel's LONG form: one wave per chunk, the row's walk replayed from
 the CSR records) -- chunk borders inside alleles, behind deletions, rows with hundreds of variants.
-FUZZ_RAGGED=1: output_length = -1 (rows at out_offsets, any length): the pipelined kernel's ragged form, with FUZZ_LONG the chunked one's."""
+FUZZ_RAGGED=1: output_length = -1 (rows at out_offsets, any length): the pipelined kernel's ragged form, with FUZZ_LONG the chunked one's.
+FUZZ_SUB=n: consecutive chunks of a long row per wave (gvl_set_tuning(GVL_TUNE_LEAN_SUB)).
+FUZZ_MANY=1: what bench.py and the native loader launch -- 4-16 batches of 1 500-6 000 queries each through gvl_reconstruct_many on
+DEFAULT flags = ONE multi-workgroup grid of recon_lean_rows_kernel, every batch of every launch compared with the oracle; the rows per
+wave drawn per case (the built-in policy, 1.5, exactly 2, 3, 8: a wave's second and later rows are the DMA prefetch a row ahead, the
+counted vmcnt and the (batch, row) arithmetic of rows w + W, w + 2 W ...).  With FUZZ_RAGGED=1: the ragged form, offsets from
+gvl_hap_offsets per batch."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,6 +19,7 @@ from oracle import oracle
 
 
 LONG = bool(int(os.environ.get("FUZZ_LONG", "0")))
+MANY = bool(int(os.environ.get("FUZZ_MANY", "0")))
 RAGGED = bool(int(os.environ.get("FUZZ_RAGGED", "0")))     # output_length = -1: rows at out_offsets (with FUZZ_LONG: the chunked kernel's ragged form)
 
 
@@ -73,10 +80,94 @@ def check(st, bt, want=(True, False)):
     return ok
 
 
+def many_case(rng):
+    """One launch of n_b batches (the last one may be shorter) cut out of one big draw -> (static, full batch, cuts, L, P, x100)."""
+    contigs = tuple(int(x) for x in rng.integers(40_000, 400_000, int(rng.integers(1, 4))))
+    st = synth.make_static(rng, contigs, density=float(rng.choice([1 / 400, 1 / 100, 1 / 30])), indel_frac=float(rng.choice([0.0, 0.15, 0.5])),
+                           af_beta=(float(rng.choice([0.3, 0.6, 2.0])), float(rng.choice([0.9, 2.5]))), max_indel=int(rng.choice([3, 30, 200])),
+                           n_frac=float(rng.choice([0.0, 0.01])))
+    P = 2
+    L = int(rng.choice([64, 256, 500, 512, 1024, 2048]))
+    n_b = int(rng.integers(4, 17))
+    per = int(rng.integers(1500, 6001))
+    cap = max(1, (40 << 20) // (L * P * n_b))            # (bounds the host side of the comparison: <= 40 MB of haplotype bytes a launch)
+    per = min(per, cap)
+    last = per if rng.random() < 0.5 else int(rng.integers(1, per + 1))
+    nq = per * (n_b - 1) + last
+    full = synth.make_batch(rng, st, nq, P, L, slack=int(rng.choice([0, 8, 40])), rc_frac=float(rng.choice([0.0, 0.5])),
+                            random_shifts=bool(rng.random() < 0.5), lookback=int(rng.choice([40, 300])),
+                            edge_frac=float(rng.choice([0.0, 0.0, 0.02])), permute_csr=bool(rng.random() < 0.5))
+    if RAGGED:
+        full.regions = full.regions.copy()
+        full.regions[:, 2] += rng.integers(0, 7, len(full.regions)).astype(full.regions.dtype)
+    cuts = [(i * per, min((i + 1) * per, nq)) for i in range(n_b)]
+    x100 = int(rng.choice([0, 0, 150, 200, 300, 800]))
+    return st, full, cuts, L, P, x100
+
+
+def check_many(st, full, cuts, L, P, x100, want):
+    from genvarloader_amd import _lib
+
+    onehot, haps = want
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens, alt_alleles=st.alt_alleles,
+                     alt_offsets=st.alt_offsets, geno_offsets=full.geno_offsets, geno_v_idxs=full.geno_v_idxs, pad_char=st.pad_char)
+    assert dev.ref4 is not None and dev.slot_rec is not None
+    _lib.set_tuning(_lib.TUNE_PIPE_ROWS_X100, x100)
+    try:
+        bts, outs, keep = [], [], []
+        for a, b in cuts:
+            rc = None if full.to_rc is None else full.to_rc[a * P:b * P]
+            if RAGGED:
+                d0 = dev.prepare_batch(full.regions[a:b], full.shifts[a:b], full.geno_offset_idx[a:b], -1, to_rc=rc)
+                oo, tm, _ = dev.hap_offsets(d0)
+                total, mx = (int(v) for v in tm.cpu().tolist())
+                dbt = dev.prepare_batch(d0.regions, d0.shifts, d0.geno_offset_idx, -1, to_rc=d0.to_rc, out_offsets=oo, max_row_len=mx)
+            else:
+                dbt = dev.prepare_batch(full.regions[a:b], full.shifts[a:b], full.geno_offset_idx[a:b], L, to_rc=rc)
+                total = (b - a) * P * L
+            o, oc = dev.alloc_output(dbt, total, haps=haps, onehot=onehot)
+            bts.append(dbt); outs.append(oc); keep.append(o)
+        dev.launch_many(dev.pack_many(bts, outs))
+        torch.cuda.synchronize()
+        _lib.check_async()
+    finally:
+        _lib.set_tuning(_lib.TUNE_PIPE_ROWS_X100, 0)
+    ok = True
+    for i, (a, b) in enumerate(cuts):
+        rc = None if full.to_rc is None else full.to_rc[a * P:b * P]
+        eh, eo, eoh = oracle.reconstruct_haplotypes_fused(
+            full.regions[a:b], full.shifts[a:b], full.geno_offset_idx[a:b], full.geno_offsets, full.geno_v_idxs, st.v_starts, st.ilens,
+            st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, -1 if RAGGED else L, None, None, rc, True, onehot=True,
+            n_threads=8)
+        ok = ok and np.array_equal(keep[i].out_offsets.cpu().numpy(), eo)
+        if onehot:
+            ok = ok and np.array_equal(keep[i].onehot.cpu().numpy(), eoh)
+        if haps:
+            ok = ok and np.array_equal(keep[i].haps.cpu().numpy(), eh)
+    return ok
+
+
 if __name__ == "__main__":
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     oracle.build()
+    if int(os.environ.get("FUZZ_SUB", "0")) > 0:
+        from genvarloader_amd import _lib
+
+        _lib.set_tuning(_lib.TUNE_LEAN_SUB, int(os.environ["FUZZ_SUB"]))
+    if MANY:
+        bad, t0, rows = 0, time.time(), 0
+        for ci in range(n_cases):
+            rng = np.random.default_rng(seed0 * 100003 + ci)
+            st, full, cuts, L, P, x100 = many_case(rng)
+            want = ((True, False), (True, True), (False, True))[ci % 3]
+            rows += cuts[-1][1] * P
+            if not check_many(st, full, cuts, L, P, x100, want):
+                bad += 1
+                print(f"MISMATCH many-case {ci} (seed {seed0}) onehot, haps = {want}: L={L} batches={len(cuts)} per={cuts[0][1]} last={cuts[-1][1] - cuts[-1][0]} "
+                      f"x100={x100} V/row={full.mean_variants:.1f}", flush=True)
+        print(f"{n_cases} lean many-batch launches ({rows} rows), {bad} mismatches, {time.time()-t0:.1f} s")
+        sys.exit(1 if bad else 0)
     bad = 0
     t0 = time.time()
     for ci in range(n_cases):
