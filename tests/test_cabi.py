@@ -38,7 +38,7 @@ def test_header_symbols_all_exported(lib):
     assert sorted(_lib.SYMBOLS) == decl
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in gvl_hip.h but not exported"
-    assert lib.gvl_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.gvl_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_ctypes_structs_match_c_layout(tmp_path):
