@@ -149,8 +149,9 @@ def _check_fresh(p: Path) -> None:
     if "GVL_HIP_LIB" in os.environ or os.environ.get("GVL_ALLOW_STALE_LIB"):
         return
     stamp = p.with_suffix(".so.content")
-    srcs = [_HERE / "csrc" / "gvl_hip.hip", _HERE / "csrc" / "gvl_lean.inc", _HERE / "csrc" / "gvl_lean_pipe.inc", _HERE.parent / "include" / "gvl_hip.h"]
-    if not all(f.exists() for f in srcs):
+    # (the same set, in the same order, as __graft_entry__.hip_sources())
+    srcs = sorted((_HERE / "csrc").glob("*.hip")) + sorted((_HERE / "csrc").glob("*.inc")) + [_HERE.parent / "include" / "gvl_hip.h"]
+    if len(srcs) < 2 or not all(f.exists() for f in srcs):
         return
     if not stamp.exists():
         # an in-tree library next to its sources but without its stamp (e.g. a snapshot that shipped the .so alone): nothing says
@@ -161,7 +162,7 @@ def _check_fresh(p: Path) -> None:
     for f in srcs:
         h.update(f.read_bytes())
     if stamp.read_text().strip() != h.hexdigest():
-        raise GvlError(f"{p} was not built from the sources next to it (csrc/gvl_hip.hip, csrc/gvl_lean*.inc, include/gvl_hip.h changed "
+        raise GvlError(f"{p} was not built from the sources next to it (csrc/*.hip, csrc/*.inc, include/gvl_hip.h changed "
                        "since): run `python -c 'import __graft_entry__ as g; g.build()'` (GVL_ALLOW_STALE_LIB=1 overrides)")
 
 

@@ -1,0 +1,51 @@
+// gvl_lean.hip -- recon_lean_kernel (gvl_lean.inc: a wave per row; rows of several chunks -- BASELINE config 4 -- by chunks) and its launcher.
+#include "gvl_internal.inc"
+
+namespace {
+#include "gvl_dev.inc"
+#include "gvl_recon_body.inc"
+#include "gvl_lean.inc"
+}  // namespace
+
+namespace gvli {
+int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
+    LeanArgs A;
+    memset(&A, 0, sizeof(A));
+    A.ref4 = RA.ref4; A.ref_offsets = RA.ref_offsets; A.srec = RA.srec;
+    A.regions = RA.regions; A.shifts = RA.shifts; A.geno_offset_idx = RA.geno_offset_idx; A.to_rc = RA.to_rc;
+    A.onehot = RA.onehot; A.haps = RA.haps; A.out_offsets_w = RA.out_offsets_w; A.alt_alleles = RA.alt_alleles; A.stamps = RA.stamps;
+    A.go_starts = RA.go_starts; A.go_stops = RA.go_stops; A.grec = RA.grec; A.alt_offsets = RA.alt_offsets;
+    A.n_geno_offsets = RA.n_geno_offsets;
+    A.n_rows = (int)RA.n_rows; A.n_contigs = RA.n_contigs; A.regions_stride = (int)RA.regions_stride;
+    A.ploidy_shift = RA.ploidy_shift; A.ploidy = RA.ploidy; A.L = (int)RA.fixed_len; A.dbg = RA.dbg;
+    A.chunks = chunks;
+    // rows of several chunks: a wave takes `sub` consecutive chunks, the second and later ones resume the first one's walk.
+    // 2 by default -- BASELINE config 4's 256 rows x 64 chunks are then 8 192 waves, every wave slot of the part once;
+    // gvl_set_tuning(GVL_TUNE_LEAN_SUB) overrides (1 = every chunk its own wave and its own walk)
+    const i64 sub_t = tune(GVL_TUNE_LEAN_SUB);
+    A.sub = chunks > 1 ? (sub_t > 0 ? (int)(sub_t > 64 ? 64 : sub_t) : 2) : 1;
+    const i64 per_row = (chunks + A.sub - 1) / A.sub;
+    const unsigned grid = (unsigned)(((i64)A.n_rows * per_row + LEAN_WAVES - 1) / LEAN_WAVES);
+    const dim3 g(grid), b(LEAN_THREADS);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned xl = 0;
+    if (chunks > 1 && RA.out_offsets) {         // ragged long rows (lean_long_rag_eligible)
+        A.out_offsets = RA.out_offsets;
+        A.out_offsets_w = nullptr;
+        A.L = 0;
+        if (A.onehot && A.haps) recon_lean_kernel<true, true, true, true><<<g, b, 0, s>>>(A, RA);
+        else if (A.onehot) recon_lean_kernel<true, false, true, true><<<g, b, 0, s>>>(A, RA);
+        else recon_lean_kernel<false, true, true, true><<<g, b, 0, s>>>(A, RA);
+    } else if (chunks > 1) {
+        if (A.onehot && A.haps) recon_lean_kernel<true, true, true><<<g, b, 0, s>>>(A, RA);
+        else if (A.onehot) recon_lean_kernel<true, false, true><<<g, b, 0, s>>>(A, RA);
+        else recon_lean_kernel<false, true, true><<<g, b, 0, s>>>(A, RA);
+    } else {
+        if (A.onehot && A.haps) recon_lean_kernel<true, true, false><<<g, b, xl, s>>>(A, RA);
+        else if (A.onehot) recon_lean_kernel<true, false, false><<<g, b, xl, s>>>(A, RA);
+        else recon_lean_kernel<false, true, false><<<g, b, 0, s>>>(A, RA);
+    }
+    return check_launch("gvl_reconstruct (lean)");
+}
+
+}  // namespace gvli

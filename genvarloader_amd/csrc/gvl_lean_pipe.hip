@@ -1,0 +1,83 @@
+// gvl_lean_pipe.hip -- recon_lean_rows_kernel (gvl_lean_pipe.inc: one grid over a group of batches, a wave pipelines over rows) and its launcher.
+#include "gvl_internal.inc"
+
+namespace {
+#include "gvl_dev.inc"
+#include "gvl_recon_body.inc"
+#include "gvl_lean.inc"
+#include "gvl_lean_pipe.inc"
+}  // namespace
+
+namespace gvli {
+// can these (lean-eligible, one-chunk) batches share a grid?  the same shape and outputs; every batch but the last has the
+// first one's row count
+bool lean_pipe_compatible(const ReconArgs *RAs, int n) {
+    const ReconArgs &F = RAs[0];
+    if (((uintptr_t)F.ref4 & 15) || ((uintptr_t)F.srec & 15)) return false;        // (16-byte DMA sources)
+    i64 total = 0;
+    for (int i = 0; i < n; ++i) {
+        const ReconArgs &R = RAs[i];
+        if (R.fixed_len != F.fixed_len || R.ploidy != F.ploidy || R.regions_stride != F.regions_stride ||
+            (R.out_offsets != nullptr) != (F.out_offsets != nullptr) ||
+            (R.onehot != nullptr) != (F.onehot != nullptr) || (R.haps != nullptr) != (F.haps != nullptr) || R.dbg != F.dbg)
+            return false;
+        if (R.n_rows <= 0 || R.n_rows > F.n_rows || (i + 1 < n && R.n_rows != F.n_rows)) return false;
+        total += R.n_rows;
+    }
+    return total <= 0x7FFFFFF0ll && F.regions_stride <= 0x7FFFFFFFll;
+}
+int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks) {
+    const ReconArgs &RA = RAs[0];
+    LeanArgs A;
+    LeanMany M;
+    memset(&A, 0, sizeof(A));
+    memset(&M, 0, sizeof(M));
+    A.ref4 = RA.ref4; A.ref_offsets = RA.ref_offsets; A.srec = RA.srec;
+    A.regions = RA.regions; A.shifts = RA.shifts; A.geno_offset_idx = RA.geno_offset_idx; A.to_rc = RA.to_rc;
+    A.onehot = RA.onehot; A.haps = RA.haps; A.out_offsets_w = RA.out_offsets_w; A.alt_alleles = RA.alt_alleles;
+    A.go_starts = RA.go_starts; A.go_stops = RA.go_stops; A.grec = RA.grec; A.alt_offsets = RA.alt_offsets;
+    A.n_geno_offsets = RA.n_geno_offsets;
+    A.n_contigs = RA.n_contigs; A.regions_stride = (int)RA.regions_stride;
+    A.ploidy_shift = RA.ploidy_shift; A.ploidy = RA.ploidy; A.L = (int)RA.fixed_len; A.dbg = RA.dbg;
+    A.chunks = 1; A.sub = 1;
+    A.rows_per_batch = (int)RA.n_rows; A.n_batches = n;
+    A.max_row_len = (int)((i64)RA.chunk_len * (RA.out_offsets ? rag_chunks : 1));
+    i64 total = 0;
+    for (int i = 0; i < n; ++i) {
+        LeanBatch &b = M.b[i];
+        b.regions = RAs[i].regions; b.shifts = RAs[i].shifts; b.geno_offset_idx = RAs[i].geno_offset_idx; b.to_rc = RAs[i].to_rc;
+        b.onehot = RAs[i].onehot; b.haps = RAs[i].haps; b.out_offsets_w = RAs[i].out_offsets_w; b.n_rows = RAs[i].n_rows;
+        b.out_offsets = RAs[i].out_offsets;
+        total += RAs[i].n_rows;
+    }
+    A.n_rows = (int)total;
+    // Rows per wave (x 100).  Measured (profiles/r04_pipe_experiments.txt G, K): ONE row per wave -- no row-to-row prefetch at
+    // all -- is the best schedule up to ~12 batches per launch (short waves: the hardware's workgroup dispatch balances the chip);
+    // above that "two rows per wave", which is 1.5 on average: the first half of the waves take two rows (w, w + W), the second
+    // half -- dispatched last -- one, so the grid drains in short waves (125 / 175 measure like 150; exactly 2, or 3, are slower).
+    // gvl_set_tuning(GVL_TUNE_PIPE_ROWS_X100) overrides (200 = exactly two rows for every wave, 300 = three, ...).
+    i64 x100 = tune(GVL_TUNE_PIPE_ROWS_X100);
+    if (x100 < 100) x100 = total >= 49152 ? 150 : 100;
+    if (x100 > 100 * (i64)PIPE_MAX_ROWS) x100 = 100 * (i64)PIPE_MAX_ROWS;      // (a wave's deferred-rows mask has a bit per row)
+    i64 waves = (total * 100 + x100 - 1) / x100;
+    if (debug_flags() & 33554432) {
+        i64 rpw = (total + LEAN_WAVES - 1) / LEAN_WAVES;
+        rpw = rpw > PIPE_MAX_ROWS ? PIPE_MAX_ROWS : (rpw < 1 ? 1 : rpw);
+        waves = (total + rpw - 1) / rpw;
+    }
+    const unsigned grid = (unsigned)((waves + LEAN_WAVES - 1) / LEAN_WAVES);
+    const dim3 g(grid), b(LEAN_THREADS);
+    hipStream_t s = (hipStream_t)stream;
+    if (RA.out_offsets) {
+        if (A.onehot && A.haps) recon_lean_rows_kernel<true, true, true><<<g, b, 0, s>>>(A, RA, M);
+        else if (A.onehot) recon_lean_rows_kernel<true, false, true><<<g, b, 0, s>>>(A, RA, M);
+        else recon_lean_rows_kernel<false, true, true><<<g, b, 0, s>>>(A, RA, M);
+    } else {
+        if (A.onehot && A.haps) recon_lean_rows_kernel<true, true, false><<<g, b, 0, s>>>(A, RA, M);
+        else if (A.onehot) recon_lean_rows_kernel<true, false, false><<<g, b, 0, s>>>(A, RA, M);
+        else recon_lean_rows_kernel<false, true, false><<<g, b, 0, s>>>(A, RA, M);
+    }
+    return check_launch("gvl_reconstruct (lean, pipelined)");
+}
+
+}  // namespace gvli
