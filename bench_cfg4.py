@@ -166,13 +166,23 @@ def measure(args, init_dist=True):
         e1.record(cur); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
 
+
     def bound(fn, *args):
         # the ctypes arguments are built ONCE: built per call (a dozen pointer conversions) the call costs the host ~ 40 us and
         # a 20 us kernel's back-to-back launches measure the host (round 3 and the first round-4 passes reported the painter at
         # 38-54 us = 0.18-0.24 of peak that way; rocprofv3 has its kernel at 21 us)
         return lambda: _lib.check(fn(*args))
 
-    t_recon = timeit(lambda: dev.launch(dbt, slot[1]))
+    # the haplotype kernel three ways: with the rows' chunk plans made ahead (gvl_hap_plan: what the native loader does once per
+    # epoch -- the step's way), making them itself in front of every launch, and without plans (round 4's kernel: every chunk-wave walks its row)
+    plan = dev.hap_plan(dbt)
+    dbt_p = dbt if plan is None else dev.prepare_batch(reg, sh, goi, L, to_rc=rc, hap_plan=plan)
+    t_recon = timeit(bound(lib.gvl_reconstruct, C.byref(dev.c), C.byref(dbt_p.c), C.byref(slot[1]), gdev._stream_ptr()))
+    t_recon_self = timeit(bound(lib.gvl_reconstruct, C.byref(dev.c), C.byref(dbt.c), C.byref(slot[1]), gdev._stream_ptr()))
+    t_plan = None if plan is None else timeit(bound(lib.gvl_hap_plan, C.byref(dev.c), C.byref(dbt.c), gdev._ptr(plan), gdev._stream_ptr()))
+    lib.gvl_set_debug_flags(int(os.environ.get("GVL_DBG", "0") or 0) | 536870912)
+    t_recon_noplan = timeit(bound(lib.gvl_reconstruct, C.byref(dev.c), C.byref(dbt.c), C.byref(slot[1]), gdev._stream_ptr()))
+    lib.gvl_set_debug_flags(-1)
     a, e, v, io, pm = ds._itv[0]
     qs, qe = reg[:, 1].contiguous(), reg[:, 2].contiguous()
     diffs = dev.get_diffs_sparse(goi, q_starts=qs, q_ends=qe)
@@ -238,6 +248,10 @@ def measure(args, init_dist=True):
                          "step_GBps": (hap_bytes + realign_bytes) / (ms_step * 1e-3) / 1e9,
                          "step_frac": (hap_bytes + realign_bytes) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "kernels": {
+                "recon_lean_kernel<long>, chunk plans made ahead (the step's way)": {"ms": t_recon, "algorithmic_bytes": hap_bytes, "frac": hap_bytes / (t_recon * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "recon_lean_kernel<long> behind its own hap_plan_kernel (a stand-alone gvl_reconstruct)": {"ms": t_recon_self, "algorithmic_bytes": hap_bytes, "frac": hap_bytes / (t_recon_self * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "recon_lean_kernel<long> without chunk plans (GVL_DBG 536870912: round 4's kernel)": {"ms": t_recon_noplan, "algorithmic_bytes": hap_bytes, "frac": hap_bytes / (t_recon_noplan * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "hap_plan_kernel (a batch's rows)": {"ms": t_plan},
                 "realign_tracks_kernel": {"ms": t_realign, "algorithmic_bytes": realign_bytes,
                                           "frac": realign_bytes / (t_realign * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "intervals_to_tracks (tiled + per-value)": {"ms": t_paint, "algorithmic_bytes": paint_bytes,

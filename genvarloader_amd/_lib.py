@@ -32,6 +32,8 @@ SYMBOLS = (
     "gvl_pack_reference",
     "gvl_reconstruct",
     "gvl_reconstruct_many",
+    "gvl_hap_plan_bytes",
+    "gvl_hap_plan",
     "gvl_get_diffs_sparse",
     "gvl_hap_offsets",
     "gvl_paint_tracks",
@@ -84,7 +86,7 @@ class GvlBatch(C.Structure):
     _fields_ = [
         ("regions", _vp), ("regions_stride", _i64), ("shifts", _vp), ("geno_offset_idx", _vp),
         ("batch", _i64), ("ploidy", _i64), ("keep", _vp), ("keep_offsets", _vp), ("to_rc", _vp),
-        ("output_length", _i64), ("out_offsets", _vp), ("max_row_len", _i64),
+        ("output_length", _i64), ("out_offsets", _vp), ("max_row_len", _i64), ("hap_plan", _vp),
     ]
 
 
@@ -198,12 +200,14 @@ def load() -> C.CDLL:
         if fn is None:
             raise GvlError(f"{p} does not export {name}")
         if name not in ("gvl_last_error", "gvl_loader_slot_bytes", "gvl_loader_table_bytes", "gvl_tracks_scratch_bytes",
-                        "gvl_ref4_bytes"):
+                        "gvl_ref4_bytes", "gvl_hap_plan_bytes"):
             fn.restype = C.c_int
     lib.gvl_loader_slot_bytes.restype = C.c_int64
     lib.gvl_loader_table_bytes.restype = C.c_int64
     lib.gvl_tracks_scratch_bytes.restype = C.c_int64
     lib.gvl_ref4_bytes.restype = C.c_int64
+    lib.gvl_hap_plan_bytes.restype = C.c_int64
+    lib.gvl_hap_plan_bytes.argtypes = [C.c_int64, C.c_int64]
     lib.gvl_ref4_bytes.argtypes = [C.c_int64]
     lib.gvl_set_tuning.argtypes = [C.c_int32, C.c_int64]
     _LIB = lib

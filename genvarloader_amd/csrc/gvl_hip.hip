@@ -359,6 +359,7 @@ int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
 // 2097152 realignment from intervals never uses its window (every value looked up in the interval list itself)
 // 4194304 tracks are always painted into the scratch track first (no realignment straight from the intervals)
 // 8388608 / 16777216  timing ablations of realign_tracks_kernel (NO output): stop behind the walk / behind the window build
+// 536870912 rows of several chunks go without chunk plans (hap_plan_kernel): every chunk-wave of the lean kernel walks its row itself
 // and 1 / 2 / 4 = timing ablations (no variants / no stores / no loads).
 int g_debug_override = -1;
 int debug_flags() {
@@ -430,10 +431,40 @@ int fill_diff_args(DiffArgs &D, const gvl_static *st, const gvl_batch *bt, const
     return GVL_OK;
 }
 
-}  // namespace gvli
+// Stream-ordered scratch (the painter's work lists, the chunk plans of a stand-alone long-row launch) comes from a pool the LIBRARY owns, one per device (created at the first use on that device):
+// with the device's default pool every call paid a driver allocation (the default release threshold is 0: 25 of the 45 us of a
+// stand-alone painting of BASELINE config 4's batch), and raising THAT pool's threshold would change the allocator for every other
+// hipMallocAsync user of the process.  The library's pools keep up to 256 MiB each across synchronisations.
+hipError_t pool_alloc(void **p, size_t bytes, hipStream_t s) {
+    static std::mutex mu;
+    static hipMemPool_t pools[64] = {nullptr};
+    static bool tried[64] = {false};
+    int dev = 0;
+    hipMemPool_t pool = nullptr;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!tried[dev]) {
+            tried[dev] = true;
+            hipMemPoolProps props;
+            memset(&props, 0, sizeof(props));
+            props.allocType = hipMemAllocationTypePinned;
+            props.location.type = hipMemLocationTypeDevice;
+            props.location.id = dev;
+            hipMemPool_t np = nullptr;
+            if (hipMemPoolCreate(&np, &props) == hipSuccess && np) {
+                uint64_t thr = 256ull << 20;
+                (void)hipMemPoolSetAttribute(np, hipMemPoolAttrReleaseThreshold, &thr);
+                pools[dev] = np;
+            }
+            (void)hipGetLastError();
+        }
+        pool = pools[dev];
+    }
+    if (pool) return hipMallocFromPoolAsync(p, bytes, pool, s);
+    return hipMallocAsync(p, bytes, s);          // (no pool of our own: the device's default pool, untouched)
+}
 
-namespace {
-}  // namespace
+}  // namespace gvli
 
 extern "C" {
 
@@ -610,6 +641,7 @@ static int fill_recon_args(const gvl_static *st, const gvl_batch *bt, const gvl_
     A.grec = (debug_flags() & 16) ? nullptr : st->geno_rec;
     A.srec = (debug_flags() & (64 | 512 | 8)) ? nullptr : st->slot_rec;
     A.ref4 = st->ref4;
+    A.hplan = (const u32 *)bt->hap_plan;
     A.n_geno_offsets = st->n_geno_offsets;
     A.n_contigs = (int)(st->n_contigs < 0 ? 0 : (st->n_contigs > 0x7FFFFFFFll ? 0x7FFFFFFF : st->n_contigs));
     A.regions = bt->regions; A.regions_stride = bt->regions_stride; A.shifts = bt->shifts;
@@ -657,7 +689,7 @@ static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_o
     }
     if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;     // u32 positions in the kernel
     // (2097152 ... 16777216 concern the track kernels only)
-    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 268435456)) == 0;
+    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 268435456 | 536870912)) == 0;
 }
 
 // ragged rows (out_offsets) longer than the pipelined form's 2560 bases: the chunked lean kernel's ragged form (<.., LONG, RAGL>)
@@ -669,7 +701,7 @@ static bool lean_long_rag_eligible(const gvl_static *st, const gvl_batch *bt, co
     const i64 n_rows = bt->batch * bt->ploidy;
     if (n_rows <= 0 || n_rows * chunks > 0x7FFFFFF0ll) return false;
     if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;
-    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 268435456)) == 0;
+    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 268435456 | 536870912)) == 0;
 }
 
 // ---- the pipelined form (gvl_lean_pipe.inc): rows of one chunk, `n` batches of the same shape in ONE grid ----------
@@ -688,7 +720,7 @@ static bool lean_rag_eligible(const gvl_static *st, const gvl_batch *bt, const g
     const i64 n_rows = bt->batch * bt->ploidy;
     if (n_rows <= 0 || n_rows > 0x7FFFFFF0ll) return false;
     if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;
-    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 268435456)) == 0;
+    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 268435456 | 536870912)) == 0;
 }
 static bool lean_pipe_wanted(i64 total_rows, int n_batches = 1) {
     if (debug_flags() & 67108864) return false;
@@ -749,6 +781,39 @@ int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_o
         if (rc) return rc;
     }
     return GVL_OK;
+}
+
+int64_t gvl_hap_plan_bytes(int64_t n_rows, int64_t output_length) {
+    int chunks = 1, chunk_len = 0;
+    if (n_rows <= 0 || output_length <= 2048 || (output_length & 3) || pick_chunk(output_length, &chunks, &chunk_len)) return 0;
+    if (chunks < 2 || chunks > HP_MAX_CHUNKS || chunk_len != LEAN_MAX_TRIPS * TRIP) return 0;
+    return hap_plan_bytes(n_rows, chunks);
+}
+
+int gvl_hap_plan(const gvl_static *st, const gvl_batch *bt, void *plan, void *stream) {
+    if (!st || !bt || !plan) return fail(GVL_ERR_INVALID, "%s", "gvl_hap_plan: NULL argument");
+    if (bt->keep || bt->keep_offsets || bt->out_offsets) return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_hap_plan: fixed-length rows without a keep mask only");
+    if (bt->batch < 0 || bt->ploidy <= 0 || bt->batch * bt->ploidy > 0x7FFFFFF0ll) return fail(GVL_ERR_INVALID, "%s", "gvl_hap_plan: bad batch / ploidy");
+    if (bt->batch == 0) return GVL_OK;
+    if (gvl_hap_plan_bytes(bt->batch * bt->ploidy, bt->output_length) <= 0)
+        return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_hap_plan: rows of 2 .. 512 chunks of 2048 bases (a multiple of 4 bases) only");
+    if (!st->ref_offsets || !st->geno_o_starts || !st->geno_o_stops || !bt->regions || !bt->shifts || !bt->geno_offset_idx || bt->regions_stride < 3)
+        return fail(GVL_ERR_INVALID, "%s", "gvl_hap_plan: NULL/invalid array");
+    ReconArgs A;
+    memset(&A, 0, sizeof(A));
+    A.ref_offsets = (const i64 *)st->ref_offsets; A.alt_offsets = (const i64 *)st->alt_offsets;
+    A.go_starts = (const i64 *)st->geno_o_starts; A.go_stops = (const i64 *)st->geno_o_stops;
+    A.grec = (debug_flags() & 16) ? nullptr : st->geno_rec;       // (without the inline records no chunk is planned: every one flagged)
+    A.n_geno_offsets = st->n_geno_offsets;
+    A.n_contigs = (int)(st->n_contigs < 0 ? 0 : (st->n_contigs > 0x7FFFFFFFll ? 0x7FFFFFFF : st->n_contigs));
+    A.regions = bt->regions; A.regions_stride = bt->regions_stride; A.shifts = bt->shifts;
+    A.geno_offset_idx = (const i64 *)bt->geno_offset_idx;
+    A.fixed_len = bt->output_length;
+    A.n_rows = bt->batch * bt->ploidy; A.ploidy = (int)bt->ploidy; A.ploidy_shift = log2_exact(bt->ploidy);
+    A.dbg = debug_flags();
+    int chunks = 1;
+    if (pick_chunk(bt->output_length, &chunks, &A.chunk_len)) return fail(GVL_ERR_INVALID, "%s", "gvl_hap_plan: too many chunks");
+    return launch_hap_plan(A, chunks, (u32 *)plan, stream);
 }
 
 int gvl_get_reference(const gvl_static *st, const int32_t *regions, int64_t regions_stride,

@@ -8,8 +8,7 @@ namespace {
 }  // namespace
 
 namespace gvli {
-int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
-    LeanArgs A;
+static void fill_lean_args(LeanArgs &A, const ReconArgs &RA, int chunks) {
     memset(&A, 0, sizeof(A));
     A.ref4 = RA.ref4; A.ref_offsets = RA.ref_offsets; A.srec = RA.srec;
     A.regions = RA.regions; A.shifts = RA.shifts; A.geno_offset_idx = RA.geno_offset_idx; A.to_rc = RA.to_rc;
@@ -19,6 +18,22 @@ int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
     A.n_rows = (int)RA.n_rows; A.n_contigs = RA.n_contigs; A.regions_stride = (int)RA.regions_stride;
     A.ploidy_shift = RA.ploidy_shift; A.ploidy = RA.ploidy; A.L = (int)RA.fixed_len; A.dbg = RA.dbg;
     A.chunks = chunks;
+}
+
+// The chunk plans of a batch's rows (hap_plan_kernel; rows of 2 .. HP_MAX_CHUNKS chunks, fixed length): `plan` holds
+// hap_plan_bytes(rows, chunks) bytes.  gvl_hap_plan's launch -- the native loader makes every row's plan of an epoch with it -- and
+// launch_lean's own when the batch comes without plans.
+int launch_hap_plan(const ReconArgs &RA, int chunks, u32 *plan, void *stream) {
+    LeanArgs A;
+    fill_lean_args(A, RA, chunks);
+    if (A.n_rows <= 0) return GVL_OK;
+    hap_plan_kernel<<<dim3((unsigned)((A.n_rows + LEAN_WAVES - 1) / LEAN_WAVES)), dim3(LEAN_THREADS), 0, (hipStream_t)stream>>>(A, plan);
+    return check_launch("gvl_hap_plan");
+}
+
+int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
+    LeanArgs A;
+    fill_lean_args(A, RA, chunks);
     // rows of several chunks: a wave takes `sub` consecutive chunks, the second and later ones resume the first one's walk.
     // 2 by default -- BASELINE config 4's 256 rows x 64 chunks are then 8 192 waves, every wave slot of the part once;
     // gvl_set_tuning(GVL_TUNE_LEAN_SUB) overrides (1 = every chunk its own wave and its own walk)
@@ -37,9 +52,25 @@ int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
         else if (A.onehot) recon_lean_kernel<true, false, true, true><<<g, b, 0, s>>>(A, RA);
         else recon_lean_kernel<false, true, true, true><<<g, b, 0, s>>>(A, RA);
     } else if (chunks > 1) {
+        // the rows' chunk plans: the caller's (gvl_batch.hap_plan: made once per epoch by the native loader), or made here, in
+        // stream-ordered scratch, in front of the kernel (GVL_DBG & 536870912: none -- every chunk-wave walks its row)
+        A.hplan = RA.hplan;
+        u32 *scratch = nullptr;
+        if (!A.hplan && chunks <= HP_MAX_CHUNKS && !(debug_flags() & 536870912)) {
+            if (pool_alloc((void **)&scratch, (size_t)hap_plan_bytes(A.n_rows, chunks), s) == hipSuccess && scratch) {
+                const int rc = launch_hap_plan(RA, chunks, scratch, stream);
+                if (rc) { (void)hipFreeAsync(scratch, s); return rc; }
+                A.hplan = scratch;
+            } else {
+                (void)hipGetLastError();
+                scratch = nullptr;
+            }
+        }
+        if (debug_flags() & 536870912) A.hplan = nullptr;
         if (A.onehot && A.haps) recon_lean_kernel<true, true, true><<<g, b, 0, s>>>(A, RA);
         else if (A.onehot) recon_lean_kernel<true, false, true><<<g, b, 0, s>>>(A, RA);
         else recon_lean_kernel<false, true, true><<<g, b, 0, s>>>(A, RA);
+        if (scratch) (void)hipFreeAsync(scratch, s);
     } else {
         if (A.onehot && A.haps) recon_lean_kernel<true, true, false><<<g, b, xl, s>>>(A, RA);
         else if (A.onehot) recon_lean_kernel<true, false, false><<<g, b, xl, s>>>(A, RA);

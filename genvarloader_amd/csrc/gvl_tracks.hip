@@ -85,38 +85,6 @@ static int paint_launch(const int64_t *offset_idxs, const int32_t *starts, int64
     }
     return check_launch("gvl_intervals_to_tracks");
 }
-// The painter's stream-ordered scratch comes from a pool the LIBRARY owns, one per device (created at the first use on that device):
-// with the device's default pool every call paid a driver allocation (the default release threshold is 0: 25 of the 45 us of a
-// stand-alone painting of BASELINE config 4's batch), and raising THAT pool's threshold would change the allocator for every other
-// hipMallocAsync user of the process.  The library's pools keep up to 256 MiB each across synchronisations.
-static hipError_t paint_alloc(void **p, size_t bytes, hipStream_t s) {
-    static std::mutex mu;
-    static hipMemPool_t pools[64] = {nullptr};
-    static bool tried[64] = {false};
-    int dev = 0;
-    hipMemPool_t pool = nullptr;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!tried[dev]) {
-            tried[dev] = true;
-            hipMemPoolProps props;
-            memset(&props, 0, sizeof(props));
-            props.allocType = hipMemAllocationTypePinned;
-            props.location.type = hipMemLocationTypeDevice;
-            props.location.id = dev;
-            hipMemPool_t np = nullptr;
-            if (hipMemPoolCreate(&np, &props) == hipSuccess && np) {
-                uint64_t thr = 256ull << 20;
-                (void)hipMemPoolSetAttribute(np, hipMemPoolAttrReleaseThreshold, &thr);
-                pools[dev] = np;
-            }
-            (void)hipGetLastError();
-        }
-        pool = pools[dev];
-    }
-    if (pool) return hipMallocFromPoolAsync(p, bytes, pool, s);
-    return hipMallocAsync(p, bytes, s);          // (no pool of our own: the device's default pool, untouched)
-}
 static bool paint_can_tile(const int32_t *pmax, int64_t max_row_len) {
     return pmax && max_row_len < 0x7FFFFF00ll && (max_row_len + 2047) / 2048 <= 0x7FFFFFFFll / 4;
 }
@@ -137,7 +105,7 @@ int gvl_intervals_to_tracks(const int64_t *offset_idxs, const int32_t *starts, i
     int *scratch = nullptr;
     if (!itv_pmax_ends && n_intervals > 0) {
         // no precomputed prefix maxima: build them for the queried lists in stream-ordered scratch
-        if (paint_alloc((void **)&scratch, (size_t)n_intervals * sizeof(int), s) != hipSuccess) {
+        if (pool_alloc((void **)&scratch, (size_t)n_intervals * sizeof(int), s) != hipSuccess) {
             (void)hipGetLastError();
             return fail(GVL_ERR_HIP, "%s", "gvl_intervals_to_tracks: scratch allocation failed (pass itv_pmax_ends)");
         }
@@ -152,7 +120,7 @@ int gvl_intervals_to_tracks(const int64_t *offset_idxs, const int32_t *starts, i
     const i64 n_chunks = (max_row_len + 2047) / 2048;
     PaintTodo *todo = nullptr;
     if (paint_can_tile(itv_pmax_ends, max_row_len) &&
-        paint_alloc((void **)&todo, (size_t)(n_queries * n_chunks) * sizeof(PaintTodo), s) != hipSuccess) {
+        pool_alloc((void **)&todo, (size_t)(n_queries * n_chunks) * sizeof(PaintTodo), s) != hipSuccess) {
         (void)hipGetLastError();
         todo = nullptr;
     }
@@ -188,7 +156,7 @@ int gvl_paint_tracks(const gvl_track_set *ts, const int64_t *offset_idxs, const 
     // malloc + free pair cost more than the painting itself)
     const bool complete = ts->tile_complete != 0 && X.offsets && !(debug_flags() & (8192 | 1024));
     if (!complete && paint_can_tile(ts->itv_pmax_ends, max_row_len) &&
-        paint_alloc((void **)&todo, (size_t)(n_queries * n_chunks) * sizeof(PaintTodo), s) != hipSuccess) {
+        pool_alloc((void **)&todo, (size_t)(n_queries * n_chunks) * sizeof(PaintTodo), s) != hipSuccess) {
         (void)hipGetLastError();
         todo = nullptr;
     }

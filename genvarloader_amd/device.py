@@ -179,7 +179,7 @@ class HapsDevice:
 
     # ------------------------------------------------------------------ batches
     def prepare_batch(self, regions, shifts, geno_offset_idx, output_length, keep=None,
-                      keep_offsets=None, to_rc=None, out_offsets=None, max_row_len=None) -> DeviceBatch:
+                      keep_offsets=None, to_rc=None, out_offsets=None, max_row_len=None, hap_plan=None) -> DeviceBatch:
         d = self.device
         reg = _dev(regions, torch.int32, d)
         goi = _dev(geno_offset_idx, torch.int64, d)
@@ -212,8 +212,22 @@ class HapsDevice:
             keep_offsets=None if ko is None else ko.data_ptr(),
             to_rc=None if rc is None else rc.data_ptr(), output_length=output_length,
             out_offsets=None if oo is None else oo.data_ptr(), max_row_len=mrl,
+            hap_plan=None if hap_plan is None else hap_plan.data_ptr(),
         )
-        return DeviceBatch(reg, sh, goi, kp, ko, rc, oo, output_length, mrl, c)
+        bt = DeviceBatch(reg, sh, goi, kp, ko, rc, oo, output_length, mrl, c)
+        bt._hap_plan = hap_plan          # (kept alive with the batch)
+        return bt
+
+    def hap_plan(self, bt: DeviceBatch) -> torch.Tensor | None:
+        """``gvl_hap_plan``: the chunk plans of a batch's long fixed-length rows (one walk per row; pass the result to
+        :meth:`prepare_batch` as ``hap_plan`` for the same request arrays).  None when rows of this length are not planned."""
+        n = int(self.lib.gvl_hap_plan_bytes(C.c_int64(bt.n_rows), C.c_int64(bt.output_length)))
+        if n <= 0:
+            return None
+        plan = torch.empty(n, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.gvl_hap_plan(C.byref(self.c), C.byref(bt.c), _ptr(plan), _stream_ptr()))
+        return plan
 
     def hap_offsets(self, bt: DeviceBatch, want_diffs=False):
         """Fused-entry sizing (ffi/mod.rs:769-811) on the device.

@@ -145,6 +145,9 @@ typedef struct gvl_batch {
                                       k * output_length. */
     int64_t max_row_len;           /* host hint: upper bound of any row's length
                                       (fixed mode: ignored, output_length is used) */
+    const void *hap_plan;          /* nullable: the chunk plans of THESE rows (gvl_hap_plan over exactly these
+                                      request arrays; fixed-length rows longer than 2048 bases).  NULL: the launch
+                                      makes them itself, in stream-ordered scratch */
 } gvl_batch;
 
 /* Outputs; any of the data pointers may be NULL (that output is skipped), but
@@ -236,6 +239,18 @@ int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *ou
 #define GVL_MANY_MAX 16
 int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_out *outs,
                          int32_t n, void *stream);
+
+/* Chunk plans of long rows (BASELINE config 4: 131 072 bases = 64 chunks of 2048).  The lean kernel gives every pair of chunks
+ * of a row its own wave; with a plan such a wave finds where its window starts and which applied variants touch its chunk in two
+ * reads, without one it replays the row's walk (src/reconstruct/mod.rs:85-198) up to its chunk.  gvl_hap_plan walks every row of
+ * `bt` ONCE (bt->output_length = the fixed row length; regions / shifts / geno_offset_idx of batch * ploidy rows; no keep mask)
+ * into `plan`, gvl_hap_plan_bytes(batch * ploidy, output_length) bytes of device memory; row k's plans are the k-th
+ * gvl_hap_plan_bytes(1, output_length) bytes, so a plan made over a whole epoch's request table is handed to the epoch's batches
+ * as pointers into it (gvl_batch.hap_plan; the native loader does exactly that).  Results never depend on it: a chunk the plan
+ * cannot express is flagged and walks its row as before.  gvl_hap_plan_bytes is 0 for rows that are not planned (one chunk, or
+ * more than 512). */
+int64_t gvl_hap_plan_bytes(int64_t n_rows, int64_t output_length);
+int gvl_hap_plan(const gvl_static *st, const gvl_batch *bt, void *plan, void *stream);
 
 /* Per-row length deltas.  Replaces get_diffs_sparse (src/ffi/mod.rs:143-185 ->
  * src/genotypes/mod.rs:15-125).  Query mode iff q_starts, q_ends and st->v_starts

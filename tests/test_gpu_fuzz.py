@@ -92,8 +92,8 @@ def test_fuzz_lean_kernel_pipelined(dbg):
     _run("fuzz_lean.py", 400, 204 + (dbg >> 15) % 7, dbg=dbg)
 
 
-@pytest.mark.parametrize("dbg,sub", [(0, 2), (32768, 2), (65536, 2), (0, 1), (0, 4)],
-                         ids=["default", "every-chunk-solo", "rereads", "one-chunk-per-wave", "four-chunks-per-wave"])
+@pytest.mark.parametrize("dbg,sub", [(0, 2), (32768, 2), (65536, 2), (0, 1), (0, 4), (536870912, 2), (536870912, 1)],
+                         ids=["default", "every-chunk-solo", "rereads", "one-chunk-per-wave", "four-chunks-per-wave", "no-chunk-plans", "no-chunk-plans-one-chunk-per-wave"])
 def test_fuzz_lean_kernel_long_rows(dbg, sub):
     """FUZZ_LONG=1: rows of 2 052 ... 40 000 bases = the lean kernel's chunked form (BASELINE config 4's haplotype kernel),
     with 1 / 2 / 4 consecutive chunks per wave (FUZZ_SUB -> gvl_set_tuning)."""

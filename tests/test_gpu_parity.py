@@ -46,7 +46,9 @@ KERNEL_PATHS = {0: "default", 8: "scalar-walk", 64: "csr-inline-records", 80: "c
                 # the lean kernel's pipelined form (gvl_lean_pipe.inc) on ONE workgroup -- a wave takes every fourth row of the
                 # batch, many rows per wave --; with every row / every indel row deferred to the wave's end; and never
                 33554432: "lean-pipelined", 33554432 + 32768: "lean-pipelined-defers-every-row",
-                33554432 + 65536: "lean-pipelined-defers-indel-rows", 67108864: "no-lean-pipeline"}
+                33554432 + 65536: "lean-pipelined-defers-indel-rows", 67108864: "no-lean-pipeline",
+                # rows of several chunks without chunk plans (hap_plan_kernel): every chunk-wave walks its row itself, as in round 4
+                536870912: "no-chunk-plans"}
 
 
 @pytest.fixture(params=sorted(KERNEL_PATHS), ids=[KERNEL_PATHS[k] for k in sorted(KERNEL_PATHS)])
@@ -415,6 +417,46 @@ def test_ragged_mode(gpu, oracle, seed, kpath):
     np.testing.assert_array_equal(diffs.cpu().numpy(), exp_d)
     np.testing.assert_array_equal(oo.cpu().numpy(), exp_off)
     assert tm.cpu().tolist() == [int(exp_off[-1]), int(np.diff(exp_off).max())]
+
+
+def test_long_rows_with_the_callers_chunk_plans(gpu, oracle):
+    """gvl_hap_plan: the chunk plans of long rows made ONCE over a table of request rows (what the native loader does per epoch) and
+    handed to launches over slices of that table as pointers into it (gvl_batch.hap_plan) == the launch's own plans == no plans ==
+    the oracle.  Rows of 20 chunks, dense enough that some chunks hold more than HP_ENT = 8 entries (flagged: their waves walk the
+    row), insertions of hundreds of bases across chunk borders, shifts, windows over the contigs' edges."""
+    from genvarloader_amd import _lib
+
+    lib = _lib.load()
+    for seed, L, kw in ((3, 40_960, dict(density=1 / 40, indel_frac=0.3, max_indel=300, edge_frac=0.2)),
+                        (4, 40_004, dict(density=1 / 9, indel_frac=0.6, max_indel=30, edge_frac=0.0)),
+                        (5, 131_072, dict(density=1 / 300, indel_frac=0.15, edge_frac=0.0))):
+        st, bt = _synth(seed, (1 << 19, 300_000), 12, L, rc_frac=0.5, random_shifts=True, **kw)
+        dev = make_dev(gpu, st, bt)
+        exp, exp_off, exp_oh = oracle_fused(oracle, st, bt, onehot=True)
+        full = dev.prepare_batch(bt.regions, bt.shifts, bt.geno_offset_idx, L, to_rc=bt.to_rc)
+        plan = dev.hap_plan(full)
+        per_row = int(lib.gvl_hap_plan_bytes(1, L))
+        assert plan is not None and plan.numel() == per_row * bt.n_windows
+        hdr = plan.view(gpu.torch.int32).view(bt.n_windows, -1, 4 + 8 * 8)[:, :, 1].cpu().numpy()
+        planned = (hdr & 0x100) != 0
+        assert planned.any() and (seed != 4 or (~planned).any())
+        P = 2
+        for a, b in ((0, 5), (5, 12)):                      # two launches over slices of the table
+            sl = dev.prepare_batch(bt.regions[a:b], bt.shifts[a:b], bt.geno_offset_idx[a:b], L, to_rc=bt.to_rc[a * P:b * P],
+                                   hap_plan=plan[a * P * per_row:])
+            out, oc = dev.alloc_output(sl, (b - a) * P * L, haps=True, onehot=True)
+            dev.launch(sl, oc)
+            gpu.torch.cuda.synchronize()
+            np.testing.assert_array_equal(out.haps.cpu().numpy(), exp[a * P * L:b * P * L], err_msg=f"seed {seed} rows {a}:{b}")
+            np.testing.assert_array_equal(out.onehot.cpu().numpy(), exp_oh[a * P * L:b * P * L], err_msg=f"seed {seed} rows {a}:{b}")
+        for flags in (0, 536870912):                        # the launch's own plans; none
+            lib.gvl_set_debug_flags(flags)
+            try:
+                out = dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, L, to_rc=bt.to_rc, haps=True, onehot=True)
+                np.testing.assert_array_equal(out.haps.cpu().numpy(), exp, err_msg=f"seed {seed} flags {flags}")
+                np.testing.assert_array_equal(out.onehot.cpu().numpy(), exp_oh, err_msg=f"seed {seed} flags {flags}")
+            finally:
+                lib.gvl_set_debug_flags(-1)
 
 
 @pytest.mark.parametrize("outputs", ["onehot+haps", "onehot", "haps"])
