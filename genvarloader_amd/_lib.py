@@ -121,7 +121,7 @@ class GvlLoaderConfig(C.Structure):
 
 
 LOADER_SLOT_PARTS = 12       # GVL_LOADER_SLOT_PARTS
-LOADER_TABLE_PARTS = 8       # GVL_LOADER_TABLE_PARTS
+LOADER_TABLE_PARTS = 9       # GVL_LOADER_TABLE_PARTS
 
 
 class GvlLoaderBatch(C.Structure):

@@ -1054,6 +1054,7 @@ struct gvl_loader {
     int G, n_sets;
     int2 *e_plan_hdr; i32x4 *e_plan_ent;    // tracks, rows of several chunks: the rows' plans (track_plan_kernel) of the epoch (or NULL)
     int e_chunks;
+    u8 *e_hplan; i64 e_hplan_row;           // rows of several chunks: the epoch's chunk plans (gvl_hap_plan over the whole table; or NULL) and the bytes of one row's
     i64 *e_track_offsets, *e_out_offsets;   // tracks: every batch's scratch-track offsets ((bs + 1) per batch) and the k * L output offsets
     u64 counter;                  // the running epoch's number + 1 (keys the random draws together with cfg.seed)
     bool epoch_set;               // gvl_loader_set_epoch named the next epoch (else: epochs started so far)
@@ -1093,6 +1094,16 @@ static i64 loader_track_plan_bytes(const gvl_loader_config *cfg, i64 n) {
     return b <= cap ? b : 0;
 }
 
+// the haplotype kernel's chunk plans of an epoch's rows (fixed-length rows of several chunks the lean kernel takes; under the same
+// cap as the track plans: an epoch whose plans would not fit makes them per launch instead)
+static i64 loader_hap_plan_bytes(const gvl_loader_config *cfg, i64 n) {
+    if (cfg->output_length <= 2048 || cfg->want_annot || (cfg->want_onehot && cfg->onehot_layout != GVL_ONEHOT_LC)) return 0;
+    const i64 cap_t = tune(GVL_TUNE_TRACK_PLAN_MAX_MB);
+    const i64 cap = (cap_t > 0 ? cap_t : 512) << 20;
+    const i64 b = gvl_hap_plan_bytes(n * cfg->ploidy, cfg->output_length);
+    return b <= cap ? b : 0;
+}
+
 static bool loader_ragged(const gvl_loader_config *c) { return c->output_length == -1; }
 // bases per row a slot reserves: the fixed length, or the ragged bound
 static i64 loader_row_cap(const gvl_loader_config *c) { return loader_ragged(c) ? c->max_row_len : c->output_length; }
@@ -1121,7 +1132,7 @@ int64_t gvl_loader_table_bytes(const gvl_loader_config *cfg, int64_t n, int64_t 
     const bool tr = cfg->n_tracks > 0;
     const i64 sizes[GVL_LOADER_TABLE_PARTS] = {16 * n, 8 * n * P, 4 * n * P, n * P, 8 * nb,
                                                tr ? 8 * (n + nb) : 0, tr ? 8 * (cfg->batch_size * P + 1) : 0,
-                                               tr ? loader_track_plan_bytes(cfg, n) : 0};
+                                               tr ? loader_track_plan_bytes(cfg, n) : 0, loader_hap_plan_bytes(cfg, n)};
     i64 off = 0;
     for (int i = 0; i < GVL_LOADER_TABLE_PARTS; ++i) {
         if (part_offsets) part_offsets[i] = off;
@@ -1242,6 +1253,15 @@ static int loader_fill_table(gvl_loader *ld, const int64_t *order, i64 n, int32_
                                        c.rc_neg, c.deterministic, c.output_length < 0 ? 0 : c.output_length, c.seed, counter,
                                        t_regions, (int64_t *)t_goi, t_to_rc, t_shifts, s);
     if (rc) return rc;
+    if (po[9] > po[8] && !(debug_flags() & 536870912)) {
+        // rows of several chunks: every row's chunk plans, once per epoch (the batches' launches get pointers into them)
+        gvl_batch gb;
+        memset(&gb, 0, sizeof(gb));
+        gb.regions = t_regions; gb.regions_stride = 4; gb.shifts = t_shifts; gb.geno_offset_idx = (const int64_t *)t_goi;
+        gb.batch = n_used; gb.ploidy = c.ploidy; gb.output_length = c.output_length; gb.max_row_len = c.output_length;
+        const int rc_p = gvl_hap_plan(&ld->st, &gb, base + po[8], s);
+        if (rc_p) return rc_p;
+    }
     if (c.n_tracks > 0 && c.track_seed_mode == 1) {
         const i64 grid = (n_batches * WAVE + 255) / 256;
         batch_seeds_kernel<<<dim3((unsigned)grid), dim3(256), 0, s>>>((const i64 *)order, n_used, bs, n_batches, c.deterministic,
@@ -1358,6 +1378,8 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
         ld->e_seeds = (u64 *)(base + po[4]);
         ld->e_track_offsets = (i64 *)(base + po[5]);
         ld->e_out_offsets = (i64 *)(base + po[6]);
+        ld->e_hplan = (loader_hap_plan_bytes(&c, n) > 0 && !(debug_flags() & 536870912)) ? base + po[8] : nullptr;
+        ld->e_hplan_row = gvl_hap_plan_bytes(1, c.output_length);
         const i64 wsb = c.n_tracks > 0 ? loader_track_plan_bytes(&c, n) : 0;
         int cl = 0;
         ld->e_chunks = 1;
@@ -1441,6 +1463,7 @@ static int loader_submit(gvl_loader *ld, i64 g) {
         bt.regions = o.regions; bt.regions_stride = 4; bt.shifts = o.shifts; bt.geno_offset_idx = o.geno_offset_idx;
         bt.batch = o.batch; bt.ploidy = c.ploidy; bt.to_rc = c.rc_neg ? o.to_rc : nullptr;
         bt.output_length = c.output_length; bt.max_row_len = loader_row_cap(&c);
+        bt.hap_plan = ld->e_hplan ? ld->e_hplan + j * c.batch_size * c.ploidy * ld->e_hplan_row : nullptr;
         gvl_out &oc = ocs[m];
         memset(&oc, 0, sizeof(oc));
         oc.haps = o.haps; oc.onehot = o.onehot; oc.onehot_layout = c.onehot_layout; oc.out_offsets = o.out_offsets;

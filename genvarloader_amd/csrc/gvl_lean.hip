@@ -52,25 +52,14 @@ int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
         else if (A.onehot) recon_lean_kernel<true, false, true, true><<<g, b, 0, s>>>(A, RA);
         else recon_lean_kernel<false, true, true, true><<<g, b, 0, s>>>(A, RA);
     } else if (chunks > 1) {
-        // the rows' chunk plans: the caller's (gvl_batch.hap_plan: made once per epoch by the native loader), or made here, in
-        // stream-ordered scratch, in front of the kernel (GVL_DBG & 536870912: none -- every chunk-wave walks its row)
-        A.hplan = RA.hplan;
-        u32 *scratch = nullptr;
-        if (!A.hplan && chunks <= HP_MAX_CHUNKS && !(debug_flags() & 536870912)) {
-            if (pool_alloc((void **)&scratch, (size_t)hap_plan_bytes(A.n_rows, chunks), s) == hipSuccess && scratch) {
-                const int rc = launch_hap_plan(RA, chunks, scratch, stream);
-                if (rc) { (void)hipFreeAsync(scratch, s); return rc; }
-                A.hplan = scratch;
-            } else {
-                (void)hipGetLastError();
-                scratch = nullptr;
-            }
-        }
-        if (debug_flags() & 536870912) A.hplan = nullptr;
+        // the rows' chunk plans, when the caller brings them (gvl_batch.hap_plan: made once per epoch by the native loader; GVL_DBG &
+        // 536870912: ignored).  A stand-alone launch does NOT make them for itself: measured (profiles/r05_cfg4_plans.txt), the
+        // planner in front of every launch costs more than the walks it saves (7 us + a stream-ordered allocation against 2.7 us)
+        A.hplan = (debug_flags() & 536870912) ? nullptr : RA.hplan;
+        if (chunks > HP_MAX_CHUNKS) A.hplan = nullptr;
         if (A.onehot && A.haps) recon_lean_kernel<true, true, true><<<g, b, 0, s>>>(A, RA);
         else if (A.onehot) recon_lean_kernel<true, false, true><<<g, b, 0, s>>>(A, RA);
         else recon_lean_kernel<false, true, true><<<g, b, 0, s>>>(A, RA);
-        if (scratch) (void)hipFreeAsync(scratch, s);
     } else {
         if (A.onehot && A.haps) recon_lean_kernel<true, true, false><<<g, b, xl, s>>>(A, RA);
         else if (A.onehot) recon_lean_kernel<true, false, false><<<g, b, xl, s>>>(A, RA);

@@ -146,8 +146,8 @@ typedef struct gvl_batch {
     int64_t max_row_len;           /* host hint: upper bound of any row's length
                                       (fixed mode: ignored, output_length is used) */
     const void *hap_plan;          /* nullable: the chunk plans of THESE rows (gvl_hap_plan over exactly these
-                                      request arrays; fixed-length rows longer than 2048 bases).  NULL: the launch
-                                      makes them itself, in stream-ordered scratch */
+                                      request arrays; fixed-length rows longer than 2048 bases).  NULL: every
+                                      chunk-wave of the launch walks its row itself */
 } gvl_batch;
 
 /* Outputs; any of the data pointers may be NULL (that output is skipped), but
@@ -520,7 +520,7 @@ typedef struct gvl_loader_batch {
  * geno_offset_idx, shifts, to_rc, out_offsets, annot_v_idxs, annot_ref_pos, tracks, track scratch,
  * sizes), for a full batch.  (Parts 2-5 are unused since the request arrays live in the epoch table.) */
 #define GVL_LOADER_SLOT_PARTS 12
-#define GVL_LOADER_TABLE_PARTS 8
+#define GVL_LOADER_TABLE_PARTS 9
 int64_t gvl_loader_slot_bytes(const gvl_loader_config *cfg, int64_t *part_offsets);
 /* `st` is copied; the device arrays it points to must outlive the loader. */
 int gvl_loader_create(const gvl_static *st, const gvl_loader_config *cfg, gvl_loader **out);
@@ -563,7 +563,9 @@ int gvl_loader_set_epoch(gvl_loader *ld, uint64_t epoch);
  * seeds u64 (ceil(n / batch_size)), and -- with tracks -- every batch's scratch-track offsets i64 (batch_size + 1
  * per batch), the k * output_length row offsets i64 (batch_size * ploidy + 1) the realignment reads and, for rows of several
  * 2048-value chunks, the rows' realignment plans (the row's entries, 2 KB per row, + 8 B per (row, chunk); left out when an
- * epoch's would exceed GVL_TRACK_PLAN_MAX_MB, default 512)).  The table is the
+ * epoch's would exceed gvl_set_tuning(GVL_TUNE_TRACK_PLAN_MAX_MB), default 512); and, last, for fixed-length rows of several
+ * 2048-base chunks the haplotype kernel's chunk plans of every row (gvl_hap_plan_bytes; same cap: an epoch without them plans per
+ * launch)).  The table is the
  * caller's device memory (256-byte aligned) and must stay alive until the epoch ends; batch j's
  * request arrays are rows [j * batch_size, ...) of its parts. */
 int64_t gvl_loader_table_bytes(const gvl_loader_config *cfg, int64_t n, int64_t *part_offsets);
