@@ -34,11 +34,16 @@ int launch_hap_plan(const ReconArgs &RA, int chunks, u32 *plan, void *stream) {
 int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
     LeanArgs A;
     fill_lean_args(A, RA, chunks);
-    // rows of several chunks: a wave takes `sub` consecutive chunks, the second and later ones resume the first one's walk.
-    // 2 by default -- BASELINE config 4's 256 rows x 64 chunks are then 8 192 waves, every wave slot of the part once;
-    // gvl_set_tuning(GVL_TUNE_LEAN_SUB) overrides (1 = every chunk its own wave and its own walk)
+    // the rows' chunk plans, when the caller brings them (gvl_batch.hap_plan: made once per epoch by the native loader; GVL_DBG &
+    // 536870912: ignored).  A stand-alone launch does NOT make them for itself: measured (profiles/r05_cfg4_plans.txt), the
+    // planner in front of every launch costs more than the walks it saves (7 us + a stream-ordered allocation against 2.7 us)
+    if (chunks > 1 && !RA.out_offsets && chunks <= HP_MAX_CHUNKS && !(debug_flags() & 536870912)) A.hplan = RA.hplan;
+    // rows of several chunks: a wave takes `sub` consecutive chunks.  Without plans 2 -- the second chunk resumes the first one's
+    // walk; BASELINE config 4's 256 rows x 64 chunks are then 8 192 waves, every wave slot of the part once --, with plans 1: there
+    // is no walk to share, and 16 384 short waves start their reads under each other's stores (34.9 against 37.6 us,
+    // profiles/r05_cfg4_plans.txt).  gvl_set_tuning(GVL_TUNE_LEAN_SUB) overrides.
     const i64 sub_t = tune(GVL_TUNE_LEAN_SUB);
-    A.sub = chunks > 1 ? (sub_t > 0 ? (int)(sub_t > 64 ? 64 : sub_t) : 2) : 1;
+    A.sub = chunks > 1 ? (sub_t > 0 ? (int)(sub_t > 64 ? 64 : sub_t) : (A.hplan ? 1 : 2)) : 1;
     const i64 per_row = (chunks + A.sub - 1) / A.sub;
     const unsigned grid = (unsigned)(((i64)A.n_rows * per_row + LEAN_WAVES - 1) / LEAN_WAVES);
     const dim3 g(grid), b(LEAN_THREADS);
@@ -52,11 +57,6 @@ int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
         else if (A.onehot) recon_lean_kernel<true, false, true, true><<<g, b, 0, s>>>(A, RA);
         else recon_lean_kernel<false, true, true, true><<<g, b, 0, s>>>(A, RA);
     } else if (chunks > 1) {
-        // the rows' chunk plans, when the caller brings them (gvl_batch.hap_plan: made once per epoch by the native loader; GVL_DBG &
-        // 536870912: ignored).  A stand-alone launch does NOT make them for itself: measured (profiles/r05_cfg4_plans.txt), the
-        // planner in front of every launch costs more than the walks it saves (7 us + a stream-ordered allocation against 2.7 us)
-        A.hplan = (debug_flags() & 536870912) ? nullptr : RA.hplan;
-        if (chunks > HP_MAX_CHUNKS) A.hplan = nullptr;
         if (A.onehot && A.haps) recon_lean_kernel<true, true, true><<<g, b, 0, s>>>(A, RA);
         else if (A.onehot) recon_lean_kernel<true, false, true><<<g, b, 0, s>>>(A, RA);
         else recon_lean_kernel<false, true, true><<<g, b, 0, s>>>(A, RA);
