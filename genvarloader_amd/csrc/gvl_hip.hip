@@ -359,6 +359,8 @@ int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
 // 2097152 realignment from intervals never uses its window (every value looked up in the interval list itself)
 // 4194304 tracks are always painted into the scratch track first (no realignment straight from the intervals)
 // 8388608 / 16777216  timing ablations of realign_tracks_kernel (NO output): stop behind the walk / behind the window build
+// 1073741824 round 4's routing of the other output modes: channel-major one-hot, keep masks, annotations and get_reference run the
+//        all-purpose kernel (their lean forms are this round's)
 // 536870912 rows of several chunks go without chunk plans (hap_plan_kernel): every chunk-wave of the lean kernel walks its row itself
 // and 1 / 2 / 4 = timing ablations (no variants / no stores / no loads).
 int g_debug_override = -1;
@@ -642,6 +644,7 @@ static int fill_recon_args(const gvl_static *st, const gvl_batch *bt, const gvl_
     A.srec = (debug_flags() & (64 | 512 | 8)) ? nullptr : st->slot_rec;
     A.ref4 = st->ref4;
     A.hplan = (const u32 *)bt->hap_plan;
+    A.oh_cl = (out->onehot && out->onehot_layout == GVL_ONEHOT_CL) ? 1u : 0u;
     A.n_geno_offsets = st->n_geno_offsets;
     A.n_contigs = (int)(st->n_contigs < 0 ? 0 : (st->n_contigs > 0x7FFFFFFFll ? 0x7FFFFFFF : st->n_contigs));
     A.regions = bt->regions; A.regions_stride = bt->regions_stride; A.shifts = bt->shifts;
@@ -676,7 +679,9 @@ static int fill_recon_args(const gvl_static *st, const gvl_batch *bt, const gvl_
 // into 2048-base chunks): one wave per chunk, variants from the CSR's inline records (LONG).
 static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_out *out, int chunks, int chunk_len) {
     if (!st->ref4 || (!out->onehot && !out->haps)) return false;
-    if (out->annot_v_idxs || out->annot_ref_pos || (out->onehot && out->onehot_layout != GVL_ONEHOT_LC)) return false;
+    if (out->annot_v_idxs || out->annot_ref_pos) return false;
+    // (channel-major one-hot: rows of one chunk only, and only the pipelined kernel has the form -- see lean_wants_pipe)
+    if (out->onehot && out->onehot_layout != GVL_ONEHOT_LC && (chunks != 1 || (debug_flags() & (67108864 | 1073741824)))) return false;
     if (bt->out_offsets || bt->keep || bt->keep_offsets) return false;
     if (bt->output_length <= 0 || (bt->output_length & 3)) return false;
     const i64 n_rows = bt->batch * bt->ploidy;
@@ -689,7 +694,7 @@ static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_o
     }
     if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;     // u32 positions in the kernel
     // (2097152 ... 16777216 concern the track kernels only)
-    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 268435456 | 536870912)) == 0;
+    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 268435456 | 536870912 | 1073741824)) == 0;
 }
 
 // ragged rows (out_offsets) longer than the pipelined form's 2560 bases: the chunked lean kernel's ragged form (<.., LONG, RAGL>)
@@ -701,7 +706,7 @@ static bool lean_long_rag_eligible(const gvl_static *st, const gvl_batch *bt, co
     const i64 n_rows = bt->batch * bt->ploidy;
     if (n_rows <= 0 || n_rows * chunks > 0x7FFFFFF0ll) return false;
     if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;
-    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 268435456 | 536870912)) == 0;
+    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 268435456 | 536870912 | 1073741824)) == 0;
 }
 
 // ---- the pipelined form (gvl_lean_pipe.inc): rows of one chunk, `n` batches of the same shape in ONE grid ----------
@@ -720,7 +725,7 @@ static bool lean_rag_eligible(const gvl_static *st, const gvl_batch *bt, const g
     const i64 n_rows = bt->batch * bt->ploidy;
     if (n_rows <= 0 || n_rows > 0x7FFFFFF0ll) return false;
     if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;
-    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 268435456 | 536870912)) == 0;
+    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 268435456 | 536870912 | 1073741824)) == 0;
 }
 static bool lean_pipe_wanted(i64 total_rows, int n_batches = 1) {
     if (debug_flags() & 67108864) return false;
@@ -738,7 +743,8 @@ int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *ou
     const int rc = fill_recon_args(st, bt, out, A, &chunks, &variant);
     if (rc) return rc;
     if (A.n_rows > 0 && lean_eligible(st, bt, out, chunks, A.chunk_len)) {
-        if (chunks == 1 && lean_pipe_wanted(A.n_rows) && lean_pipe_compatible(&A, 1)) return launch_lean_rows(&A, 1, stream, 1);
+        if (chunks == 1 && (lean_pipe_wanted(A.n_rows) || A.oh_cl) && lean_pipe_compatible(&A, 1)) return launch_lean_rows(&A, 1, stream, 1);
+        if (A.oh_cl) return launch_recon(A, chunks, variant, stream);        // (only the pipelined kernel has the channel-major form)
         return launch_lean(A, chunks, stream);
     }
     if (A.n_rows > 0 && !(debug_flags() & 67108864) && lean_rag_eligible(st, bt, out) && lean_pipe_compatible(&A, 1))
@@ -758,7 +764,7 @@ int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_o
     ReconArgs A[GVL_MANY_MAX];
     int chunks[GVL_MANY_MAX], variant[GVL_MANY_MAX];
     bool lean[GVL_MANY_MAX];
-    bool all_one_chunk_lean = n > 0, all_rag = n > 0 && !(debug_flags() & 67108864);
+    bool all_one_chunk_lean = n > 0, all_rag = n > 0 && !(debug_flags() & 67108864), any_cl = false;
     i64 total = 0;
     for (int i = 0; i < n; ++i) {
         chunks[i] = 1; variant[i] = 0;
@@ -767,17 +773,22 @@ int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_o
         lean[i] = A[i].n_rows > 0 && (lean_eligible(st, &bts[i], &outs[i], chunks[i], A[i].chunk_len) ||
                                       (!lean_rag_eligible(st, &bts[i], &outs[i]) && lean_long_rag_eligible(st, &bts[i], &outs[i], chunks[i], A[i].chunk_len)));
         all_one_chunk_lean = all_one_chunk_lean && lean[i] && chunks[i] == 1;
+        any_cl = any_cl || A[i].oh_cl;
         all_rag = all_rag && A[i].n_rows > 0 && lean_rag_eligible(st, &bts[i], &outs[i]);
         total += A[i].n_rows;
     }
-    if (all_one_chunk_lean && lean_pipe_wanted(total, n) && lean_pipe_compatible(A, n)) return launch_lean_rows(A, n, stream, 1);
+    if (all_one_chunk_lean && (lean_pipe_wanted(total, n) || any_cl) && lean_pipe_compatible(A, n)) return launch_lean_rows(A, n, stream, 1);
     if (all_rag && lean_pipe_compatible(A, n)) {
         int min_chunks = chunks[0];             // (the launch reports a row longer than the smallest bound any of its batches gave)
         for (int i = 1; i < n; ++i) min_chunks = chunks[i] < min_chunks ? chunks[i] : min_chunks;
         return launch_lean_rows(A, n, stream, min_chunks);
     }
     for (int i = 0; i < n; ++i) {
-        const int rc = lean[i] ? launch_lean(A[i], chunks[i], stream) : launch_recon(A[i], chunks[i], variant[i], stream);
+        int rc;
+        if (lean[i] && A[i].oh_cl)       // (channel-major one-hot: the pipelined kernel's form, or the all-purpose kernel)
+            rc = lean_pipe_compatible(&A[i], 1) ? launch_lean_rows(&A[i], 1, stream, 1) : launch_recon(A[i], chunks[i], variant[i], stream);
+        else
+            rc = lean[i] ? launch_lean(A[i], chunks[i], stream) : launch_recon(A[i], chunks[i], variant[i], stream);
         if (rc) return rc;
     }
     return GVL_OK;

@@ -19,7 +19,8 @@ bool lean_pipe_compatible(const ReconArgs *RAs, int n) {
         const ReconArgs &R = RAs[i];
         if (R.fixed_len != F.fixed_len || R.ploidy != F.ploidy || R.regions_stride != F.regions_stride ||
             (R.out_offsets != nullptr) != (F.out_offsets != nullptr) ||
-            (R.onehot != nullptr) != (F.onehot != nullptr) || (R.haps != nullptr) != (F.haps != nullptr) || R.dbg != F.dbg)
+            (R.onehot != nullptr) != (F.onehot != nullptr) || (R.haps != nullptr) != (F.haps != nullptr) || R.dbg != F.dbg ||
+            R.oh_cl != F.oh_cl)
             return false;
         if (R.n_rows <= 0 || R.n_rows > F.n_rows || (i + 1 < n && R.n_rows != F.n_rows)) return false;
         total += R.n_rows;
@@ -72,6 +73,9 @@ int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks) 
         if (A.onehot && A.haps) recon_lean_rows_kernel<true, true, true><<<g, b, 0, s>>>(A, RA, M);
         else if (A.onehot) recon_lean_rows_kernel<true, false, true><<<g, b, 0, s>>>(A, RA, M);
         else recon_lean_rows_kernel<false, true, true><<<g, b, 0, s>>>(A, RA, M);
+    } else if (RA.oh_cl) {       // channel-major one-hot (rows, 4, L)
+        if (A.haps) recon_lean_rows_kernel<true, true, false, true><<<g, b, 0, s>>>(A, RA, M);
+        else recon_lean_rows_kernel<true, false, false, true><<<g, b, 0, s>>>(A, RA, M);
     } else {
         if (A.onehot && A.haps) recon_lean_rows_kernel<true, true, false><<<g, b, 0, s>>>(A, RA, M);
         else if (A.onehot) recon_lean_rows_kernel<true, false, false><<<g, b, 0, s>>>(A, RA, M);

@@ -48,7 +48,9 @@ KERNEL_PATHS = {0: "default", 8: "scalar-walk", 64: "csr-inline-records", 80: "c
                 33554432: "lean-pipelined", 33554432 + 32768: "lean-pipelined-defers-every-row",
                 33554432 + 65536: "lean-pipelined-defers-indel-rows", 67108864: "no-lean-pipeline",
                 # rows of several chunks without chunk plans (hap_plan_kernel): every chunk-wave walks its row itself, as in round 4
-                536870912: "no-chunk-plans"}
+                536870912: "no-chunk-plans",
+                # round 4's routing: channel-major one-hot, keep masks, annotations and get_reference on the all-purpose kernel
+                1073741824: "no-lean-forms-of-other-modes"}
 
 
 @pytest.fixture(params=sorted(KERNEL_PATHS), ids=[KERNEL_PATHS[k] for k in sorted(KERNEL_PATHS)])
@@ -738,7 +740,7 @@ def test_genome_dataset_batches(gpu, oracle, kpath, scale_kw):
 
 
 @pytest.mark.parametrize("x100", [0, 200, 300], ids=["default-1.5-rows-per-wave", "exactly-2", "exactly-3"])
-@pytest.mark.parametrize("want", ["onehot", "both", "ragged-onehot", "ragged-both"])
+@pytest.mark.parametrize("want", ["onehot", "both", "ragged-onehot", "ragged-both", "cl-onehot", "cl-both"])
 def test_bench_launch_every_row_vs_oracle(gpu, oracle, want, x100):
     """The launch bench.py times and the native loader submits, at its full size and on DEFAULT flags: 16 batches of 4096 x 2048
     (BASELINE config 3) of one dataset through pack_many / launch_many = ONE grid of recon_lean_rows_kernel over 65 536 rows on
@@ -753,7 +755,9 @@ def test_bench_launch_every_row_vs_oracle(gpu, oracle, want, x100):
     dev = HapsDevice(**ds.static_kwargs())
     assert dev.slot_rec is not None and dev.ref4 is not None
     hs = ds.host_static()
-    ragged, haps = want.startswith("ragged"), want.endswith("both")
+    ragged, haps, cl = want.startswith("ragged"), want.endswith("both"), want.startswith("cl")
+    if x100 == 300 and (haps or cl):
+        pytest.skip("three rows per wave: the one-hot-only forms cover the schedule")
     L = -1 if ragged else ds.length
     qsets = ds.draw_batches(16, 2048, seed=3)
     bts, outs, keep = [], [], []
@@ -767,7 +771,7 @@ def test_bench_launch_every_row_vs_oracle(gpu, oracle, want, x100):
         else:
             dbt = dev.prepare_batch(r["regions"], r["shifts"], r["geno_offset_idx"], L, to_rc=r["to_rc"])
             total = dbt.n_rows * L
-        o, oc = dev.alloc_output(dbt, total, haps=haps, onehot=True)
+        o, oc = dev.alloc_output(dbt, total, haps=haps, onehot=True, layout="cl" if cl else "lc")
         bts.append(dbt); outs.append(oc); keep.append(o)
     assert sum(b.n_rows for b in bts) == 65_536
     _lib.check_async()
@@ -787,7 +791,10 @@ def test_bench_launch_every_row_vs_oracle(gpu, oracle, want, x100):
             hs.alt_alleles, hs.alt_offsets, hs.ref, hs.ref_offsets, hs.pad_char, L, None, None, hb.to_rc, True,
             onehot=True, n_threads=8)
         np.testing.assert_array_equal(keep[i].out_offsets.cpu().numpy(), exp_off, err_msg=f"batch {i}")
-        np.testing.assert_array_equal(keep[i].onehot.cpu().numpy(), exp_oh, err_msg=f"batch {i}")
+        if cl:       # (rows, 4, L): plane c of row k = channel c of the row-major one-hot
+            np.testing.assert_array_equal(keep[i].onehot.cpu().numpy(), exp_oh.reshape(-1, ds.length, 4).transpose(0, 2, 1), err_msg=f"batch {i}")
+        else:
+            np.testing.assert_array_equal(keep[i].onehot.cpu().numpy(), exp_oh, err_msg=f"batch {i}")
         if haps:
             np.testing.assert_array_equal(keep[i].haps.cpu().numpy(), exp, err_msg=f"batch {i}")
         if ragged:

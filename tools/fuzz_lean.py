@@ -63,17 +63,20 @@ def one_case(rng):
     return st, bt
 
 
-def check(st, bt, want=(True, False)):
+def check(st, bt, want=(True, False), layout="lc"):
     onehot, haps = want
     dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens, alt_alleles=st.alt_alleles,
                      alt_offsets=st.alt_offsets, geno_offsets=bt.geno_offsets, geno_v_idxs=bt.geno_v_idxs, pad_char=st.pad_char)
     assert dev.ref4 is not None and dev.slot_rec is not None
-    out = dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, bt.output_length, None, None, bt.to_rc, haps=haps, onehot=onehot)
+    out = dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, bt.output_length, None, None, bt.to_rc, haps=haps, onehot=onehot,
+                          layout=layout)
     args = (bt.regions, bt.shifts, bt.geno_offset_idx, bt.geno_offsets, bt.geno_v_idxs, st.v_starts, st.ilens, st.alt_alleles,
             st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, bt.output_length, None, None, bt.to_rc, False)
     eh, eo, eoh = oracle.reconstruct_haplotypes_fused(*args, onehot=True)
     ok = np.array_equal(out.out_offsets.cpu().numpy(), eo)
-    if onehot:
+    if onehot and layout == "cl":
+        ok = ok and np.array_equal(out.onehot.cpu().numpy(), eoh.reshape(-1, bt.output_length, 4).transpose(0, 2, 1))
+    elif onehot:
         ok = ok and np.array_equal(out.onehot.cpu().numpy(), eoh)
     if haps:
         ok = ok and np.array_equal(out.haps.cpu().numpy(), eh)
@@ -87,7 +90,7 @@ def many_case(rng):
                            af_beta=(float(rng.choice([0.3, 0.6, 2.0])), float(rng.choice([0.9, 2.5]))), max_indel=int(rng.choice([3, 30, 200])),
                            n_frac=float(rng.choice([0.0, 0.01])))
     P = 2
-    L = int(rng.choice([64, 256, 500, 512, 1024, 2048]))
+    L = int(rng.choice([64, 256, 500, 508, 512, 1024, 1036, 2040, 2048]))
     n_b = int(rng.integers(4, 17))
     per = int(rng.integers(1500, 6001))
     cap = max(1, (40 << 20) // (L * P * n_b))            # (bounds the host side of the comparison: <= 40 MB of haplotype bytes a launch)
@@ -102,6 +105,8 @@ def many_case(rng):
         full.regions[:, 2] += rng.integers(0, 7, len(full.regions)).astype(full.regions.dtype)
     cuts = [(i * per, min((i + 1) * per, nq)) for i in range(n_b)]
     x100 = int(rng.choice([0, 0, 150, 200, 300, 800]))
+    if not RAGGED and rng.random() < 0.4:          # channel-major one-hot (rows, 4, L): lengths that end in a partial 16-base group too
+        full.meta["layout"] = "cl"
     return st, full, cuts, L, P, x100
 
 
@@ -109,6 +114,7 @@ def check_many(st, full, cuts, L, P, x100, want):
     from genvarloader_amd import _lib
 
     onehot, haps = want
+    layout = full.meta.get("layout", "lc") if onehot else "lc"
     dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens, alt_alleles=st.alt_alleles,
                      alt_offsets=st.alt_offsets, geno_offsets=full.geno_offsets, geno_v_idxs=full.geno_v_idxs, pad_char=st.pad_char)
     assert dev.ref4 is not None and dev.slot_rec is not None
@@ -125,7 +131,7 @@ def check_many(st, full, cuts, L, P, x100, want):
             else:
                 dbt = dev.prepare_batch(full.regions[a:b], full.shifts[a:b], full.geno_offset_idx[a:b], L, to_rc=rc)
                 total = (b - a) * P * L
-            o, oc = dev.alloc_output(dbt, total, haps=haps, onehot=onehot)
+            o, oc = dev.alloc_output(dbt, total, haps=haps, onehot=onehot, layout=layout)
             bts.append(dbt); outs.append(oc); keep.append(o)
         dev.launch_many(dev.pack_many(bts, outs))
         torch.cuda.synchronize()
@@ -140,7 +146,9 @@ def check_many(st, full, cuts, L, P, x100, want):
             st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, -1 if RAGGED else L, None, None, rc, True, onehot=True,
             n_threads=8)
         ok = ok and np.array_equal(keep[i].out_offsets.cpu().numpy(), eo)
-        if onehot:
+        if onehot and layout == "cl":
+            ok = ok and np.array_equal(keep[i].onehot.cpu().numpy(), eoh.reshape(-1, L, 4).transpose(0, 2, 1))
+        elif onehot:
             ok = ok and np.array_equal(keep[i].onehot.cpu().numpy(), eoh)
         if haps:
             ok = ok and np.array_equal(keep[i].haps.cpu().numpy(), eh)
@@ -174,7 +182,9 @@ if __name__ == "__main__":
         rng = np.random.default_rng(seed0 * 100003 + ci)
         st, bt = one_case(rng)
         want = ((True, False), (True, True), (False, True))[ci % 3]         # one-hot only / one-hot + bytes / bytes only
-        if not check(st, bt, want):
+        # (fixed-length rows of one chunk: every fourth case channel-major -- the pipelined kernel's form, also on launches of one small batch)
+        layout = "cl" if (want[0] and not RAGGED and not LONG and ci % 4 == 1) else "lc"
+        if not check(st, bt, want, layout):
             bad += 1
             print(f"MISMATCH case {ci} (seed {seed0}) onehot, haps = {want}: L={bt.output_length} P={bt.meta['P']} q={bt.meta['B']} V/row={bt.mean_variants:.1f} "
                   f"shiftmax={bt.shifts.max()}", flush=True)
