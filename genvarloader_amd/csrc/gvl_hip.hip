@@ -682,7 +682,10 @@ static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_o
     if (out->annot_v_idxs || out->annot_ref_pos) return false;
     // (channel-major one-hot: rows of one chunk only, and only the pipelined kernel has the form -- see lean_wants_pipe)
     if (out->onehot && out->onehot_layout != GVL_ONEHOT_LC && (chunks != 1 || (debug_flags() & (67108864 | 1073741824)))) return false;
-    if (bt->out_offsets || bt->keep || bt->keep_offsets) return false;
+    if (bt->out_offsets) return false;
+    // (a keep mask: both arrays or neither; rows of one chunk only, and only the pipelined kernel reads one)
+    if ((bt->keep != nullptr) != (bt->keep_offsets != nullptr)) return false;
+    if (bt->keep && (chunks != 1 || (debug_flags() & (67108864 | 1073741824)))) return false;
     if (bt->output_length <= 0 || (bt->output_length & 3)) return false;
     const i64 n_rows = bt->batch * bt->ploidy;
     if (chunks == 1) {
@@ -719,7 +722,8 @@ static bool lean_long_rag_eligible(const gvl_static *st, const gvl_batch *bt, co
 static bool lean_rag_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_out *out) {
     if (!st->ref4 || !st->slot_rec || (!out->onehot && !out->haps) || !bt->out_offsets) return false;
     if (out->annot_v_idxs || out->annot_ref_pos || (out->onehot && out->onehot_layout != GVL_ONEHOT_LC)) return false;
-    if (bt->keep || bt->keep_offsets) return false;
+    if ((bt->keep != nullptr) != (bt->keep_offsets != nullptr)) return false;
+    if (bt->keep && (debug_flags() & 1073741824)) return false;
     const i64 ml = bt->max_row_len > bt->output_length ? bt->max_row_len : bt->output_length;
     if (ml <= 0 || ml > (i64)PIPE_RAG_MAXT * TRIP) return false;
     const i64 n_rows = bt->batch * bt->ploidy;
@@ -743,8 +747,9 @@ int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *ou
     const int rc = fill_recon_args(st, bt, out, A, &chunks, &variant);
     if (rc) return rc;
     if (A.n_rows > 0 && lean_eligible(st, bt, out, chunks, A.chunk_len)) {
-        if (chunks == 1 && (lean_pipe_wanted(A.n_rows) || A.oh_cl) && lean_pipe_compatible(&A, 1)) return launch_lean_rows(&A, 1, stream, 1);
-        if (A.oh_cl) return launch_recon(A, chunks, variant, stream);        // (only the pipelined kernel has the channel-major form)
+        const bool pipe_only = A.oh_cl || A.keep;         // (only the pipelined kernel has the channel-major form and reads keep masks)
+        if (chunks == 1 && (lean_pipe_wanted(A.n_rows) || pipe_only) && lean_pipe_compatible(&A, 1)) return launch_lean_rows(&A, 1, stream, 1);
+        if (pipe_only) return launch_recon(A, chunks, variant, stream);
         return launch_lean(A, chunks, stream);
     }
     if (A.n_rows > 0 && !(debug_flags() & 67108864) && lean_rag_eligible(st, bt, out) && lean_pipe_compatible(&A, 1))
@@ -773,7 +778,7 @@ int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_o
         lean[i] = A[i].n_rows > 0 && (lean_eligible(st, &bts[i], &outs[i], chunks[i], A[i].chunk_len) ||
                                       (!lean_rag_eligible(st, &bts[i], &outs[i]) && lean_long_rag_eligible(st, &bts[i], &outs[i], chunks[i], A[i].chunk_len)));
         all_one_chunk_lean = all_one_chunk_lean && lean[i] && chunks[i] == 1;
-        any_cl = any_cl || A[i].oh_cl;
+        any_cl = any_cl || A[i].oh_cl || A[i].keep;
         all_rag = all_rag && A[i].n_rows > 0 && lean_rag_eligible(st, &bts[i], &outs[i]);
         total += A[i].n_rows;
     }
@@ -785,7 +790,7 @@ int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_o
     }
     for (int i = 0; i < n; ++i) {
         int rc;
-        if (lean[i] && A[i].oh_cl)       // (channel-major one-hot: the pipelined kernel's form, or the all-purpose kernel)
+        if (lean[i] && (A[i].oh_cl || A[i].keep))       // (channel-major one-hot, a keep mask: the pipelined kernel's forms, or the all-purpose kernel)
             rc = lean_pipe_compatible(&A[i], 1) ? launch_lean_rows(&A[i], 1, stream, 1) : launch_recon(A[i], chunks[i], variant[i], stream);
         else
             rc = lean[i] ? launch_lean(A[i], chunks[i], stream) : launch_recon(A[i], chunks[i], variant[i], stream);

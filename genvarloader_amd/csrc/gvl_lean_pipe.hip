@@ -49,6 +49,7 @@ int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks) 
         b.regions = RAs[i].regions; b.shifts = RAs[i].shifts; b.geno_offset_idx = RAs[i].geno_offset_idx; b.to_rc = RAs[i].to_rc;
         b.onehot = RAs[i].onehot; b.haps = RAs[i].haps; b.out_offsets_w = RAs[i].out_offsets_w; b.n_rows = RAs[i].n_rows;
         b.out_offsets = RAs[i].out_offsets;
+        b.keep = RAs[i].keep; b.keep_offsets = RAs[i].keep_offsets;
         total += RAs[i].n_rows;
     }
     A.n_rows = (int)total;

@@ -386,18 +386,69 @@ def test_long_rows_chunked(gpu, oracle, kpath):
     check_batch(gpu, oracle, st, bt)
 
 
-def test_keep_mask(gpu, oracle):
+def test_keep_mask(gpu, oracle, kpath):
+    """Rows under a keep mask (src/reconstruct/mod.rs:86-90): a random mask and the exonic mask the reference's spliced path makes
+    (genotypes/mod.rs:132-176); fixed-length and ragged rows; with annotations (the all-purpose kernel) and without (the pipelined
+    lean kernel reads the row's keep bytes with its slot line; GVL_DBG 2^30: the all-purpose kernel as in round 4)."""
     st, bt = _synth(12, (80_000,), 64, 1500, indel_frac=0.25, density=1 / 30, rc_frac=0.3)
     idx = bt.geno_offset_idx.ravel()
     n_per = bt.geno_offsets[1, idx] - bt.geno_offsets[0, idx]
     bt.keep_offsets = np.concatenate([[0], np.cumsum(n_per)]).astype(np.int64)
     bt.keep = np.random.default_rng(1).random(int(bt.keep_offsets[-1])) < 0.6
+    assert (n_per > 8).any() and (n_per <= 8).any()          # rows from the slot line and rows that overflow it
     check_batch(gpu, oracle, st, bt, annotate=True)
+    check_batch(gpu, oracle, st, bt)
     # exonic keep-mask produced the reference way (genotypes/mod.rs:132-176)
     keep, ko = oracle.choose_exonic_variants(bt.regions[:, 1], bt.regions[:, 2], bt.geno_offset_idx,
                                              bt.geno_v_idxs, bt.geno_offsets, st.v_starts, st.ilens)
     bt.keep, bt.keep_offsets = keep, ko
     check_batch(gpu, oracle, st, bt)
+    # ragged rows under the mask (what the spliced path launches: rows at the caller's offsets)
+    dev = make_dev(gpu, st, bt)
+    out = dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, -1, bt.keep, bt.keep_offsets, bt.to_rc, haps=True, onehot=True)
+    bt.output_length = -1
+    exp, exp_off, exp_oh = oracle_fused(oracle, st, bt, onehot=True)
+    np.testing.assert_array_equal(out.out_offsets.cpu().numpy(), exp_off)
+    np.testing.assert_array_equal(out.haps.cpu().numpy(), exp)
+    np.testing.assert_array_equal(out.onehot.cpu().numpy(), exp_oh)
+
+
+def test_keep_mask_many_batches_one_grid(gpu, oracle):
+    """Six batches of 1 500 queries under keep masks (one of them WITHOUT a mask) in one gvl_reconstruct_many call = one grid of the
+    pipelined kernel, two rows per wave: every batch against the oracle; keep bytes at every alignment (rows of 0-12 variants)."""
+    from genvarloader_amd import _lib
+
+    st, full = _synth(14, (400_000, 200_000), 9000, 512, indel_frac=0.3, density=1 / 60, rc_frac=0.5, random_shifts=True, permute_csr=True)
+    P = 2
+    idx = full.geno_offset_idx.ravel()
+    n_per = full.geno_offsets[1, idx] - full.geno_offsets[0, idx]
+    ko_all = np.concatenate([[0], np.cumsum(n_per)]).astype(np.int64)
+    keep_all = np.random.default_rng(2).random(int(ko_all[-1])) < 0.7
+    dev = make_dev(gpu, st, full)
+    cuts = [(i * 1500, (i + 1) * 1500) for i in range(6)]
+    bts, outs, keepo = [], [], []
+    for i, (a, b) in enumerate(cuts):
+        ko = ko_all[a * P:b * P + 1] - ko_all[a * P]
+        kp = keep_all[ko_all[a * P]:ko_all[b * P]]
+        kw = dict() if i == 3 else dict(keep=kp, keep_offsets=ko)
+        dbt = dev.prepare_batch(full.regions[a:b], full.shifts[a:b], full.geno_offset_idx[a:b], 512, to_rc=full.to_rc[a * P:b * P], **kw)
+        o, oc = dev.alloc_output(dbt, (b - a) * P * 512, haps=True, onehot=True)
+        bts.append(dbt); outs.append(oc); keepo.append((o, kw))
+    _lib.set_tuning(_lib.TUNE_PIPE_ROWS_X100, 200)
+    try:
+        dev.launch_many(dev.pack_many(bts, outs))
+        gpu.torch.cuda.synchronize()
+        _lib.check_async()
+    finally:
+        _lib.set_tuning(_lib.TUNE_PIPE_ROWS_X100, 0)
+    for i, (a, b) in enumerate(cuts):
+        o, kw = keepo[i]
+        exp, exp_off, exp_oh = oracle.reconstruct_haplotypes_fused(
+            full.regions[a:b], full.shifts[a:b], full.geno_offset_idx[a:b], full.geno_offsets, full.geno_v_idxs, st.v_starts,
+            st.ilens, st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, 512, kw.get("keep"), kw.get("keep_offsets"),
+            full.to_rc[a * P:b * P], True, onehot=True, n_threads=8)
+        np.testing.assert_array_equal(o.haps.cpu().numpy(), exp, err_msg=f"batch {i}")
+        np.testing.assert_array_equal(o.onehot.cpu().numpy(), exp_oh, err_msg=f"batch {i}")
 
 
 @pytest.mark.parametrize("seed", [21, 22])

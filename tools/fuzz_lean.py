@@ -60,6 +60,11 @@ def one_case(rng):
         bt.regions = bt.regions.copy()
         bt.regions[:, 2] += rng.integers(0, 7, len(bt.regions)).astype(bt.regions.dtype)      # (lengths of every residue mod 4)
         bt.output_length = -1
+    if not LONG and rng.random() < 0.3:            # a keep mask (rows of one chunk: the pipelined kernel reads it with the slot line)
+        idx = bt.geno_offset_idx.ravel()
+        n_per = bt.geno_offsets[1, idx] - bt.geno_offsets[0, idx]
+        bt.keep_offsets = np.concatenate([[0], np.cumsum(n_per)]).astype(np.int64)
+        bt.keep = rng.random(int(bt.keep_offsets[-1])) < float(rng.choice([0.2, 0.7, 0.95]))
     return st, bt
 
 
@@ -68,10 +73,10 @@ def check(st, bt, want=(True, False), layout="lc"):
     dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens, alt_alleles=st.alt_alleles,
                      alt_offsets=st.alt_offsets, geno_offsets=bt.geno_offsets, geno_v_idxs=bt.geno_v_idxs, pad_char=st.pad_char)
     assert dev.ref4 is not None and dev.slot_rec is not None
-    out = dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, bt.output_length, None, None, bt.to_rc, haps=haps, onehot=onehot,
-                          layout=layout)
+    out = dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, bt.output_length, bt.keep, bt.keep_offsets, bt.to_rc, haps=haps,
+                          onehot=onehot, layout=layout)
     args = (bt.regions, bt.shifts, bt.geno_offset_idx, bt.geno_offsets, bt.geno_v_idxs, st.v_starts, st.ilens, st.alt_alleles,
-            st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, bt.output_length, None, None, bt.to_rc, False)
+            st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, bt.output_length, bt.keep, bt.keep_offsets, bt.to_rc, False)
     eh, eo, eoh = oracle.reconstruct_haplotypes_fused(*args, onehot=True)
     ok = np.array_equal(out.out_offsets.cpu().numpy(), eo)
     if onehot and layout == "cl":
