@@ -854,6 +854,17 @@ int gvl_get_reference(const gvl_static *st, const int32_t *regions, int64_t regi
     A.pad = st->pad_char;
     A.haps = out; A.onehot = onehot;
     if (n_rows > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_get_reference: batch too large");
+    // Rows of at most 2560 bases with the packed reference present: the pipelined lean kernel's ragged form with no slot lines (a row
+    // inside its contig is one window read + the stream; rows that need padding run the all-purpose body at their wave's end).
+    // GVL_DBG 2^30 / 67108864: the all-purpose kernel for every row, as until round 4.
+    if (st->ref4 && !((uintptr_t)st->ref4 & 15) && max_row_len > 0 && max_row_len <= (i64)PIPE_RAG_MAXT * TRIP && n_rows <= 0x7FFFFFF0ll &&
+        st->ref_len < (1ll << 32) - 8192 &&
+        (debug_flags() & ~(2 | 4 | 32768 | 65536 | 33554432 | 268435456 | 536870912)) == 0) {
+        A.ref4 = st->ref4;
+        A.dbg = debug_flags();
+        A.async_err = async_err_word();
+        return launch_lean_rows(&A, 1, stream, chunks);
+    }
     return launch_recon(A, chunks, (onehot ? OH_LC : OH_NONE) | (out ? 4 : 0), stream);
 }
 

@@ -41,6 +41,7 @@ int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks) 
     A.n_contigs = RA.n_contigs; A.regions_stride = (int)RA.regions_stride;
     A.ploidy_shift = RA.ploidy_shift; A.ploidy = RA.ploidy; A.L = (int)RA.fixed_len; A.dbg = RA.dbg;
     A.chunks = 1; A.sub = 1;
+    A.ref_only = RA.ref_only;
     A.rows_per_batch = (int)RA.n_rows; A.n_batches = n;
     A.max_row_len = (int)((i64)RA.chunk_len * (RA.out_offsets ? rag_chunks : 1));
     i64 total = 0;

@@ -169,8 +169,8 @@ class HapsDevice:
         # instead of the byte reference -- half the bytes and cache lines behind the cold window reads.
         self.ref4 = None
         n_ref = int(self.ref.numel())
-        if packed_reference is None:
-            packed_reference = self.slot_rec is not None and n_ref > 0 and n_ref // 2 <= torch.cuda.mem_get_info(d)[0] // 4
+        if packed_reference is None:      # (also for a reference-only static: gvl_get_reference's lean route reads it)
+            packed_reference = n_ref > 0 and n_ref // 2 <= torch.cuda.mem_get_info(d)[0] // 4
         if packed_reference and n_ref > 0:
             with torch.cuda.device(d):
                 self.ref4 = torch.empty(int(self.lib.gvl_ref4_bytes(n_ref)), dtype=torch.uint8, device=d)

@@ -147,7 +147,22 @@ def test_golden_choose_exonic_variants(gpu, oracle):
     assert 0 < keep.sum() < keep.size
 
 
-def test_golden_get_reference(gpu):
+REF_PATHS = {0: "lean-route", 32768: "lean-route-defers-every-row", 33554432: "lean-route-one-workgroup", 1073741824: "all-purpose-kernel"}
+
+
+@pytest.fixture(params=sorted(REF_PATHS), ids=[REF_PATHS[k] for k in sorted(REF_PATHS)])
+def refpath(request, gpu):
+    """get_reference's routes: the pipelined lean kernel without slot lines (rows of at most 2560 bases), the same with every row
+    handed to the all-purpose body, on one workgroup, and round 4's all-purpose kernel."""
+    from genvarloader_amd import _lib
+
+    lib = _lib.load()
+    lib.gvl_set_debug_flags(int(request.param))
+    yield request.param
+    lib.gvl_set_debug_flags(-1)
+
+
+def test_golden_get_reference(gpu, refpath):
     cases = load_ref_cases("get_reference")
     assert len(cases) == 200
     for ci, (inp, exp) in enumerate(cases):
@@ -390,7 +405,7 @@ def test_keep_mask(gpu, oracle, kpath):
     """Rows under a keep mask (src/reconstruct/mod.rs:86-90): a random mask and the exonic mask the reference's spliced path makes
     (genotypes/mod.rs:132-176); fixed-length and ragged rows; with annotations (the all-purpose kernel) and without (the pipelined
     lean kernel reads the row's keep bytes with its slot line; GVL_DBG 2^30: the all-purpose kernel as in round 4)."""
-    st, bt = _synth(12, (80_000,), 64, 1500, indel_frac=0.25, density=1 / 30, rc_frac=0.3)
+    st, bt = _synth(12, (80_000,), 64, 1500, indel_frac=0.25, density=1 / 80, rc_frac=0.3)
     idx = bt.geno_offset_idx.ravel()
     n_per = bt.geno_offsets[1, idx] - bt.geno_offsets[0, idx]
     bt.keep_offsets = np.concatenate([[0], np.cumsum(n_per)]).astype(np.int64)
@@ -564,7 +579,7 @@ def test_spliced_caller_offsets(gpu, oracle):
     np.testing.assert_array_equal(got, exp)
 
 
-def test_get_reference_synthetic(gpu, oracle):
+def test_get_reference_synthetic(gpu, oracle, refpath):
     st, bt = _synth(51, (30_000, 10_000, 5), 300, 900, edge_frac=0.5, rc_frac=0.5)
     lens = (bt.regions[:, 2] - bt.regions[:, 1]).astype(np.int64)
     oo = np.concatenate([[0], np.cumsum(lens)])
@@ -575,6 +590,22 @@ def test_get_reference_synthetic(gpu, oracle):
     dev = gpu.ffi._ref_static(st.ref, st.ref_offsets, st.pad_char)
     out, oh = dev.get_reference(bt.regions, oo, to_rc, onehot=True)
     np.testing.assert_array_equal(oh.cpu().numpy(), oracle.onehot(exp))
+    np.testing.assert_array_equal(out.cpu().numpy(), exp)
+    # rows whose length is NOT their region's (padded_slice's out_len != stop - start), empty regions (start >= stop: untouched = zeros),
+    # regions that end in front of their contig, IUPAC / lower-case bytes (the lean route's byte table cannot write them: deferred)
+    rng = np.random.default_rng(9)
+    reg = bt.regions.copy()
+    reg[::7, 2] = reg[::7, 1] - rng.integers(0, 5, len(reg[::7]))             # start >= stop
+    reg[3::11, 2] = -rng.integers(1, 50, len(reg[3::11]))                      # stop < 0
+    ref2 = st.ref.copy()
+    ref2[rng.random(ref2.size) < 0.01] = ord("r")
+    lens2 = rng.integers(0, 1200, len(reg)).astype(np.int64)
+    oo2 = np.concatenate([[0], np.cumsum(lens2)])
+    exp2 = oracle.get_reference(reg, oo2, ref2, st.ref_offsets, st.pad_char, True, to_rc)
+    got2 = gpu.ffi.get_reference(reg, oo2, ref2, st.ref_offsets, st.pad_char, True, to_rc)
+    keep_rows = np.repeat(reg[:, 1] < reg[:, 2], lens2)                       # (rows the reference leaves untouched: zeros there, zeros here)
+    np.testing.assert_array_equal(got2[keep_rows], exp2[keep_rows])
+    np.testing.assert_array_equal(got2[~keep_rows], 0)
 
 
 def test_get_diffs_modes(gpu, oracle):
