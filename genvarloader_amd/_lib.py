@@ -63,7 +63,7 @@ SYMBOLS = (
 )
 
 ABI_VERSION = 9          # include/gvl_hip.h: GVL_ABI_VERSION
-TUNE_PIPE_ROWS_X100, TUNE_PIPE_MIN_ROWS, TUNE_LEAN_SUB, TUNE_TRACK_PLAN_MAX_MB = 0, 1, 2, 3     # GVL_TUNE_*
+TUNE_PIPE_ROWS_X100, TUNE_PIPE_MIN_ROWS, TUNE_LEAN_SUB, TUNE_TRACK_PLAN_MAX_MB, TUNE_RAGGED_SIZING = 0, 1, 2, 3, 4     # GVL_TUNE_*
 GVL_ONEHOT_LC = 0
 GVL_ONEHOT_CL = 1
 
@@ -121,7 +121,7 @@ class GvlLoaderConfig(C.Structure):
 
 
 LOADER_SLOT_PARTS = 12       # GVL_LOADER_SLOT_PARTS
-LOADER_TABLE_PARTS = 9       # GVL_LOADER_TABLE_PARTS
+LOADER_TABLE_PARTS = 10       # GVL_LOADER_TABLE_PARTS
 
 
 class GvlLoaderBatch(C.Structure):

@@ -1081,6 +1081,7 @@ struct gvl_loader {
     int G, n_sets;
     int2 *e_plan_hdr; i32x4 *e_plan_ent;    // tracks, rows of several chunks: the rows' plans (track_plan_kernel) of the epoch (or NULL)
     int e_chunks;
+    i64 *e_rag_offs, *e_rag_sizes;          // ragged rows: every batch's row offsets ((bs * P + 1) per batch) and {total, longest} of the epoch (or NULL)
     u8 *e_hplan; i64 e_hplan_row;           // rows of several chunks: the epoch's chunk plans (gvl_hap_plan over the whole table; or NULL) and the bytes of one row's
     i64 *e_track_offsets, *e_out_offsets;   // tracks: every batch's scratch-track offsets ((bs + 1) per batch) and the k * L output offsets
     u64 counter;                  // the running epoch's number + 1 (keys the random draws together with cfg.seed)
@@ -1132,6 +1133,11 @@ static i64 loader_hap_plan_bytes(const gvl_loader_config *cfg, i64 n) {
 }
 
 static bool loader_ragged(const gvl_loader_config *c) { return c->output_length == -1; }
+// ragged rows are sized once per EPOCH (in the table) instead of once per group of batches -- whenever the group sizing would be
+// used; gvl_set_tuning(GVL_TUNE_RAGGED_SIZING, 1): per group, as in round 4 (GVL_DBG & 134217728: per batch, as before that)
+static bool loader_epoch_sizing(const gvl_static *st, const gvl_loader_config *c) {
+    return loader_ragged(c) && !diffs_long_rows(st) && !(debug_flags() & 134217728) && tune(GVL_TUNE_RAGGED_SIZING) != 1;
+}
 // bases per row a slot reserves: the fixed length, or the ragged bound
 static i64 loader_row_cap(const gvl_loader_config *c) { return loader_ragged(c) ? c->max_row_len : c->output_length; }
 
@@ -1159,7 +1165,8 @@ int64_t gvl_loader_table_bytes(const gvl_loader_config *cfg, int64_t n, int64_t 
     const bool tr = cfg->n_tracks > 0;
     const i64 sizes[GVL_LOADER_TABLE_PARTS] = {16 * n, 8 * n * P, 4 * n * P, n * P, 8 * nb,
                                                tr ? 8 * (n + nb) : 0, tr ? 8 * (cfg->batch_size * P + 1) : 0,
-                                               tr ? loader_track_plan_bytes(cfg, n) : 0, loader_hap_plan_bytes(cfg, n)};
+                                               tr ? loader_track_plan_bytes(cfg, n) : 0, loader_hap_plan_bytes(cfg, n),
+                                               loader_ragged(cfg) ? 8 * nb * (cfg->batch_size * P + 1 + 2) : 0};
     i64 off = 0;
     for (int i = 0; i < GVL_LOADER_TABLE_PARTS; ++i) {
         if (part_offsets) part_offsets[i] = off;
@@ -1289,6 +1296,29 @@ static int loader_fill_table(gvl_loader *ld, const int64_t *order, i64 n, int32_
         const int rc_p = gvl_hap_plan(&ld->st, &gb, base + po[8], s);
         if (rc_p) return rc_p;
     }
+    if (po[10] > po[9] && loader_epoch_sizing(&ld->st, &c)) {
+        // ragged rows: every batch's row lengths -> offsets + {total, longest row}, for the whole epoch (rows cut to the slots'
+        // capacity are reported, never silent)
+        gvl_batch gb;
+        memset(&gb, 0, sizeof(gb));
+        gb.regions = t_regions; gb.regions_stride = 4; gb.shifts = t_shifts; gb.geno_offset_idx = (const int64_t *)t_goi;
+        gb.batch = n_used; gb.ploidy = c.ploidy;
+        DiffArgs D;
+        int rc0 = fill_diff_args(D, &ld->st, &gb, "gvl_loader(ragged sizing)");
+        if (rc0) return rc0;
+        D.q_starts = gb.regions + 1; D.q_ends = gb.regions + 2; D.q_stride = gb.regions_stride;
+        D.diffs = nullptr; D.output_length = -1; D.lengths = nullptr;
+        D.len_cap = c.max_row_len; D.async_err = async_err_word();
+        const i64 rpb = bs * c.ploidy;
+        i64 *const offs = (i64 *)(base + po[9]);
+        i64 *const sizes = offs + n_batches * (rpb + 1);
+        hap_lengths_epoch_kernel<<<dim3((unsigned)((D.n_rows + 255) / 256)), dim3(256), 0, s>>>(D, gb.regions, (i64)gb.regions_stride, rpb, offs);
+        rc0 = check_launch("gvl_loader(ragged lengths, epoch)");
+        if (rc0) return rc0;
+        hap_scan_epoch_kernel<<<dim3((unsigned)n_batches), dim3(256), 0, s>>>(offs, sizes, rpb, D.n_rows);
+        rc0 = check_launch("gvl_loader(ragged offsets, epoch)");
+        if (rc0) return rc0;
+    }
     if (c.n_tracks > 0 && c.track_seed_mode == 1) {
         const i64 grid = (n_batches * WAVE + 255) / 256;
         batch_seeds_kernel<<<dim3((unsigned)grid), dim3(256), 0, s>>>((const i64 *)order, n_used, bs, n_batches, c.deterministic,
@@ -1406,6 +1436,11 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
         ld->e_track_offsets = (i64 *)(base + po[5]);
         ld->e_out_offsets = (i64 *)(base + po[6]);
         ld->e_hplan = (loader_hap_plan_bytes(&c, n) > 0 && !(debug_flags() & 536870912)) ? base + po[8] : nullptr;
+        ld->e_rag_offs = loader_epoch_sizing(&ld->st, &c) ? (i64 *)(base + po[9]) : nullptr;
+        {
+            const i64 nb_used = drop_last ? n / c.batch_size : (n + c.batch_size - 1) / c.batch_size;
+            ld->e_rag_sizes = ld->e_rag_offs ? ld->e_rag_offs + nb_used * (c.batch_size * c.ploidy + 1) : nullptr;
+        }
         ld->e_hplan_row = gvl_hap_plan_bytes(1, c.output_length);
         const i64 wsb = c.n_tracks > 0 ? loader_track_plan_bytes(&c, n) : 0;
         int cl = 0;
@@ -1499,6 +1534,14 @@ static int loader_submit(gvl_loader *ld, i64 g) {
             // row lengths and offsets on the device (rows cut to the slot's capacity are reported, never silent);
             // the reconstruct launch below then reads them -- no host round trip.  One sizing per GROUP (below) unless the
             // dataset's rows take the wave-per-row length kernel (or GVL_DBG & 134217728: per batch, as before round 4)
+            if (ld->e_rag_offs) {
+                // sized with the epoch's table: the launch reads its rows' offsets THERE (nothing in front of it); the consumer's
+                // copies go to the slots behind it
+                grp.offs[m] = (i64 *)o.out_offsets; grp.sizes[m] = (i64 *)o.sizes;
+                bt.out_offsets = (const int64_t *)(ld->e_rag_offs + j * (c.batch_size * c.ploidy + 1));
+                oc.out_offsets = nullptr;
+                continue;
+            }
             if (diffs_long_rows(&ld->st) || (debug_flags() & 134217728)) {
                 const int rc0 = hap_offsets_impl(&ld->st, &bt, nullptr, o.out_offsets, o.sizes, c.max_row_len, s);
                 if (rc0) return rc0;
@@ -1535,6 +1578,12 @@ static int loader_submit(gvl_loader *ld, i64 g) {
     int rc = GVL_OK;
     (void)traced("launch reconstruct", [&] { rc = gvl_reconstruct_many(&ld->st, bts, ocs, m, s); return hipSuccess; });
     if (rc) return rc;
+    if (ld->e_rag_offs && m > 0) {
+        const i64 rpb = c.batch_size * c.ploidy, j0 = g * ld->G;
+        hap_offsets_copy_kernel<<<dim3(4, (unsigned)m), dim3(256), 0, s>>>(grp, ld->e_rag_offs + j0 * (rpb + 1), ld->e_rag_sizes + 2 * j0, rpb);
+        rc = check_launch("gvl_loader(ragged offsets to the slots)");
+        if (rc) return rc;
+    }
     if (c.n_tracks > 0) {
         m = 0;
         for (i64 j = g * ld->G; j < (g + 1) * ld->G && j < ld->n_batches; ++j, ++m) {

@@ -173,8 +173,10 @@ int gvl_set_debug_flags(int flags);
  *                                the waves, 200 = exactly two, 300 = three ...; at most 3200).  Built in: 150 from 49 152 rows.
  *   GVL_TUNE_PIPE_MIN_ROWS       launches with fewer rows keep the wave-per-row kernel (built in: 8192; 2048 for groups).
  *   GVL_TUNE_LEAN_SUB            consecutive chunks of a long row one wave takes (built in: 2).
- *   GVL_TUNE_TRACK_PLAN_MAX_MB   row plans of an epoch larger than this are not kept (built in: 512). */
-enum { GVL_TUNE_PIPE_ROWS_X100 = 0, GVL_TUNE_PIPE_MIN_ROWS = 1, GVL_TUNE_LEAN_SUB = 2, GVL_TUNE_TRACK_PLAN_MAX_MB = 3, GVL_TUNE_COUNT = 4 };
+ *   GVL_TUNE_TRACK_PLAN_MAX_MB   row plans of an epoch larger than this are not kept (built in: 512).
+ *   GVL_TUNE_RAGGED_SIZING       1: the native loader sizes ragged rows once per group of batches (round 4's way), not once per epoch. */
+enum { GVL_TUNE_PIPE_ROWS_X100 = 0, GVL_TUNE_PIPE_MIN_ROWS = 1, GVL_TUNE_LEAN_SUB = 2, GVL_TUNE_TRACK_PLAN_MAX_MB = 3, GVL_TUNE_RAGGED_SIZING = 4,
+       GVL_TUNE_COUNT = 5 };
 int gvl_set_tuning(int32_t key, int64_t value);
 const char *gvl_last_error(void);
 /* (The flag behind gvl_async_error is PROCESS-global: it says that some launch of this process met the
@@ -520,7 +522,7 @@ typedef struct gvl_loader_batch {
  * geno_offset_idx, shifts, to_rc, out_offsets, annot_v_idxs, annot_ref_pos, tracks, track scratch,
  * sizes), for a full batch.  (Parts 2-5 are unused since the request arrays live in the epoch table.) */
 #define GVL_LOADER_SLOT_PARTS 12
-#define GVL_LOADER_TABLE_PARTS 9
+#define GVL_LOADER_TABLE_PARTS 10
 int64_t gvl_loader_slot_bytes(const gvl_loader_config *cfg, int64_t *part_offsets);
 /* `st` is copied; the device arrays it points to must outlive the loader. */
 int gvl_loader_create(const gvl_static *st, const gvl_loader_config *cfg, gvl_loader **out);
@@ -565,7 +567,9 @@ int gvl_loader_set_epoch(gvl_loader *ld, uint64_t epoch);
  * 2048-value chunks, the rows' realignment plans (the row's entries, 2 KB per row, + 8 B per (row, chunk); left out when an
  * epoch's would exceed gvl_set_tuning(GVL_TUNE_TRACK_PLAN_MAX_MB), default 512); and, last, for fixed-length rows of several
  * 2048-base chunks the haplotype kernel's chunk plans of every row (gvl_hap_plan_bytes; same cap: an epoch without them plans per
- * launch)).  The table is the
+ * launch); and for ragged rows (output_length = -1) every batch's row offsets i64 (batch_size * ploidy + 1 per batch) and its
+ * {total, longest row} (2 i64 per batch): the rows' lengths are a function of the table's regions and the genotypes, so they are
+ * sized once per epoch, not once per group of batches).  The table is the
  * caller's device memory (256-byte aligned) and must stay alive until the epoch ends; batch j's
  * request arrays are rows [j * batch_size, ...) of its parts. */
 int64_t gvl_loader_table_bytes(const gvl_loader_config *cfg, int64_t n, int64_t *part_offsets);

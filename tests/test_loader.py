@@ -544,16 +544,22 @@ def test_tracks_row_plans_rows_of_many_trips(oracle, dbg, python_loop, strategy,
         _lib.load().gvl_set_debug_flags(-1)
 
 
-@pytest.fixture(params=[0, 134217728, 67108864, 33554432], ids=["default", "sizing-per-batch", "no-pipelined-kernel", "pipelined-one-workgroup"])
+@pytest.fixture(params=[0, -1, 134217728, 67108864, 33554432],
+                ids=["default-sized-per-epoch", "sizing-per-group", "sizing-per-batch", "no-pipelined-kernel", "pipelined-one-workgroup"])
 def ragged_path(request):
-    """Ragged rows reach their output through the lean kernel's pipelined form behind ONE sizing per group of batches (default), behind
-    a sizing per batch, through the all-purpose kernel, and through the pipelined form on one workgroup (many rows per wave)."""
+    """Ragged rows reach their output through the lean kernel's pipelined form with their offsets sized ONCE PER EPOCH in the loader's
+    table (default), behind one sizing per group of batches (round 4: gvl_set_tuning(GVL_TUNE_RAGGED_SIZING, 1)), behind a sizing per
+    batch, through the all-purpose kernel, and through the pipelined form on one workgroup (many rows per wave)."""
     from genvarloader_amd import _lib
 
     lib = _lib.load()
-    lib.gvl_set_debug_flags(int(request.param))
+    if request.param == -1:
+        _lib.set_tuning(_lib.TUNE_RAGGED_SIZING, 1)
+    else:
+        lib.gvl_set_debug_flags(int(request.param))
     yield request.param
     lib.gvl_set_debug_flags(-1)
+    _lib.set_tuning(_lib.TUNE_RAGGED_SIZING, 0)
 
 
 @pytest.mark.gpu
