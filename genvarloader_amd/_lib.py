@@ -28,6 +28,7 @@ SYMBOLS = (
     "gvl_pack_variants",
     "gvl_pack_genotypes",
     "gvl_pack_slots",
+    "gvl_pack_slot_vidx",
     "gvl_ref4_bytes",
     "gvl_pack_reference",
     "gvl_reconstruct",
@@ -78,7 +79,7 @@ class GvlStatic(C.Structure):
         ("n_variants", _i64), ("alt_len", _i64), ("vrec", _vp),
         ("geno_o_starts", _vp), ("geno_o_stops", _vp), ("n_geno_offsets", _i64),
         ("geno_v_idxs", _vp), ("n_geno", _i64), ("pad_char", C.c_uint8), ("geno_rec", _vp),
-        ("slot_rec", _vp), ("ref4", _vp),
+        ("slot_rec", _vp), ("ref4", _vp), ("slot_vidx", _vp),
     ]
 
 

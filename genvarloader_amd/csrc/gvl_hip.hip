@@ -567,7 +567,7 @@ int gvl_static_upload(const gvl_static *host, int32_t with_layouts, gvl_static *
     d.geno_o_stops = (const int64_t *)dev_copy(o, host->geno_o_stops, (size_t)no * 8, s, &ok);
     d.geno_v_idxs = (const int32_t *)dev_copy(o, host->geno_v_idxs, (size_t)ng * 4, s, &ok);
     d.vrec = (const gvl_vrec *)dev_copy(o, nullptr, (size_t)(nv > 0 ? nv : 1) * sizeof(gvl_vrec), s, &ok);
-    d.geno_rec = nullptr; d.slot_rec = nullptr;
+    d.geno_rec = nullptr; d.slot_rec = nullptr; d.slot_vidx = nullptr;
     int rc = ok ? GVL_OK : fail(GVL_ERR_HIP, "%s", "gvl_static_upload: device allocation / copy failed");
     if (!rc && nv > 0) rc = gvl_pack_variants(d.v_starts, d.ilens, d.alt_offsets, d.alt_alleles, nv, (gvl_vrec *)d.vrec, stream);
     if (!rc && with_layouts && ng > 0 && nv > 0) {
@@ -577,6 +577,10 @@ int gvl_static_upload(const gvl_static *host, int32_t with_layouts, gvl_static *
     if (!rc && ok && with_layouts && no > 0 && nv > 0 && host->alt_len < (1ll << 32)) {
         gvl_srec *sr = (gvl_srec *)dev_copy(o, nullptr, (size_t)no * GVL_SLOT_RECS * sizeof(gvl_srec), s, &ok);
         if (ok) { rc = gvl_pack_slots(&d, sr, stream); if (!rc) d.slot_rec = sr; }
+        if (ok && !rc) {
+            int32_t *sv = (int32_t *)dev_copy(o, nullptr, (size_t)no * GVL_SLOT_RECS * sizeof(int32_t), s, &ok);
+            if (ok) { rc = gvl_pack_slot_vidx(&d, sv, stream); if (!rc) d.slot_vidx = sv; }
+        }
     }
     d.ref4 = nullptr;
     if (!rc && ok && with_layouts && host->ref_len > 0) {
@@ -596,6 +600,25 @@ int gvl_static_free(gvl_static *st) {
     for (int i = 0; i < o->n; ++i) (void)hipFree(o->bufs[i]);
     delete o;
     return GVL_OK;
+}
+
+__global__ __launch_bounds__(256) void pack_slot_vidx_kernel(const i64 *go_starts, const i64 *go_stops, i64 n_slots, const int *geno_v_idxs, int *out) {
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_slots * GVL_SLOT_RECS) return;
+    const i64 o = t / GVL_SLOT_RECS;
+    const int j = (int)(t - o * GVL_SLOT_RECS);
+    const i64 s0 = go_starts[o], n = go_stops[o] - s0;
+    out[t] = (n >= 0 && j < n && n <= GVL_SLOT_RECS) ? geno_v_idxs[s0 + j] : -1;       // (a slot that overflows its line: read from the CSR's inline records)
+}
+int gvl_pack_slot_vidx(const gvl_static *st, int32_t *out, void *stream) {
+    if (!st || st->n_geno_offsets < 0) return fail(GVL_ERR_INVALID, "%s", "gvl_pack_slot_vidx: bad arguments");
+    if (st->n_geno_offsets == 0) return GVL_OK;
+    if (!st->geno_o_starts || !st->geno_o_stops || !out || (st->n_geno > 0 && !st->geno_v_idxs)) return fail(GVL_ERR_INVALID, "%s", "gvl_pack_slot_vidx: NULL array");
+    const i64 grid = (st->n_geno_offsets * GVL_SLOT_RECS + 255) / 256;
+    if (grid > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_pack_slot_vidx: too many slots");
+    pack_slot_vidx_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>((const i64 *)st->geno_o_starts, (const i64 *)st->geno_o_stops,
+                                                                                      st->n_geno_offsets, st->geno_v_idxs, out);
+    return check_launch("gvl_pack_slot_vidx");
 }
 
 int gvl_pack_slots(const gvl_static *st, gvl_srec *srec_out, void *stream) {
@@ -645,6 +668,7 @@ static int fill_recon_args(const gvl_static *st, const gvl_batch *bt, const gvl_
     A.ref4 = st->ref4;
     A.hplan = (const u32 *)bt->hap_plan;
     A.oh_cl = (out->onehot && out->onehot_layout == GVL_ONEHOT_CL) ? 1u : 0u;
+    A.slot_vidx = st->slot_vidx;
     A.n_geno_offsets = st->n_geno_offsets;
     A.n_contigs = (int)(st->n_contigs < 0 ? 0 : (st->n_contigs > 0x7FFFFFFFll ? 0x7FFFFFFF : st->n_contigs));
     A.regions = bt->regions; A.regions_stride = bt->regions_stride; A.shifts = bt->shifts;
@@ -679,7 +703,12 @@ static int fill_recon_args(const gvl_static *st, const gvl_batch *bt, const gvl_
 // into 2048-base chunks): one wave per chunk, variants from the CSR's inline records (LONG).
 static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_out *out, int chunks, int chunk_len) {
     if (!st->ref4 || (!out->onehot && !out->haps)) return false;
-    if (out->annot_v_idxs || out->annot_ref_pos) return false;
+    // (annotated haplotypes: bytes + BOTH annotation streams, no one-hot, rows of one chunk, the slot records' variant indices present;
+    // only the pipelined kernel has the form)
+    if (out->annot_v_idxs || out->annot_ref_pos) {
+        if (!out->annot_v_idxs || !out->annot_ref_pos || !out->haps || out->onehot || !st->slot_vidx || chunks != 1 || ((uintptr_t)st->slot_vidx & 15) ||
+            (debug_flags() & (67108864 | 1073741824))) return false;
+    }
     // (channel-major one-hot: rows of one chunk only, and only the pipelined kernel has the form -- see lean_wants_pipe)
     if (out->onehot && out->onehot_layout != GVL_ONEHOT_LC && (chunks != 1 || (debug_flags() & (67108864 | 1073741824)))) return false;
     if (bt->out_offsets) return false;
@@ -721,7 +750,11 @@ static bool lean_long_rag_eligible(const gvl_static *st, const gvl_batch *bt, co
 // within the pipelined kernel's 10 trips.  There is no wave-per-row lean kernel for these: pipelined form or the all-purpose kernel.
 static bool lean_rag_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_out *out) {
     if (!st->ref4 || !st->slot_rec || (!out->onehot && !out->haps) || !bt->out_offsets) return false;
-    if (out->annot_v_idxs || out->annot_ref_pos || (out->onehot && out->onehot_layout != GVL_ONEHOT_LC)) return false;
+    if (out->onehot && out->onehot_layout != GVL_ONEHOT_LC) return false;
+    if (out->annot_v_idxs || out->annot_ref_pos) {
+        if (!out->annot_v_idxs || !out->annot_ref_pos || !out->haps || out->onehot || !st->slot_vidx || ((uintptr_t)st->slot_vidx & 15) ||
+            (debug_flags() & 1073741824)) return false;
+    }
     if ((bt->keep != nullptr) != (bt->keep_offsets != nullptr)) return false;
     if (bt->keep && (debug_flags() & 1073741824)) return false;
     const i64 ml = bt->max_row_len > bt->output_length ? bt->max_row_len : bt->output_length;
@@ -747,7 +780,7 @@ int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *ou
     const int rc = fill_recon_args(st, bt, out, A, &chunks, &variant);
     if (rc) return rc;
     if (A.n_rows > 0 && lean_eligible(st, bt, out, chunks, A.chunk_len)) {
-        const bool pipe_only = A.oh_cl || A.keep;         // (only the pipelined kernel has the channel-major form and reads keep masks)
+        const bool pipe_only = A.oh_cl || A.keep || A.av;         // (only the pipelined kernel has the channel-major and annotated forms and reads keep masks)
         if (chunks == 1 && (lean_pipe_wanted(A.n_rows) || pipe_only) && lean_pipe_compatible(&A, 1)) return launch_lean_rows(&A, 1, stream, 1);
         if (pipe_only) return launch_recon(A, chunks, variant, stream);
         return launch_lean(A, chunks, stream);
@@ -778,7 +811,7 @@ int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_o
         lean[i] = A[i].n_rows > 0 && (lean_eligible(st, &bts[i], &outs[i], chunks[i], A[i].chunk_len) ||
                                       (!lean_rag_eligible(st, &bts[i], &outs[i]) && lean_long_rag_eligible(st, &bts[i], &outs[i], chunks[i], A[i].chunk_len)));
         all_one_chunk_lean = all_one_chunk_lean && lean[i] && chunks[i] == 1;
-        any_cl = any_cl || A[i].oh_cl || A[i].keep;
+        any_cl = any_cl || A[i].oh_cl || A[i].keep || A[i].av;
         all_rag = all_rag && A[i].n_rows > 0 && lean_rag_eligible(st, &bts[i], &outs[i]);
         total += A[i].n_rows;
     }
@@ -790,7 +823,7 @@ int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_o
     }
     for (int i = 0; i < n; ++i) {
         int rc;
-        if (lean[i] && (A[i].oh_cl || A[i].keep))       // (channel-major one-hot, a keep mask: the pipelined kernel's forms, or the all-purpose kernel)
+        if (lean[i] && (A[i].oh_cl || A[i].keep || A[i].av))       // (channel-major one-hot, a keep mask: the pipelined kernel's forms, or the all-purpose kernel)
             rc = lean_pipe_compatible(&A[i], 1) ? launch_lean_rows(&A[i], 1, stream, 1) : launch_recon(A[i], chunks[i], variant[i], stream);
         else
             rc = lean[i] ? launch_lean(A[i], chunks[i], stream) : launch_recon(A[i], chunks[i], variant[i], stream);

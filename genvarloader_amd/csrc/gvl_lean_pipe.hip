@@ -20,7 +20,7 @@ bool lean_pipe_compatible(const ReconArgs *RAs, int n) {
         if (R.fixed_len != F.fixed_len || R.ploidy != F.ploidy || R.regions_stride != F.regions_stride ||
             (R.out_offsets != nullptr) != (F.out_offsets != nullptr) ||
             (R.onehot != nullptr) != (F.onehot != nullptr) || (R.haps != nullptr) != (F.haps != nullptr) || R.dbg != F.dbg ||
-            R.oh_cl != F.oh_cl)
+            R.oh_cl != F.oh_cl || (R.av != nullptr) != (F.av != nullptr) || (R.ap != nullptr) != (F.ap != nullptr))
             return false;
         if (R.n_rows <= 0 || R.n_rows > F.n_rows || (i + 1 < n && R.n_rows != F.n_rows)) return false;
         total += R.n_rows;
@@ -42,6 +42,7 @@ int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks) 
     A.ploidy_shift = RA.ploidy_shift; A.ploidy = RA.ploidy; A.L = (int)RA.fixed_len; A.dbg = RA.dbg;
     A.chunks = 1; A.sub = 1;
     A.ref_only = RA.ref_only;
+    A.slot_vidx = RA.slot_vidx;
     A.rows_per_batch = (int)RA.n_rows; A.n_batches = n;
     A.max_row_len = (int)((i64)RA.chunk_len * (RA.out_offsets ? rag_chunks : 1));
     i64 total = 0;
@@ -51,6 +52,7 @@ int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks) 
         b.onehot = RAs[i].onehot; b.haps = RAs[i].haps; b.out_offsets_w = RAs[i].out_offsets_w; b.n_rows = RAs[i].n_rows;
         b.out_offsets = RAs[i].out_offsets;
         b.keep = RAs[i].keep; b.keep_offsets = RAs[i].keep_offsets;
+        b.av = RAs[i].av; b.ap = RAs[i].ap;
         total += RAs[i].n_rows;
     }
     A.n_rows = (int)total;
@@ -71,7 +73,10 @@ int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks) 
     const unsigned grid = (unsigned)((waves + LEAN_WAVES - 1) / LEAN_WAVES);
     const dim3 g(grid), b(LEAN_THREADS);
     hipStream_t s = (hipStream_t)stream;
-    if (RA.out_offsets) {
+    if (RA.av && RA.ap) {          // annotated haplotypes: bytes + the two annotation streams
+        if (RA.out_offsets) recon_lean_rows_kernel<false, true, true, false, true><<<g, b, 0, s>>>(A, RA, M);
+        else recon_lean_rows_kernel<false, true, false, false, true><<<g, b, 0, s>>>(A, RA, M);
+    } else if (RA.out_offsets) {
         if (A.onehot && A.haps) recon_lean_rows_kernel<true, true, true><<<g, b, 0, s>>>(A, RA, M);
         else if (A.onehot) recon_lean_rows_kernel<true, false, true><<<g, b, 0, s>>>(A, RA, M);
         else recon_lean_rows_kernel<false, true, true><<<g, b, 0, s>>>(A, RA, M);

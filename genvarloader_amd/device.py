@@ -157,6 +157,7 @@ class HapsDevice:
         # read after geno_offset_idx instead of geno_o_starts/stops -> records -> alt_offsets.  Same
         # default: build when it costs less than a quarter of the free HBM (and ALT bytes fit u32).
         self.slot_rec = None
+        self.slot_vidx = None
         if slot_records is None:
             slot_records = (n_go > 0 and n_var > 0 and int(self.alt_alleles.numel()) < (1 << 32)
                             and 128 * n_go <= torch.cuda.mem_get_info(d)[0] // 4)
@@ -165,6 +166,11 @@ class HapsDevice:
                 self.slot_rec = torch.empty((n_go * 8, 4), dtype=torch.int32, device=d)
                 _lib.check(self.lib.gvl_pack_slots(C.byref(self.c), _ptr(self.slot_rec), _stream_ptr()))
             self.c.slot_rec = self.slot_rec.data_ptr()
+            # ... and the records' variant indices (32 B per slot): what annotated haplotypes need next to the slot line
+            with torch.cuda.device(d):
+                self.slot_vidx = torch.empty((n_go * 8,), dtype=torch.int32, device=d)
+                _lib.check(self.lib.gvl_pack_slot_vidx(C.byref(self.c), _ptr(self.slot_vidx), _stream_ptr()))
+            self.c.slot_vidx = self.slot_vidx.data_ptr()
         # Nibble-packed reference (gvl_pack_reference, ref_len / 2 bytes): what the lean one-hot kernel reads
         # instead of the byte reference -- half the bytes and cache lines behind the cold window reads.
         self.ref4 = None

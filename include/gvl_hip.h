@@ -123,6 +123,8 @@ typedef struct gvl_static {
     const gvl_grec *geno_rec;    /* nullable: n_geno, from gvl_pack_genotypes() */
     const gvl_srec *slot_rec;    /* nullable: GVL_SLOT_RECS * n_geno_offsets, from gvl_pack_slots() */
     const uint8_t *ref4;         /* nullable: (ref_len + 1) / 2 + GVL_REF4_PAD bytes, from gvl_pack_reference() */
+    const int32_t *slot_vidx;    /* nullable: GVL_SLOT_RECS * n_geno_offsets i32, from gvl_pack_slot_vidx(): the variant index of
+                                    every slot record (-1: no record) -- what annotated haplotypes need next to the slot line */
 } gvl_static;
 
 /* Per-batch arrays.  Mirrors `ReconstructionRequest` (_haps.py:58-93) as
@@ -212,6 +214,10 @@ int gvl_pack_genotypes(const gvl_static *st, gvl_grec *grec_out, void *stream);
  * ref4_out: gvl_ref4_bytes(ref_len) = (ref_len + 1) / 2 + GVL_REF4_PAD bytes. */
 int64_t gvl_ref4_bytes(int64_t ref_len);
 int gvl_pack_reference(const uint8_t *ref, int64_t ref_len, uint8_t *ref4_out, void *stream);
+
+/* Build the slot records' variant indices (once per dataset; optional: the lean path of annotated haplotypes reads them with the
+ * slot line).  out: GVL_SLOT_RECS * n_geno_offsets i32. */
+int gvl_pack_slot_vidx(const gvl_static *st, int32_t *out, void *stream);
 
 /* Build the slot-major records (once per dataset; optional, see gvl_srec).
  * Needs st->vrec, alt_offsets, geno_o_starts/stops, geno_v_idxs, n_geno_offsets, n_variants;

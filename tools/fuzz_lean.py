@@ -68,13 +68,13 @@ def one_case(rng):
     return st, bt
 
 
-def check(st, bt, want=(True, False), layout="lc"):
+def check(st, bt, want=(True, False), layout="lc", annotate=False):
     onehot, haps = want
     dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens, alt_alleles=st.alt_alleles,
                      alt_offsets=st.alt_offsets, geno_offsets=bt.geno_offsets, geno_v_idxs=bt.geno_v_idxs, pad_char=st.pad_char)
     assert dev.ref4 is not None and dev.slot_rec is not None
     out = dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, bt.output_length, bt.keep, bt.keep_offsets, bt.to_rc, haps=haps,
-                          onehot=onehot, layout=layout)
+                          onehot=onehot, layout=layout, annotate=annotate)
     args = (bt.regions, bt.shifts, bt.geno_offset_idx, bt.geno_offsets, bt.geno_v_idxs, st.v_starts, st.ilens, st.alt_alleles,
             st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, bt.output_length, bt.keep, bt.keep_offsets, bt.to_rc, False)
     eh, eo, eoh = oracle.reconstruct_haplotypes_fused(*args, onehot=True)
@@ -85,6 +85,9 @@ def check(st, bt, want=(True, False), layout="lc"):
         ok = ok and np.array_equal(out.onehot.cpu().numpy(), eoh)
     if haps:
         ok = ok and np.array_equal(out.haps.cpu().numpy(), eh)
+    if annotate:
+        _, av, ap, _ = oracle.reconstruct_annotated_haplotypes_fused(*args)
+        ok = ok and np.array_equal(out.annot_v_idxs.cpu().numpy(), av) and np.array_equal(out.annot_ref_pos.cpu().numpy(), ap)
     return ok
 
 
@@ -119,6 +122,7 @@ def check_many(st, full, cuts, L, P, x100, want):
     from genvarloader_amd import _lib
 
     onehot, haps = want
+    annotate = haps and not onehot and x100 != 300       # (bytes only: annotated -- the pipelined kernel's annotated form in one grid)
     layout = full.meta.get("layout", "lc") if onehot else "lc"
     dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens, alt_alleles=st.alt_alleles,
                      alt_offsets=st.alt_offsets, geno_offsets=full.geno_offsets, geno_v_idxs=full.geno_v_idxs, pad_char=st.pad_char)
@@ -136,7 +140,7 @@ def check_many(st, full, cuts, L, P, x100, want):
             else:
                 dbt = dev.prepare_batch(full.regions[a:b], full.shifts[a:b], full.geno_offset_idx[a:b], L, to_rc=rc)
                 total = (b - a) * P * L
-            o, oc = dev.alloc_output(dbt, total, haps=haps, onehot=onehot, layout=layout)
+            o, oc = dev.alloc_output(dbt, total, haps=haps, onehot=onehot, layout=layout, annotate=annotate)
             bts.append(dbt); outs.append(oc); keep.append(o)
         dev.launch_many(dev.pack_many(bts, outs))
         torch.cuda.synchronize()
@@ -157,6 +161,11 @@ def check_many(st, full, cuts, L, P, x100, want):
             ok = ok and np.array_equal(keep[i].onehot.cpu().numpy(), eoh)
         if haps:
             ok = ok and np.array_equal(keep[i].haps.cpu().numpy(), eh)
+        if annotate:
+            _, av, ap, _ = oracle.reconstruct_annotated_haplotypes_fused(
+                full.regions[a:b], full.shifts[a:b], full.geno_offset_idx[a:b], full.geno_offsets, full.geno_v_idxs, st.v_starts, st.ilens,
+                st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, -1 if RAGGED else L, None, None, rc, True, n_threads=8)
+            ok = ok and np.array_equal(keep[i].annot_v_idxs.cpu().numpy(), av) and np.array_equal(keep[i].annot_ref_pos.cpu().numpy(), ap)
     return ok
 
 
@@ -189,7 +198,9 @@ if __name__ == "__main__":
         want = ((True, False), (True, True), (False, True))[ci % 3]         # one-hot only / one-hot + bytes / bytes only
         # (fixed-length rows of one chunk: every fourth case channel-major -- the pipelined kernel's form, also on launches of one small batch)
         layout = "cl" if (want[0] and not RAGGED and not LONG and ci % 4 == 1) else "lc"
-        if not check(st, bt, want, layout):
+        # (bytes only, rows of one chunk: every other such case annotated -- the pipelined kernel's annotated form)
+        annotate = want == (False, True) and not LONG and ci % 2 == 0
+        if not check(st, bt, want, layout, annotate):
             bad += 1
             print(f"MISMATCH case {ci} (seed {seed0}) onehot, haps = {want}: L={bt.output_length} P={bt.meta['P']} q={bt.meta['B']} V/row={bt.mean_variants:.1f} "
                   f"shiftmax={bt.shifts.max()}", flush=True)
