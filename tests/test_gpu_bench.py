@@ -13,7 +13,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 REPO = Path(__file__).resolve().parent.parent
-SMALL = ["--scale", "small", "--queries", "16384", "--rotate", "8", "--min-region-ms", "2", "--cpu-budget", "1.5", "--no-secondary"]
+SMALL = ["--scale", "small", "--queries", "16384", "--rotate", "8", "--min-region-ms", "2", "--cpu-budget", "1.5", "--no-secondary",
+         "--max-leg-s", "1.5", "--sustained-s", "1"]
 
 
 def _free_port():
