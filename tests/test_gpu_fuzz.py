@@ -100,7 +100,7 @@ def test_fuzz_lean_kernel_long_rows(dbg, sub):
     _run("fuzz_lean.py", 120, 210 + sub + (dbg >> 15), dbg=dbg, FUZZ_LONG=1, FUZZ_SUB=sub)
 
 
-@pytest.mark.parametrize("dbg", [0, 2097152], ids=["default", "no-window"])
+@pytest.mark.parametrize("dbg", [0, 2097152, 1073741824], ids=["default", "no-window", "general-track-kernel"])
 def test_fuzz_tracks_straight_from_intervals(dbg):
     """tools/fuzz_fused_tracks.py: realign_tracks_kernel<PAINT> (BASELINE config 4's track kernel): a batch's tracks realigned
     straight from their intervals, `tile_complete` interval sets."""

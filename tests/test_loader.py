@@ -323,8 +323,9 @@ def test_threaded_loader_matches_inline_loader_and_survives_abandoned_epochs(ora
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dbg", [0, 1024, 8, 8192, 2097152, 4194304],
-                         ids=["default", "painter-without-bucket-index", "scalar-walk", "painter-image-path", "intervals-without-window", "painter-first"])
+@pytest.mark.parametrize("dbg", [0, 1024, 8, 8192, 2097152, 4194304, 1073741824],
+                         ids=["default", "painter-without-bucket-index", "scalar-walk", "painter-image-path", "intervals-without-window", "painter-first",
+                              "general-track-kernel"])
 def test_haps_tracks_dataset_matches_oracle(oracle, dbg):
     """cfg4's dataset shape at a small size: haplotypes + two realigned tracks per batch from dataset
     indices, against the oracle's fused paint + realign for the same request."""
@@ -440,8 +441,8 @@ def test_random_fill_seeds_are_per_batch_and_the_same_in_both_submit_loops():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dbg", [0, 1024, 8192, 2097152, 4194304],
-                         ids=["bucket-index", "exact-searches", "painter-image-path", "intervals-without-window", "painter-first"])
+@pytest.mark.parametrize("dbg", [0, 1024, 8192, 2097152, 4194304, 1073741824],
+                         ids=["bucket-index", "exact-searches", "painter-image-path", "intervals-without-window", "painter-first", "general-track-kernel"])
 def test_tracks_batch_long_rows_jitter_and_dense_lists(oracle, dbg):
     """gvl_tracks_batch on rows of many 2048-value chunks whose starts are not bucket aligned (jitter),
     with sparse, ordinary and very dense interval lists (a dense list overflows the painter's tile:
@@ -490,7 +491,7 @@ def test_tracks_batch_long_rows_jitter_and_dense_lists(oracle, dbg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dbg", [0, 268435456], ids=["row-plans", "every-chunk-walks"])
+@pytest.mark.parametrize("dbg", [0, 268435456, 1073741824], ids=["row-plans", "every-chunk-walks", "row-plans-general-track-kernel"])
 @pytest.mark.parametrize("python_loop", [False, True], ids=["epoch-table-plans", "per-call-plans"])
 @pytest.mark.parametrize("strategy,param", [(0, 0.0), (4, 3.0)], ids=["repeat5p", "interpolate"])
 def test_tracks_row_plans_rows_of_many_trips(oracle, dbg, python_loop, strategy, param):
