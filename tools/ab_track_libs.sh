@@ -14,7 +14,7 @@ python3 - $T $n $dbg <<'PY'
 import csv, sys, glob
 T, n, dbg = sys.argv[1:4]
 for r in csv.DictReader(open(glob.glob(f"{T}/s/**/*kernel_stats.csv", recursive=True)[0])):
-    if any(k in r["Name"] for k in ("realign_tracks_kernel", "recon_lean_kernel", "intervals_to_tracks_tiled")) and int(r["Calls"]) > 100:
+    if any(k in r["Name"] for k in ("realign_tracks_kernel", "realign_paint_kernel", "recon_lean_kernel", "intervals_to_tracks_tiled")) and int(r["Calls"]) > 100:
         print(f"lib {n} GVL_DBG={dbg}: {r['Name'].replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '')[:44]:44s} {float(r['AverageNs'])/1e3:.2f} us")
 PY
 rm -rf $T/s
