@@ -709,8 +709,8 @@ static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_o
         if (!out->annot_v_idxs || !out->annot_ref_pos || !out->haps || out->onehot || !st->slot_vidx || chunks != 1 || ((uintptr_t)st->slot_vidx & 15) ||
             (debug_flags() & (67108864 | 1073741824))) return false;
     }
-    // (channel-major one-hot: rows of one chunk only, and only the pipelined kernel has the form -- see lean_wants_pipe)
-    if (out->onehot && out->onehot_layout != GVL_ONEHOT_LC && (chunks != 1 || (debug_flags() & (67108864 | 1073741824)))) return false;
+    // (channel-major one-hot: the pipelined kernel's form for rows of one chunk, the chunked kernel's for long rows)
+    if (out->onehot && out->onehot_layout != GVL_ONEHOT_LC && ((chunks == 1 && (debug_flags() & 67108864)) || (debug_flags() & 1073741824))) return false;
     if (bt->out_offsets) return false;
     // (a keep mask: both arrays or neither; rows of one chunk only, and only the pipelined kernel reads one)
     if ((bt->keep != nullptr) != (bt->keep_offsets != nullptr)) return false;
@@ -780,7 +780,8 @@ int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *ou
     const int rc = fill_recon_args(st, bt, out, A, &chunks, &variant);
     if (rc) return rc;
     if (A.n_rows > 0 && lean_eligible(st, bt, out, chunks, A.chunk_len)) {
-        const bool pipe_only = A.oh_cl || A.keep || A.av;         // (only the pipelined kernel has the channel-major and annotated forms and reads keep masks)
+        // (rows of one chunk: only the pipelined kernel has the channel-major and annotated forms and reads keep masks)
+        const bool pipe_only = chunks == 1 && (A.oh_cl || A.keep || A.av);
         if (chunks == 1 && (lean_pipe_wanted(A.n_rows) || pipe_only) && lean_pipe_compatible(&A, 1)) return launch_lean_rows(&A, 1, stream, 1);
         if (pipe_only) return launch_recon(A, chunks, variant, stream);
         return launch_lean(A, chunks, stream);
@@ -811,7 +812,7 @@ int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_o
         lean[i] = A[i].n_rows > 0 && (lean_eligible(st, &bts[i], &outs[i], chunks[i], A[i].chunk_len) ||
                                       (!lean_rag_eligible(st, &bts[i], &outs[i]) && lean_long_rag_eligible(st, &bts[i], &outs[i], chunks[i], A[i].chunk_len)));
         all_one_chunk_lean = all_one_chunk_lean && lean[i] && chunks[i] == 1;
-        any_cl = any_cl || A[i].oh_cl || A[i].keep || A[i].av;
+        any_cl = any_cl || (chunks[i] == 1 && (A[i].oh_cl || A[i].keep || A[i].av));
         all_rag = all_rag && A[i].n_rows > 0 && lean_rag_eligible(st, &bts[i], &outs[i]);
         total += A[i].n_rows;
     }
@@ -823,7 +824,7 @@ int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_o
     }
     for (int i = 0; i < n; ++i) {
         int rc;
-        if (lean[i] && (A[i].oh_cl || A[i].keep || A[i].av))       // (channel-major one-hot, a keep mask: the pipelined kernel's forms, or the all-purpose kernel)
+        if (lean[i] && chunks[i] == 1 && (A[i].oh_cl || A[i].keep || A[i].av))       // (channel-major one-hot, a keep mask: the pipelined kernel's forms, or the all-purpose kernel)
             rc = lean_pipe_compatible(&A[i], 1) ? launch_lean_rows(&A[i], 1, stream, 1) : launch_recon(A[i], chunks[i], variant[i], stream);
         else
             rc = lean[i] ? launch_lean(A[i], chunks[i], stream) : launch_recon(A[i], chunks[i], variant[i], stream);

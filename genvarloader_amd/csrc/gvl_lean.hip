@@ -56,6 +56,9 @@ int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
         if (A.onehot && A.haps) recon_lean_kernel<true, true, true, true><<<g, b, 0, s>>>(A, RA);
         else if (A.onehot) recon_lean_kernel<true, false, true, true><<<g, b, 0, s>>>(A, RA);
         else recon_lean_kernel<false, true, true, true><<<g, b, 0, s>>>(A, RA);
+    } else if (chunks > 1 && RA.oh_cl) {      // channel-major one-hot (rows, 4, L)
+        if (A.haps) recon_lean_kernel<true, true, true, false, true><<<g, b, 0, s>>>(A, RA);
+        else recon_lean_kernel<true, false, true, false, true><<<g, b, 0, s>>>(A, RA);
     } else if (chunks > 1) {
         if (A.onehot && A.haps) recon_lean_kernel<true, true, true><<<g, b, 0, s>>>(A, RA);
         else if (A.onehot) recon_lean_kernel<true, false, true><<<g, b, 0, s>>>(A, RA);

@@ -399,6 +399,12 @@ def test_long_rows_chunked(gpu, oracle, kpath):
     st, bt = _synth(10, (1 << 18, 50_000), 7, 40_004, indel_frac=0.5, density=1 / 12, rc_frac=0.5, edge_frac=0.4,
                     random_shifts=True, max_indel=300)
     check_batch(gpu, oracle, st, bt)
+    # channel-major one-hot (rows, 4, L) of long rows: the chunked lean kernel's CL form (round 5); a last chunk of 4 / 1028 bases
+    check_batch(gpu, oracle, st, bt, layout="cl")
+    st, bt = _synth(11, (1 << 19,), 5, 131072, indel_frac=0.15, rc_frac=0.5, random_shifts=True)
+    check_batch(gpu, oracle, st, bt, layout="cl")
+    st, bt = _synth(12, (1 << 18,), 6, 7172, indel_frac=0.4, density=1 / 30, rc_frac=0.5, edge_frac=0.3)
+    check_batch(gpu, oracle, st, bt, layout="cl")
 
 
 def test_keep_mask(gpu, oracle, kpath):

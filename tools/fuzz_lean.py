@@ -197,7 +197,7 @@ if __name__ == "__main__":
         st, bt = one_case(rng)
         want = ((True, False), (True, True), (False, True))[ci % 3]         # one-hot only / one-hot + bytes / bytes only
         # (fixed-length rows of one chunk: every fourth case channel-major -- the pipelined kernel's form, also on launches of one small batch)
-        layout = "cl" if (want[0] and not RAGGED and not LONG and ci % 4 == 1) else "lc"
+        layout = "cl" if (want[0] and not RAGGED and ci % 4 == 1) else "lc"          # (long rows: the chunked kernel's channel-major form)
         # (bytes only, rows of one chunk: every other such case annotated -- the pipelined kernel's annotated form)
         annotate = want == (False, True) and not LONG and ci % 2 == 0
         if not check(st, bt, want, layout, annotate):
