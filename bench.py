@@ -404,6 +404,8 @@ def main() -> None:
     ap.add_argument("--strong", action="store_true", help="N > 1: split ONE batch across the ranks (strong scaling)")
     ap.add_argument("--gather", action="store_true", help="N > 1: also time the RCCL all-gather of the one-hot shards")
     ap.add_argument("--no-hot", action="store_true", help="skip the extra cache-hot kernel timing")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="gvl_set_tuning before anything is launched (A/B runs): pipe_rows_x100, pipe_min_rows, lean_sub, track_plan_max_mb, ragged_sizing")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short ragged-cfg3 and cfg4 legs of the default run (N = 1 only; `secondary` in the line)")
     args = ap.parse_args()
@@ -454,6 +456,15 @@ def main() -> None:
         assert dist.get_world_size() == args.gpus
 
     from genvarloader_amd import HapsDevice, sharding, synth
+
+    if args.tune:
+        from genvarloader_amd import _lib as _tl
+
+        keys = {"pipe_rows_x100": _tl.TUNE_PIPE_ROWS_X100, "pipe_min_rows": _tl.TUNE_PIPE_MIN_ROWS, "lean_sub": _tl.TUNE_LEAN_SUB,
+                "track_plan_max_mb": _tl.TUNE_TRACK_PLAN_MAX_MB, "ragged_sizing": _tl.TUNE_RAGGED_SIZING}
+        for kv in args.tune:
+            k_, v_ = kv.split("=")
+            _tl.set_tuning(keys[k_], int(v_))
 
     # ---- synthetic dataset (per rank; --strong: the same one on every rank) ---------------
     cfg_idx = int(args.workload[3:])
@@ -868,7 +879,7 @@ def main() -> None:
 
     lean = (dev.ref4 is not None and dev.slot_rec is not None and L <= 2048 and L % 4 == 0
             and (int(os.environ.get("GVL_DBG", "0")) & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 33554432 | 67108864)) == 0)
-    piped = (lean and G > 1 and K * G >= min(2048, int(os.environ.get("GVL_PIPE_MIN_ROWS", "8192")))
+    piped = (lean and G > 1 and K * G >= 2048
              and not (int(os.environ.get("GVL_DBG", "0")) & 67108864))
     if rank == 0:
         ms_per_step = region_ms / steps
