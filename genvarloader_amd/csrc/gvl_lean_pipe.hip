@@ -95,6 +95,8 @@ int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks) 
         if (hipMemsetAsync(ctr, 0, 4, s) != hipSuccess) return fail(GVL_ERR_HIP, "%s", "gvl_reconstruct (lean, dynamic rows): hipMemsetAsync failed");
         A.dyn_ctr = ctr;
         i64 w = tune(GVL_TUNE_PIPE_DYNAMIC);
+        const i64 w_min = (total + PIPE_MAX_ROWS - 5) / (PIPE_MAX_ROWS - 4);      // (a wave takes at most PIPE_MAX_ROWS rows: enough waves for all of them)
+        w = w < w_min ? w_min : w;
         w = w > total ? total : w;
         const dim3 gd((unsigned)((w + LEAN_WAVES - 1) / LEAN_WAVES));
         recon_lean_rows_kernel<true, false, false, false, false, true><<<gd, b, 0, s>>>(A, RA, M);
