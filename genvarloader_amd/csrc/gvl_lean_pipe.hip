@@ -89,13 +89,14 @@ int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks) 
         static u32 *ring = nullptr;
         static std::atomic<unsigned> next{0};
         static std::once_flag once;
-        std::call_once(once, [] { void *p = nullptr; if (hipMalloc(&p, 64 * 64) == hipSuccess) ring = (u32 *)p; else (void)hipGetLastError(); });
+        // (a launch: 64 counters, each on a 64-byte line of its own = 4 KB; a ring of 32 launches)
+        std::call_once(once, [] { void *p = nullptr; if (hipMalloc(&p, 32 * 4096) == hipSuccess) ring = (u32 *)p; else (void)hipGetLastError(); });
         if (!ring) return fail(GVL_ERR_HIP, "%s", "gvl_reconstruct (lean, dynamic rows): no counter memory");
-        u32 *const ctr = ring + 16 * (next.fetch_add(1) & 63u);
-        if (hipMemsetAsync(ctr, 0, 4, s) != hipSuccess) return fail(GVL_ERR_HIP, "%s", "gvl_reconstruct (lean, dynamic rows): hipMemsetAsync failed");
+        u32 *const ctr = ring + 1024 * (next.fetch_add(1) & 31u);
+        if (hipMemsetAsync(ctr, 0, 4096, s) != hipSuccess) return fail(GVL_ERR_HIP, "%s", "gvl_reconstruct (lean, dynamic rows): hipMemsetAsync failed");
         A.dyn_ctr = ctr;
         i64 w = tune(GVL_TUNE_PIPE_DYNAMIC);
-        const i64 w_min = (total + PIPE_MAX_ROWS - 5) / (PIPE_MAX_ROWS - 4);      // (a wave takes at most PIPE_MAX_ROWS rows: enough waves for all of them)
+        const i64 w_min = (total + 23) / 24;      // (a wave takes at most PIPE_MAX_ROWS = 32 rows: enough waves for all of them, with room for imbalance)
         w = w < w_min ? w_min : w;
         w = w > total ? total : w;
         const dim3 gd((unsigned)((w + LEAN_WAVES - 1) / LEAN_WAVES));
