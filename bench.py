@@ -461,7 +461,7 @@ def main() -> None:
         from genvarloader_amd import _lib as _tl
 
         keys = {"pipe_rows_x100": _tl.TUNE_PIPE_ROWS_X100, "pipe_min_rows": _tl.TUNE_PIPE_MIN_ROWS, "lean_sub": _tl.TUNE_LEAN_SUB,
-                "track_plan_max_mb": _tl.TUNE_TRACK_PLAN_MAX_MB, "ragged_sizing": _tl.TUNE_RAGGED_SIZING, "pipe_dynamic": _tl.TUNE_PIPE_DYNAMIC}
+                "track_plan_max_mb": _tl.TUNE_TRACK_PLAN_MAX_MB, "ragged_sizing": _tl.TUNE_RAGGED_SIZING}
         for kv in args.tune:
             k_, v_ = kv.split("=")
             _tl.set_tuning(keys[k_], int(v_))

@@ -83,24 +83,6 @@ int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks) 
     } else if (RA.oh_cl) {       // channel-major one-hot (rows, 4, L)
         if (A.haps) recon_lean_rows_kernel<true, true, false, true><<<g, b, 0, s>>>(A, RA, M);
         else recon_lean_rows_kernel<true, false, false, true><<<g, b, 0, s>>>(A, RA, M);
-    } else if (tune(GVL_TUNE_PIPE_DYNAMIC) > 0 && A.onehot && !A.haps && !(debug_flags() & 33554432)) {
-        // the experiment: a fixed number of waves, rows beyond a wave's first from a per-launch counter (a ring of counters, each
-        // zeroed on the launch's stream in front of it)
-        static u32 *ring = nullptr;
-        static std::atomic<unsigned> next{0};
-        static std::once_flag once;
-        // (a launch: 64 counters, each on a 64-byte line of its own = 4 KB; a ring of 32 launches)
-        std::call_once(once, [] { void *p = nullptr; if (hipMalloc(&p, 32 * 4096) == hipSuccess) ring = (u32 *)p; else (void)hipGetLastError(); });
-        if (!ring) return fail(GVL_ERR_HIP, "%s", "gvl_reconstruct (lean, dynamic rows): no counter memory");
-        u32 *const ctr = ring + 1024 * (next.fetch_add(1) & 31u);
-        if (hipMemsetAsync(ctr, 0, 4096, s) != hipSuccess) return fail(GVL_ERR_HIP, "%s", "gvl_reconstruct (lean, dynamic rows): hipMemsetAsync failed");
-        A.dyn_ctr = ctr;
-        i64 w = tune(GVL_TUNE_PIPE_DYNAMIC);
-        const i64 w_min = (total + 23) / 24;      // (a wave takes at most PIPE_MAX_ROWS = 32 rows: enough waves for all of them, with room for imbalance)
-        w = w < w_min ? w_min : w;
-        w = w > total ? total : w;
-        const dim3 gd((unsigned)((w + LEAN_WAVES - 1) / LEAN_WAVES));
-        recon_lean_rows_kernel<true, false, false, false, false, true><<<gd, b, 0, s>>>(A, RA, M);
     } else {
         if (A.onehot && A.haps) recon_lean_rows_kernel<true, true, false><<<g, b, 0, s>>>(A, RA, M);
         else if (A.onehot) recon_lean_rows_kernel<true, false, false><<<g, b, 0, s>>>(A, RA, M);

@@ -176,11 +176,9 @@ int gvl_set_debug_flags(int flags);
  *   GVL_TUNE_PIPE_MIN_ROWS       launches with fewer rows keep the wave-per-row kernel (built in: 8192; 2048 for groups).
  *   GVL_TUNE_LEAN_SUB            consecutive chunks of a long row one wave takes (built in: 2).
  *   GVL_TUNE_TRACK_PLAN_MAX_MB   row plans of an epoch larger than this are not kept (built in: 512).
- *   GVL_TUNE_RAGGED_SIZING       1: the native loader sizes ragged rows once per group of batches (round 4's way), not once per epoch.
- *   GVL_TUNE_PIPE_DYNAMIC        n > 0: an experiment (profiles/r05_dynamic_rows.txt) -- one-hot-only launches of the pipelined kernel run
- *                                n persistent waves whose rows are handed out by a per-launch counter instead of w, w + W, ... */
+ *   GVL_TUNE_RAGGED_SIZING       1: the native loader sizes ragged rows once per group of batches (round 4's way), not once per epoch. */
 enum { GVL_TUNE_PIPE_ROWS_X100 = 0, GVL_TUNE_PIPE_MIN_ROWS = 1, GVL_TUNE_LEAN_SUB = 2, GVL_TUNE_TRACK_PLAN_MAX_MB = 3, GVL_TUNE_RAGGED_SIZING = 4,
-       GVL_TUNE_PIPE_DYNAMIC = 5, GVL_TUNE_COUNT = 6 };
+       GVL_TUNE_COUNT = 5 };
 int gvl_set_tuning(int32_t key, int64_t value);
 const char *gvl_last_error(void);
 /* (The flag behind gvl_async_error is PROCESS-global: it says that some launch of this process met the

@@ -890,41 +890,6 @@ def test_bench_launch_every_row_vs_oracle(gpu, oracle, want, x100):
     assert 0.4 < n_rc / 65_536 < 0.6
 
 
-@pytest.mark.parametrize("waves", [8192, 2400, 60000], ids=["8192-waves", "rows-cap-waves", "more-waves-than-slots"])
-def test_dynamic_row_handout_vs_oracle(gpu, oracle, waves):
-    """The round's experiment (gvl_set_tuning(GVL_TUNE_PIPE_DYNAMIC)): rows beyond a wave's first are handed out by a per-launch
-    counter (scalar atomics).  16 x 4096 x 2048 one-hot rows in one grid, every batch against the oracle; rows the wave defers to the
-    all-purpose body find their numbers in the wave's list (a dataset with contig edges and dense rows in it)."""
-    from genvarloader_amd import HapsDevice, _lib, synth
-
-    ds = synth.GenomeDataset(device="cuda", contigs=(3_000_000, 40_000, 30_000), n_queries=40_000, seed=20260806, density=1 / 150)
-    dev = HapsDevice(**ds.static_kwargs())
-    hs = ds.host_static()
-    qsets = ds.draw_batches(16, 2048, seed=4)
-    bts, outs, keep = [], [], []
-    for q in qsets:
-        r = ds.request(q)
-        dbt = dev.prepare_batch(r["regions"], r["shifts"], r["geno_offset_idx"], ds.length, to_rc=r["to_rc"])
-        o, oc = dev.alloc_output(dbt, dbt.n_rows * ds.length, haps=False, onehot=True)
-        bts.append(dbt); outs.append(oc); keep.append(o)
-    _lib.check_async()
-    _lib.set_tuning(_lib.TUNE_PIPE_DYNAMIC, waves)
-    try:
-        for _ in range(2):                       # (twice: the counters are a ring, zeroed per launch)
-            dev.launch_many(dev.pack_many(bts, outs))
-        gpu.torch.cuda.synchronize()
-        _lib.check_async()
-    finally:
-        _lib.set_tuning(_lib.TUNE_PIPE_DYNAMIC, 0)
-    for i, q in enumerate(qsets):
-        hb = ds.host_batch(q)
-        _, _, exp_oh = oracle.reconstruct_haplotypes_fused(
-            hb.regions, hb.shifts, hb.geno_offset_idx, hb.geno_offsets, hb.geno_v_idxs, hs.v_starts, hs.ilens,
-            hs.alt_alleles, hs.alt_offsets, hs.ref, hs.ref_offsets, hs.pad_char, ds.length, None, None, hb.to_rc, True,
-            onehot=True, n_threads=8)
-        np.testing.assert_array_equal(keep[i].onehot.cpu().numpy(), exp_oh, err_msg=f"batch {i}")
-
-
 def test_slot_records_layout(gpu):
     """gvl_pack_slots: 8 records per slot, EMPTY padding, OVERFLOW for slots with more than 8 variants."""
     st, bt = _synth(41, (60_000,), 300, 600, indel_frac=0.3, density=1 / 60)
