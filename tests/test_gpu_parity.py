@@ -495,8 +495,8 @@ def test_ragged_mode(gpu, oracle, seed, kpath):
 
 def test_long_rows_with_the_callers_chunk_plans(gpu, oracle):
     """gvl_hap_plan: the chunk plans of long rows made ONCE over a table of request rows (what the native loader does per epoch) and
-    handed to launches over slices of that table as pointers into it (gvl_batch.hap_plan) == the launch's own plans == no plans ==
-    the oracle.  Rows of 20 chunks, dense enough that some chunks hold more than HP_ENT = 8 entries (flagged: their waves walk the
+    handed to launches over slices of that table as pointers into it (gvl_batch.hap_plan) == a launch without plans (the chunk-waves replay
+    the row's walk) == the oracle.  Rows of 20 chunks, dense enough that some chunks hold more than HP_ENT = 8 entries (flagged: their waves walk the
     row), insertions of hundreds of bases across chunk borders, shifts, windows over the contigs' edges."""
     from genvarloader_amd import _lib
 
@@ -523,7 +523,7 @@ def test_long_rows_with_the_callers_chunk_plans(gpu, oracle):
             gpu.torch.cuda.synchronize()
             np.testing.assert_array_equal(out.haps.cpu().numpy(), exp[a * P * L:b * P * L], err_msg=f"seed {seed} rows {a}:{b}")
             np.testing.assert_array_equal(out.onehot.cpu().numpy(), exp_oh[a * P * L:b * P * L], err_msg=f"seed {seed} rows {a}:{b}")
-        for flags in (0, 536870912):                        # the launch's own plans; none
+        for flags in (0, 536870912):                        # no caller's plan: the replay, with and without the plan route compiled in
             lib.gvl_set_debug_flags(flags)
             try:
                 out = dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, L, to_rc=bt.to_rc, haps=True, onehot=True)
