@@ -73,20 +73,31 @@ int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks) 
     const unsigned grid = (unsigned)((waves + LEAN_WAVES - 1) / LEAN_WAVES);
     const dim3 g(grid), b(LEAN_THREADS);
     hipStream_t s = (hipStream_t)stream;
+    // (launches without a keep mask that are not gvl_get_reference's: the forms with both compiled out; GVL_DBG & 1073741824 keeps the general ones)
+    bool km = A.ref_only != 0 || (A.dbg & 1073741824);
+    for (int i = 0; i < n; ++i) km = km || RAs[i].keep != nullptr || RAs[i].keep_offsets != nullptr;
     if (RA.av && RA.ap) {          // annotated haplotypes: bytes + the two annotation streams
         if (RA.out_offsets) recon_lean_rows_kernel<false, true, true, false, true><<<g, b, 0, s>>>(A, RA, M);
         else recon_lean_rows_kernel<false, true, false, false, true><<<g, b, 0, s>>>(A, RA, M);
-    } else if (RA.out_offsets) {
+    } else if (RA.out_offsets && km) {
         if (A.onehot && A.haps) recon_lean_rows_kernel<true, true, true><<<g, b, 0, s>>>(A, RA, M);
         else if (A.onehot) recon_lean_rows_kernel<true, false, true><<<g, b, 0, s>>>(A, RA, M);
         else recon_lean_rows_kernel<false, true, true><<<g, b, 0, s>>>(A, RA, M);
+    } else if (RA.out_offsets) {
+        if (A.onehot && A.haps) recon_lean_rows_kernel<true, true, true, false, false, false><<<g, b, 0, s>>>(A, RA, M);
+        else if (A.onehot) recon_lean_rows_kernel<true, false, true, false, false, false><<<g, b, 0, s>>>(A, RA, M);
+        else recon_lean_rows_kernel<false, true, true, false, false, false><<<g, b, 0, s>>>(A, RA, M);
     } else if (RA.oh_cl) {       // channel-major one-hot (rows, 4, L)
         if (A.haps) recon_lean_rows_kernel<true, true, false, true><<<g, b, 0, s>>>(A, RA, M);
         else recon_lean_rows_kernel<true, false, false, true><<<g, b, 0, s>>>(A, RA, M);
-    } else {
+    } else if (km) {
         if (A.onehot && A.haps) recon_lean_rows_kernel<true, true, false><<<g, b, 0, s>>>(A, RA, M);
         else if (A.onehot) recon_lean_rows_kernel<true, false, false><<<g, b, 0, s>>>(A, RA, M);
         else recon_lean_rows_kernel<false, true, false><<<g, b, 0, s>>>(A, RA, M);
+    } else {
+        if (A.onehot && A.haps) recon_lean_rows_kernel<true, true, false, false, false, false><<<g, b, 0, s>>>(A, RA, M);
+        else if (A.onehot) recon_lean_rows_kernel<true, false, false, false, false, false><<<g, b, 0, s>>>(A, RA, M);
+        else recon_lean_rows_kernel<false, true, false, false, false, false><<<g, b, 0, s>>>(A, RA, M);
     }
     return check_launch("gvl_reconstruct (lean, pipelined)");
 }

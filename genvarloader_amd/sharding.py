@@ -152,7 +152,7 @@ def all_gather_rows(local, row_lengths=None, group=None):
 
 
 def epoch_order(n: int, *, shuffle: bool, seed: int = 0, epoch: int = 0, rank: int = 0, world: int = 1,
-                drop_last: bool = False, device="cpu", generator=None):
+                drop_last: bool = False, device="cpu", generator=None, scratch_generator=None):
     """This rank's dataset indices for one epoch, as an int64 tensor on ``device``.
 
     The epoch is sharded across ranks the way ``torch.utils.data.DistributedSampler`` does it
@@ -160,7 +160,8 @@ def epoch_order(n: int, *, shuffle: bool, seed: int = 0, epoch: int = 0, rank: i
     every rank draws the SAME permutation (seeded by ``seed + epoch``), the list is padded by
     wrapping (or truncated with ``drop_last``) to a multiple of ``world``, and rank ``r`` takes
     elements ``r, r + world, ...`` -- disjoint, equal-sized, no collective.  With ``world == 1``
-    and a caller ``generator`` the permutation comes from that generator instead."""
+    and a caller ``generator`` the permutation comes from that generator instead.
+    ``scratch_generator``: a generator on ``device`` to re-seed and draw from instead of making a new one per call (same draws)."""
     import torch
 
     if not (0 <= rank < world):
@@ -170,7 +171,7 @@ def epoch_order(n: int, *, shuffle: bool, seed: int = 0, epoch: int = 0, rank: i
     elif generator is not None and world == 1:
         order = torch.randperm(n, generator=generator, device=generator.device).to(device)
     else:
-        g = torch.Generator(device=device)
+        g = scratch_generator if scratch_generator is not None else torch.Generator(device=device)
         g.manual_seed(int(seed) + int(epoch))
         order = torch.randperm(n, generator=g, device=device)
     if world == 1:
