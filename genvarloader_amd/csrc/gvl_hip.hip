@@ -899,6 +899,15 @@ int gvl_get_reference(const gvl_static *st, const int32_t *regions, int64_t regi
         A.async_err = async_err_word();
         return launch_lean_rows(&A, 1, stream, chunks);
     }
+    // Longer rows (`with_seqs("reference")` at Enformer length): the chunked lean kernel's ragged form, a wave per 2048-base chunk with
+    // no walk at all.  GVL_DBG 2^30 / 1048576: the all-purpose kernel.
+    if (st->ref4 && chunks >= 2 && A.chunk_len == LEAN_MAX_TRIPS * TRIP && n_rows * (i64)chunks <= 0x7FFFFFF0ll &&
+        st->ref_len < (1ll << 32) - 8192 && (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 33554432 | 67108864 | 268435456 | 536870912)) == 0) {
+        A.ref4 = st->ref4;
+        A.dbg = debug_flags();
+        A.async_err = async_err_word();
+        return launch_lean(A, chunks, stream);
+    }
     return launch_recon(A, chunks, (onehot ? OH_LC : OH_NONE) | (out ? 4 : 0), stream);
 }
 

@@ -18,6 +18,7 @@ static void fill_lean_args(LeanArgs &A, const ReconArgs &RA, int chunks) {
     A.n_rows = (int)RA.n_rows; A.n_contigs = RA.n_contigs; A.regions_stride = (int)RA.regions_stride;
     A.ploidy_shift = RA.ploidy_shift; A.ploidy = RA.ploidy; A.L = (int)RA.fixed_len; A.dbg = RA.dbg;
     A.chunks = chunks;
+    A.ref_only = RA.ref_only;
 }
 
 // The chunk plans of a batch's rows (hap_plan_kernel; rows of 2 .. HP_MAX_CHUNKS chunks, fixed length): `plan` holds

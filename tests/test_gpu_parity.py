@@ -614,6 +614,41 @@ def test_get_reference_synthetic(gpu, oracle, refpath):
     assert (exp2 == ord("r")).any()
 
 
+@pytest.mark.parametrize("flags", [0, 32768, 1073741824], ids=["chunked-lean", "every-chunk-solo", "all-purpose-kernel"])
+def test_get_reference_long_rows(gpu, oracle, flags):
+    """get_reference rows longer than the pipelined form's 2560 bases (`with_seqs("reference")` at Enformer length): the chunked
+    lean kernel's ragged form with no walk (a wave per 2048-base chunk) == its every-chunk-solo route == round 4's all-purpose
+    kernel == the oracle.  Lengths of any residue mod 4, rows across their contig's edges (padded), reverse-complemented rows,
+    empty rows, IUPAC bytes, rows in front of their contig."""
+    from genvarloader_amd import _lib
+
+    lib = _lib.load()
+    st, bt = _synth(52, (300_000, 70_000, 9), 60, 20_000, edge_frac=0.4, rc_frac=0.5)
+    rng = np.random.default_rng(10)
+    reg = bt.regions.copy()
+    reg[:, 2] = reg[:, 1] + rng.integers(2_052, 45_000, len(reg))
+    reg[::9, 2] = reg[::9, 1] - rng.integers(0, 5, len(reg[::9]))               # start >= stop: nothing written
+    reg[4::13, 1] = -rng.integers(4_000, 9_000, len(reg[4::13]))                 # start < stop < 0: all pad
+    reg[4::13, 2] = -rng.integers(1, 50, len(reg[4::13]))
+    ref2 = st.ref.copy()
+    ref2[rng.random(ref2.size) < 0.0005] = ord("r")
+    lens = np.clip(reg[:, 2].astype(np.int64) - reg[:, 1], 0, None)
+    oo = np.concatenate([[0], np.cumsum(lens)])
+    to_rc = reg[:, 3] == -1
+    exp = oracle.get_reference(reg, oo, ref2, st.ref_offsets, st.pad_char, True, to_rc)
+    assert (exp == ord("r")).any() and (lens > 40_000).any()
+    lib.gvl_set_debug_flags(flags)
+    try:
+        dev = gpu.ffi._ref_static(ref2, st.ref_offsets, st.pad_char)
+        out, oh = dev.get_reference(reg, oo, to_rc, onehot=True)
+        np.testing.assert_array_equal(out.cpu().numpy(), exp)
+        np.testing.assert_array_equal(oh.cpu().numpy(), oracle.onehot(exp))
+        out2 = dev.get_reference(reg, oo, to_rc)
+        np.testing.assert_array_equal(out2.cpu().numpy(), exp)
+    finally:
+        lib.gvl_set_debug_flags(-1)
+
+
 def test_get_diffs_modes(gpu, oracle):
     st, bt = _synth(61, (40_000,), 200, 500, indel_frac=0.5, density=1 / 15)
     idx = bt.geno_offset_idx.ravel()

@@ -200,7 +200,11 @@ if __name__ == "__main__":
         layout = "cl" if (want[0] and not RAGGED and ci % 4 == 1) else "lc"          # (long rows: the chunked kernel's channel-major form)
         # (bytes only, rows of one chunk: every other such case annotated -- the pipelined kernel's annotated form)
         annotate = want == (False, True) and not LONG and ci % 2 == 0
-        if not check(st, bt, want, layout, annotate):
+        tc = time.time()
+        ok = check(st, bt, want, layout, annotate)
+        if time.time() - tc > float(os.environ.get("FUZZ_SLOW_S", "1e9")):
+            print(f"slow case {ci}: {time.time() - tc:.1f} s  L={bt.output_length} P={bt.meta['P']} q={bt.meta['B']} V/row={bt.mean_variants:.1f} want={want} layout={layout}", flush=True)
+        if not ok:
             bad += 1
             print(f"MISMATCH case {ci} (seed {seed0}) onehot, haps = {want}: L={bt.output_length} P={bt.meta['P']} q={bt.meta['B']} V/row={bt.mean_variants:.1f} "
                   f"shiftmax={bt.shifts.max()}", flush=True)
