@@ -77,7 +77,9 @@ int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks) 
     bool km = A.ref_only != 0 || (A.dbg & 1073741824);
     for (int i = 0; i < n; ++i) km = km || RAs[i].keep != nullptr || RAs[i].keep_offsets != nullptr;
     if (RA.av && RA.ap) {          // annotated haplotypes: bytes + the two annotation streams
-        if (RA.out_offsets) recon_lean_rows_kernel<false, true, true, false, true><<<g, b, 0, s>>>(A, RA, M);
+        if (RA.out_offsets && A.onehot) recon_lean_rows_kernel<true, true, true, false, true><<<g, b, 0, s>>>(A, RA, M);
+        else if (RA.out_offsets) recon_lean_rows_kernel<false, true, true, false, true><<<g, b, 0, s>>>(A, RA, M);
+        else if (A.onehot) recon_lean_rows_kernel<true, true, false, false, true><<<g, b, 0, s>>>(A, RA, M);
         else recon_lean_rows_kernel<false, true, false, false, true><<<g, b, 0, s>>>(A, RA, M);
     } else if (RA.out_offsets && km) {
         if (A.onehot && A.haps) recon_lean_rows_kernel<true, true, true><<<g, b, 0, s>>>(A, RA, M);

@@ -122,8 +122,9 @@ def check_many(st, full, cuts, L, P, x100, want):
     from genvarloader_amd import _lib
 
     onehot, haps = want
-    annotate = haps and not onehot and x100 != 300       # (bytes only: annotated -- the pipelined kernel's annotated form in one grid)
     layout = full.meta.get("layout", "lc") if onehot else "lc"
+    # (bytes only: annotated -- the pipelined kernel's annotated form in one grid; bytes + row-major one-hot: annotated when x100 is 150 / 800)
+    annotate = haps and ((not onehot and x100 != 300) or (onehot and layout == "lc" and x100 in (150, 800)))
     dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens, alt_alleles=st.alt_alleles,
                      alt_offsets=st.alt_offsets, geno_offsets=full.geno_offsets, geno_v_idxs=full.geno_v_idxs, pad_char=st.pad_char)
     assert dev.ref4 is not None and dev.slot_rec is not None
@@ -198,8 +199,9 @@ if __name__ == "__main__":
         want = ((True, False), (True, True), (False, True))[ci % 3]         # one-hot only / one-hot + bytes / bytes only
         # (fixed-length rows of one chunk: every fourth case channel-major -- the pipelined kernel's form, also on launches of one small batch)
         layout = "cl" if (want[0] and not RAGGED and ci % 4 == 1) else "lc"          # (long rows: the chunked kernel's channel-major form)
-        # (bytes only, rows of one chunk: every other such case annotated -- the pipelined kernel's annotated form)
-        annotate = want == (False, True) and not LONG and ci % 2 == 0
+        # (bytes only, rows of one chunk: every other such case annotated -- the pipelined kernel's annotated form; bytes + row-major
+        # one-hot: every fourth)
+        annotate = not LONG and ((want == (False, True) and ci % 2 == 0) or (want == (True, True) and layout == "lc" and ci % 4 == 3))
         tc = time.time()
         ok = check(st, bt, want, layout, annotate)
         if time.time() - tc > float(os.environ.get("FUZZ_SLOW_S", "1e9")):
