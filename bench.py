@@ -461,7 +461,8 @@ def main() -> None:
         from genvarloader_amd import _lib as _tl
 
         keys = {"pipe_rows_x100": _tl.TUNE_PIPE_ROWS_X100, "pipe_min_rows": _tl.TUNE_PIPE_MIN_ROWS, "lean_sub": _tl.TUNE_LEAN_SUB,
-                "track_plan_max_mb": _tl.TUNE_TRACK_PLAN_MAX_MB, "ragged_sizing": _tl.TUNE_RAGGED_SIZING}
+                "track_plan_max_mb": _tl.TUNE_TRACK_PLAN_MAX_MB, "ragged_sizing": _tl.TUNE_RAGGED_SIZING,
+                "hap_plan_max_mb": _tl.TUNE_HAP_PLAN_MAX_MB}
         for kv in args.tune:
             k_, v_ = kv.split("=")
             _tl.set_tuning(keys[k_], int(v_))
@@ -768,7 +769,8 @@ def main() -> None:
                 gpus, steps, warmup, min_region_ms, max_regions = 1, 20, 5, 1200.0, 400
             c4 = bench_cfg4.measure(_A, init_dist=False)
             secondary["cfg4"] = {
-                "workload": c4["config"]["workload"], "ms_per_step": c4["ms_per_step"], "windows_per_s": c4["value"],
+                "workload": c4["config"]["workload"], "dataset": c4["config"]["dataset"], "inputs": c4["config"]["inputs"],
+                "ms_per_step": c4["ms_per_step"], "windows_per_s": c4["value"],
                 "step_frac": c4["roofline"]["step_frac"], "step_GBps": c4["roofline"]["step_GBps"],
                 "step_algorithmic_bytes": c4["roofline"]["step_algorithmic_bytes"],
                 "kernel_ms": c4["roofline"]["kernel_ms"], "kernel": c4["roofline"]["kernel"], "kernel_frac": c4["roofline"]["frac"],
@@ -777,6 +779,27 @@ def main() -> None:
         except Exception as exc:
             secondary["cfg4"] = {"error": repr(exc)}
         secondary["cfg4_s"] = round(time.perf_counter() - t_s, 2)
+        # ... and the same step on a dataset whose inputs do NOT stay in the Infinity Cache (16 regions x 512 samples: 390 MB of
+        # intervals alone; the leg above reads a 70 MB dataset that does): what a training set of real size pays per batch.  Such
+        # an epoch goes without haplotype chunk plans (they cost more than the walks they save once they have to come from HBM:
+        # profiles/r05_cfg4_plans_vs_size.txt).
+        t_s = time.perf_counter()
+        try:
+            if "cfg4_cold" in skip:
+                raise RuntimeError("skipped (GVL_BENCH_SKIP)")
+            import argparse as _ap
+
+            import bench_cfg4
+            _A = _ap.Namespace(gpus=1, steps=20, warmup=5, min_region_ms=600.0, max_regions=400, samples=512)
+            c4 = bench_cfg4.measure(_A, init_dist=False)
+            secondary["cfg4_cold"] = {
+                "ms_per_step": c4["ms_per_step"], "windows_per_s": c4["value"], "step_frac": c4["roofline"]["step_frac"],
+                "step_GBps": c4["roofline"]["step_GBps"], "step_algorithmic_bytes": c4["roofline"]["step_algorithmic_bytes"],
+                "workload": c4["config"]["workload"], "dataset": c4["config"]["dataset"], "inputs": c4["config"]["inputs"],
+                "input_bytes": c4["config"]["input_bytes"], "loop": c4["config"]["loop"], "steps": c4["steps"], "regions": c4["timing"]["regions"]}
+        except Exception as exc:
+            secondary["cfg4_cold"] = {"error": repr(exc)}
+        secondary["cfg4_cold_s"] = round(time.perf_counter() - t_s, 2)
         # ---- the reference's other output modes on cfg3's rows, each under the same schedule as the headline (groups of G batches
         # per gvl_reconstruct_many call, `--streams` calls in flight, rotating cold batches): annotated haplotypes (a11,
         # src/ffi/mod.rs:2237-2397), rows under an exonic keep mask (src/genotypes/mod.rs:132-176: the spliced path's every batch),

@@ -84,7 +84,7 @@ def measure(args, init_dist=True):
         import torch.distributed as dist
 
         dist.init_process_group(backend, **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
-    R, S, P, L = int(os.environ.get("GVL_CFG4_R", 16)), int(os.environ.get("GVL_CFG4_S", 64)), 2, 131072
+    R, S, P, L = int(os.environ.get("GVL_CFG4_R", 16)), int(getattr(args, "samples", 0) or os.environ.get("GVL_CFG4_S", 64)), 2, 131072
     st, dev, ds, tracks, mean_v = build(f"cuda:{local}", R, S, P, L, seed=20260802 + 4 + 1000 * rank)
     bs = int(os.environ.get("GVL_CFG4_BS", 128))                # queries per batch = 256 windows
     order = np.random.default_rng(1).permutation(R * S)
@@ -223,6 +223,9 @@ def measure(args, init_dist=True):
         gdev._stream_ptr()))
     if rank == 0:
         hap_bytes = (L * 6 + 28.0 * mean_v + 61.0) * K
+        gv_n = dev.geno_v_idxs.numel() if getattr(dev, "geno_v_idxs", None) is not None else 0
+        hp_all = int(lib.gvl_hap_plan_bytes(C.c_int64(R * S * P), C.c_int64(L)))
+        hap_plan_epoch = hp_all if 0 < hp_all <= (64 << 20) and not (dbg & 536870912) else 0        # (the loader's cap: GVL_TUNE_HAP_PLAN_MAX_MB)
         realign_bytes = 4.0 * float(toff[-1]) + 4.0 * K * L
         paint_bytes = 4.0 * float(toff[-1]) + 12.0 * n_itv_batch
         ms_step = wall / steps * 1e3
@@ -235,6 +238,11 @@ def measure(args, init_dist=True):
                                    "+ 1 track painted from intervals and realigned (Repeat5p)",
                        "windows_per_step_per_rank": K, "length_bp": L, "ploidy": P, "mean_variants_per_window": round(mean_v, 1),
                        "dataset": f"{R} regions x {S} samples, 256 Mbp contig, {int(a.numel())} intervals",
+                       # (what a batch reads besides the reference: its queries' interval lists, genotype records and plans.  A small
+                       # dataset's stay in the 256 MB Infinity Cache from one epoch to the next; secondary.cfg4_cold's do not)
+                       "input_bytes": {"intervals": 12 * int(a.numel()), "epoch_hap_plans": hap_plan_epoch, "genotype_records": 16 * int(gv_n)},
+                       "inputs": ("resident in the 256 MB Infinity Cache (every query comes round again within a few batches)"
+                                  if 12 * int(a.numel()) + 2 * hap_plan_epoch + 16 * int(gv_n) < (200 << 20) else "from HBM (the dataset does not fit the Infinity Cache)"),
                        "batches_in_flight": len(streams) if loop != "native" else dl.in_flight * dl.group,
                        "loop": "native ring (gvl_loader_*)" if loop == "native" else "python submit loop", "parallelism": f"world_size {world}: one batch per rank per step"},
             "timing": {"how": "median of K-step regions between barrier + synchronize, host clock", "regions": len(spans)},

@@ -176,9 +176,12 @@ int gvl_set_debug_flags(int flags);
  *   GVL_TUNE_PIPE_MIN_ROWS       launches with fewer rows keep the wave-per-row kernel (built in: 8192; 2048 for groups).
  *   GVL_TUNE_LEAN_SUB            consecutive chunks of a long row one wave takes (built in: 2).
  *   GVL_TUNE_TRACK_PLAN_MAX_MB   row plans of an epoch larger than this are not kept (built in: 512).
- *   GVL_TUNE_RAGGED_SIZING       1: the native loader sizes ragged rows once per group of batches (round 4's way), not once per epoch. */
+ *   GVL_TUNE_RAGGED_SIZING       1: the native loader sizes ragged rows once per group of batches (round 4's way), not once per epoch.
+ *   GVL_TUNE_HAP_PLAN_MAX_MB     haplotype chunk plans of an epoch larger than this are not made (built in: 64 -- they pay while they
+ *                                stay in the 256 MB Infinity Cache next to the epoch's other inputs, and cost more than the walks
+ *                                they save beyond it: profiles/r05_cfg4_plans_vs_size.txt). */
 enum { GVL_TUNE_PIPE_ROWS_X100 = 0, GVL_TUNE_PIPE_MIN_ROWS = 1, GVL_TUNE_LEAN_SUB = 2, GVL_TUNE_TRACK_PLAN_MAX_MB = 3, GVL_TUNE_RAGGED_SIZING = 4,
-       GVL_TUNE_COUNT = 5 };
+       GVL_TUNE_HAP_PLAN_MAX_MB = 5, GVL_TUNE_COUNT = 6 };
 int gvl_set_tuning(int32_t key, int64_t value);
 const char *gvl_last_error(void);
 /* (The flag behind gvl_async_error is PROCESS-global: it says that some launch of this process met the

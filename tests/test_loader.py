@@ -796,6 +796,52 @@ def test_loader_onehot_only_goes_through_the_lean_kernel(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["lc", "cl"])
+def test_loader_long_fixed_rows_with_and_without_epoch_chunk_plans(oracle, layout):
+    """Fixed-length rows of several chunks through the native ring (config 4's haplotype half), one-hot row-major and channel-major:
+    with the epoch's chunk plans (gvl_hap_plan over the epoch table), without them (GVL_DBG 536870912), and with the plans' size
+    cap below the epoch's (gvl_set_tuning(GVL_TUNE_HAP_PLAN_MAX_MB): a large dataset's epochs go without plans) == the oracle."""
+    from genvarloader_amd import HapsDevice, _lib
+    from genvarloader_amd.loader import DeviceHapsDataset
+
+    R, S, P, L = 5, 6, 2, 6_148
+    st, full_regions, go, gv = _grid_dataset(23, R, S, P, L, indel_frac=0.3)
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+    assert dev.ref4 is not None and dev.geno_rec is not None
+    idx = np.arange(R * S)
+    r_idx, s_idx = np.unravel_index(idx, (R, S))
+    goi = np.ravel_multi_index((r_idx[:, None], s_idx[:, None], np.arange(P)), (R, S, P))
+    exp, _, exp_oh = oracle.reconstruct_haplotypes_fused(
+        full_regions[r_idx], np.zeros_like(goi, dtype=np.int32), goi, go, gv, st.v_starts, st.ilens, st.alt_alleles,
+        st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, L, None, None, np.repeat(full_regions[r_idx, 3] == -1, P), False,
+        onehot=True)
+    exp = exp.reshape(R * S, P, L)
+    exp_oh = exp_oh.reshape(R * S, P, L, 4)
+    if layout == "cl":
+        exp_oh = exp_oh.transpose(0, 1, 3, 2)
+    lib = _lib.load()
+    try:
+        for flags, cap_mb in ((0, 0), (536870912, 0), (0, 1)):
+            lib.gvl_set_debug_flags(flags)
+            _lib.set_tuning(_lib.TUNE_HAP_PLAN_MAX_MB, cap_mb)        # (the epoch's plans: 60 rows x 4 chunks x 272 B, far below 1 MB ...)
+            ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, onehot=True, haps=True, layout=layout)
+            seen = 0
+            for epoch in range(2):
+                for b in ds.to_dataloader(batch_size=7, shuffle=True, seed=3):
+                    oh, hp = b.onehot.cpu().numpy(), b.haps.cpu().numpy()
+                    for i, q in enumerate(b.idx.cpu().numpy().tolist()):
+                        np.testing.assert_array_equal(hp[i], exp[q], err_msg=f"flags {flags} cap {cap_mb} query {q}")
+                        np.testing.assert_array_equal(oh[i], exp_oh[q], err_msg=f"flags {flags} cap {cap_mb} query {q}")
+                        seen += 1
+            assert seen == 2 * R * S
+    finally:
+        lib.gvl_set_debug_flags(-1)
+        _lib.set_tuning(_lib.TUNE_HAP_PLAN_MAX_MB, 0)
+
+
+@pytest.mark.gpu
 def test_tracks_tile_complete_claim_is_checked():
     """gvl_track_set.tile_complete lets the tracks be realigned straight from the intervals (and the painter, where it
     still runs, skip its second launch).  The dataset only sets it for interval sets that qualify (no overlaps, distinct
