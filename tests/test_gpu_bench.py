@@ -70,6 +70,11 @@ def test_bench_secondary_legs():
     assert "error" not in rg and "error" not in c4, sec
     assert rg["ms_per_step"] > 0 and 0 < rg["step_frac"] < 1 and rg["epochs_timed"] >= 2 and rg["batches_per_epoch"] == 8
     assert c4["ms_per_step"] > 0 and 0 < c4["step_frac"] < 1 and c4["kernel_ms"] > 0 and "131072" in c4["workload"]
+    # ... and the same step on a dataset of 512 samples per region (the leg says where each dataset's inputs come from)
+    cold = sec["cfg4_cold"]
+    assert "error" not in cold, cold
+    assert cold["ms_per_step"] > 0 and 0 < cold["step_frac"] < 1 and "512 samples" in cold["dataset"] and "64 samples" in c4["dataset"]
+    assert c4["inputs"] and cold["inputs"] and cold["input_bytes"]["intervals"] > 4 * 12 * 100_000
     assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]          # the headline is cfg3's
     # the reference's other output modes + the reference-only fetch + training mode, each a driver-timed leg
     for name in ("onehot_cl", "annotated", "keep_mask", "reference", "random_shifts"):
