@@ -703,10 +703,10 @@ static int fill_recon_args(const gvl_static *st, const gvl_batch *bt, const gvl_
 // into 2048-base chunks): one wave per chunk, variants from the CSR's inline records (LONG).
 static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_out *out, int chunks, int chunk_len) {
     if (!st->ref4 || (!out->onehot && !out->haps)) return false;
-    // (annotated haplotypes: bytes + BOTH annotation streams (+ row-major one-hot), rows of one chunk, the slot records' variant indices present;
+    // (annotated haplotypes: bytes + BOTH annotation streams (+ a one-hot in either layout), rows of one chunk, the slot records' variant indices present;
     // only the pipelined kernel has the form)
     if (out->annot_v_idxs || out->annot_ref_pos) {
-        if (!out->annot_v_idxs || !out->annot_ref_pos || !out->haps || (out->onehot && out->onehot_layout != GVL_ONEHOT_LC) || !st->slot_vidx || chunks != 1 ||
+        if (!out->annot_v_idxs || !out->annot_ref_pos || !out->haps || !st->slot_vidx || chunks != 1 ||
             ((uintptr_t)st->slot_vidx & 15) || (debug_flags() & (67108864 | 1073741824))) return false;
     }
     // (channel-major one-hot: the pipelined kernel's form for rows of one chunk, the chunked kernel's for long rows)

@@ -79,6 +79,7 @@ int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks) 
     if (RA.av && RA.ap) {          // annotated haplotypes: bytes + the two annotation streams
         if (RA.out_offsets && A.onehot) recon_lean_rows_kernel<true, true, true, false, true><<<g, b, 0, s>>>(A, RA, M);
         else if (RA.out_offsets) recon_lean_rows_kernel<false, true, true, false, true><<<g, b, 0, s>>>(A, RA, M);
+        else if (A.onehot && RA.oh_cl) recon_lean_rows_kernel<true, true, false, true, true><<<g, b, 0, s>>>(A, RA, M);
         else if (A.onehot) recon_lean_rows_kernel<true, true, false, false, true><<<g, b, 0, s>>>(A, RA, M);
         else recon_lean_rows_kernel<false, true, false, false, true><<<g, b, 0, s>>>(A, RA, M);
     } else if (RA.out_offsets && km) {

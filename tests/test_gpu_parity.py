@@ -275,6 +275,16 @@ def test_cfg2_full(gpu, oracle, layout, kpath):
     check_batch(gpu, oracle, st, bt, layout=layout)
 
 
+@pytest.mark.parametrize("layout", ["lc", "cl"])
+def test_annotated_next_to_a_onehot(gpu, oracle, layout, kpath):
+    """Annotated haplotypes (bytes + variant index + reference coordinate per base, src/ffi/mod.rs:2237-2397) with a one-hot in either
+    layout next to them -- the pipelined kernel's <OH, HAPS, .., CL, ANN> forms -- on rows with indels, shifts, reverse-complemented rows and
+    rows over their contig's edges, lengths that end in a partial 16-base group."""
+    for seed, L in ((41, 2048), (42, 1_996), (43, 260)):
+        st, bt = _synth(seed, (60_000, 90_001), 120, L, indel_frac=0.3, density=1 / 35, rc_frac=0.5, random_shifts=True, edge_frac=0.15)
+        check_batch(gpu, oracle, st, bt, layout=layout, annotate=True)
+
+
 def test_cfg3_full_with_properties(gpu, oracle, kpath):
     from genvarloader_amd import synth
 

@@ -124,7 +124,7 @@ def check_many(st, full, cuts, L, P, x100, want):
     onehot, haps = want
     layout = full.meta.get("layout", "lc") if onehot else "lc"
     # (bytes only: annotated -- the pipelined kernel's annotated form in one grid; bytes + row-major one-hot: annotated when x100 is 150 / 800)
-    annotate = haps and ((not onehot and x100 != 300) or (onehot and layout == "lc" and x100 in (150, 800)))
+    annotate = haps and ((not onehot and x100 != 300) or (onehot and x100 in (150, 800)))          # (either one-hot layout)
     dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens, alt_alleles=st.alt_alleles,
                      alt_offsets=st.alt_offsets, geno_offsets=full.geno_offsets, geno_v_idxs=full.geno_v_idxs, pad_char=st.pad_char)
     assert dev.ref4 is not None and dev.slot_rec is not None
@@ -201,7 +201,7 @@ if __name__ == "__main__":
         layout = "cl" if (want[0] and not RAGGED and ci % 4 == 1) else "lc"          # (long rows: the chunked kernel's channel-major form)
         # (bytes only, rows of one chunk: every other such case annotated -- the pipelined kernel's annotated form; bytes + row-major
         # one-hot: every fourth)
-        annotate = not LONG and ((want == (False, True) and ci % 2 == 0) or (want == (True, True) and layout == "lc" and ci % 4 == 3))
+        annotate = not LONG and ((want == (False, True) and ci % 2 == 0) or (want == (True, True) and ci % 4 in (1, 3)))     # (ci % 4 == 1: channel-major)
         tc = time.time()
         ok = check(st, bt, want, layout, annotate)
         if time.time() - tc > float(os.environ.get("FUZZ_SLOW_S", "1e9")):
