@@ -39,6 +39,7 @@ SYMBOLS = (
     "gvl_hap_offsets",
     "gvl_paint_tracks",
     "gvl_get_reference",
+    "gvl_get_reference_many",
     "gvl_keep_offsets",
     "gvl_choose_exonic_variants",
     "gvl_rc_rows",
@@ -63,7 +64,7 @@ SYMBOLS = (
     "gvl_loader_destroy",
 )
 
-ABI_VERSION = 9          # include/gvl_hip.h: GVL_ABI_VERSION
+ABI_VERSION = 10         # include/gvl_hip.h: GVL_ABI_VERSION
 TUNE_PIPE_ROWS_X100, TUNE_PIPE_MIN_ROWS, TUNE_LEAN_SUB, TUNE_TRACK_PLAN_MAX_MB, TUNE_RAGGED_SIZING, TUNE_HAP_PLAN_MAX_MB = 0, 1, 2, 3, 4, 5     # GVL_TUNE_*
 GVL_ONEHOT_LC = 0
 GVL_ONEHOT_CL = 1
@@ -95,6 +96,14 @@ class GvlOut(C.Structure):
     _fields_ = [
         ("haps", _vp), ("onehot", _vp), ("onehot_layout", C.c_int32),
         ("annot_v_idxs", _vp), ("annot_ref_pos", _vp), ("out_offsets", _vp),
+    ]
+
+
+class GvlRefBatch(C.Structure):
+    """``gvl_ref_batch``: one batch of ``gvl_get_reference_many``."""
+    _fields_ = [
+        ("regions", _vp), ("regions_stride", _i64), ("n_rows", _i64), ("out_offsets", _vp), ("max_row_len", _i64),
+        ("to_rc", _vp), ("out", _vp), ("onehot", _vp),
     ]
 
 

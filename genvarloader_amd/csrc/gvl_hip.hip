@@ -911,6 +911,39 @@ int gvl_get_reference(const gvl_static *st, const int32_t *regions, int64_t regi
     return launch_recon(A, chunks, (onehot ? OH_LC : OH_NONE) | (out ? 4 : 0), stream);
 }
 
+int gvl_get_reference_many(const gvl_static *st, const gvl_ref_batch *bs, int32_t n, void *stream) {
+    if (!st || n < 0 || n > GVL_MANY_MAX || (n > 0 && !bs)) return fail(GVL_ERR_INVALID, "%s", "gvl_get_reference_many: bad arguments (n <= GVL_MANY_MAX)");
+    // one grid over the group when every batch could take the pipelined route on its own and they share a shape
+    ReconArgs A[GVL_MANY_MAX];
+    bool grouped = n >= 2 && st->ref4 && !((uintptr_t)st->ref4 & 15) && st->ref_offsets && st->ref_len < (1ll << 32) - 8192 &&
+                   (debug_flags() & ~(2 | 4 | 32768 | 65536 | 33554432 | 268435456 | 536870912)) == 0;
+    int min_chunks = 0x7FFFFFFF;
+    for (int i = 0; i < n && grouped; ++i) {
+        const gvl_ref_batch &b = bs[i];
+        if (b.n_rows <= 0 || b.n_rows > 0x7FFFFFF0ll || !b.regions || !b.out_offsets || b.regions_stride < 3 || (!b.out && !b.onehot) ||
+            b.max_row_len <= 0 || b.max_row_len > (i64)PIPE_RAG_MAXT * TRIP) { grouped = false; break; }
+        ReconArgs &R = A[i];
+        memset(&R, 0, sizeof(R));
+        R.ref = st->ref; R.ref_len = st->ref_len; R.ref_offsets = (const i64 *)st->ref_offsets; R.ref4 = st->ref4;
+        R.regions = b.regions; R.regions_stride = b.regions_stride;
+        R.n_contigs = (int)(st->n_contigs < 0 ? 0 : (st->n_contigs > 0x7FFFFFFFll ? 0x7FFFFFFF : st->n_contigs));
+        R.to_rc = b.to_rc; R.out_offsets = (const i64 *)b.out_offsets; R.fixed_len = -1;
+        R.n_rows = b.n_rows; R.ploidy = 1; R.ploidy_shift = 0;
+        int chunks = 1;
+        if (pick_chunk(b.max_row_len, &chunks, &R.chunk_len)) { grouped = false; break; }
+        min_chunks = chunks < min_chunks ? chunks : min_chunks;
+        R.ref_only = 1; R.pad = st->pad_char; R.haps = b.out; R.onehot = b.onehot;
+        R.dbg = debug_flags(); R.async_err = async_err_word();
+    }
+    if (grouped && lean_pipe_compatible(A, n)) return launch_lean_rows(A, n, stream, min_chunks);
+    for (int i = 0; i < n; ++i) {
+        const int rc = gvl_get_reference(st, bs[i].regions, bs[i].regions_stride, bs[i].n_rows, bs[i].out_offsets, bs[i].max_row_len, bs[i].to_rc,
+                                         bs[i].out, bs[i].onehot, stream);
+        if (rc) return rc;
+    }
+    return GVL_OK;
+}
+
 int gvl_get_diffs_sparse(const gvl_static *st, const gvl_batch *bt, const int32_t *q_starts,
                          const int32_t *q_ends, int64_t q_stride, int32_t *diffs, void *stream) {
     DiffArgs D;

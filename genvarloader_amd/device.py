@@ -377,6 +377,34 @@ class HapsDevice:
             return (out, oh) if onehot else out
 
 
+def _get_reference_many(self, batches, *, onehot=False, haps=True):
+    """``gvl_get_reference_many``: up to 16 batches of regions in ONE launch.  ``batches``: a list of ``(regions, out_offsets, to_rc |
+    None, total, max_row_len)`` with device tensors (``total`` = ``out_offsets[-1]``, ``max_row_len`` = a bound on the rows' lengths,
+    both host ints: no synchronisation here) -> a list of ``(bytes | None, one-hot | None)`` device tensors, one pair per batch."""
+    d = self.device
+    n = len(batches)
+    arr = (_lib.GvlRefBatch * n)()
+    outs, keep = [], []
+    with torch.cuda.device(d):
+        for i, (regions, out_offsets, to_rc, total, max_row_len) in enumerate(batches):
+            reg = _dev(regions, torch.int32, d)
+            oo = _dev(out_offsets, torch.int64, d)
+            rc = _dev(to_rc, torch.uint8, d)
+            o = torch.empty(int(total), dtype=torch.uint8, device=d) if haps else None
+            oh = torch.empty((int(total), 4), dtype=torch.uint8, device=d) if onehot else None
+            arr[i] = _lib.GvlRefBatch(regions=reg.data_ptr(), regions_stride=reg.shape[1], n_rows=reg.shape[0], out_offsets=oo.data_ptr(),
+                                      max_row_len=int(max_row_len), to_rc=None if rc is None else rc.data_ptr(),
+                                      out=None if o is None else o.data_ptr(), onehot=None if oh is None else oh.data_ptr())
+            outs.append((o, oh)); keep.append((reg, oo, rc))
+        _lib.check(self.lib.gvl_get_reference_many(C.byref(self.c), arr, C.c_int32(n), _stream_ptr()))
+    for (o, oh), k in zip(outs, keep):          # (the request arrays must outlive the asynchronous launch)
+        (o if o is not None else oh)._keepalive = k
+    return outs
+
+
+HapsDevice.get_reference_many = _get_reference_many
+
+
 def rc_flat_rows_inplace(data: torch.Tensor, offsets, to_rc) -> None:
     """rc_flat_rows_inplace (reverse.rs:56-69) on a device u8 tensor."""
     lib = _lib.load()

@@ -38,7 +38,7 @@ def test_header_symbols_all_exported(lib):
     assert sorted(_lib.SYMBOLS) == decl
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in gvl_hip.h but not exported"
-    assert lib.gvl_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.gvl_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_header_enums_match_the_python_mirror(lib):
@@ -65,7 +65,7 @@ def test_ctypes_structs_match_c_layout(tmp_path):
 
     structs = {"gvl_static": _lib.GvlStatic, "gvl_batch": _lib.GvlBatch, "gvl_out": _lib.GvlOut,
                "gvl_loader_config": _lib.GvlLoaderConfig, "gvl_loader_batch": _lib.GvlLoaderBatch,
-               "gvl_track_set": _lib.GvlTrackSet}
+               "gvl_track_set": _lib.GvlTrackSet, "gvl_ref_batch": _lib.GvlRefBatch}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

@@ -1081,3 +1081,34 @@ def test_static_upload_for_hosts_without_an_allocator(gpu, oracle):
         np.testing.assert_array_equal(haps.cpu().numpy(), exp)
         np.testing.assert_array_equal(oh.cpu().numpy(), exp_oh)
         _lib.check(lib.gvl_static_free(dst))
+
+
+def test_get_reference_many_batches_one_grid(gpu, oracle, refpath):
+    """gvl_get_reference_many: several batches of regions in ONE launch == a gvl_get_reference per batch == the oracle; batches of
+    different sizes (the last one shorter), rows over their contigs' edges, reverse-complemented rows; a group whose batches do not
+    share a shape (one with rows beyond 2560 bases) runs batch by batch."""
+    st, bt = _synth(53, (40_000, 15_000, 7), 500, 700, edge_frac=0.3, rc_frac=0.5)
+    dev = gpu.ffi._ref_static(st.ref, st.ref_offsets, st.pad_char)
+    reg = bt.regions
+    cuts = [(0, 150), (150, 300), (300, 450), (450, 500)]
+
+    def group(regs):
+        bs, exp = [], []
+        for r in regs:
+            lens = np.clip(r[:, 2].astype(np.int64) - r[:, 1], 0, None)
+            oo = np.concatenate([[0], np.cumsum(lens)])
+            to_rc = r[:, 3] == -1
+            exp.append(oracle.get_reference(r, oo, st.ref, st.ref_offsets, st.pad_char, True, to_rc))
+            bs.append((r, oo, to_rc, int(oo[-1]), int(lens.max())))
+        return bs, exp
+
+    for regs in ([reg[a:b] for a, b in cuts], [reg[:150], np.concatenate([reg[150:299], reg[299:300] * np.array([1, 1, 0, 1]) + np.array([0, 0, reg[299, 1] + 3_000, 0])]).astype(np.int32)]):
+        bs, exp = group(regs)
+        for kw in (dict(onehot=True, haps=True), dict(onehot=False, haps=True), dict(onehot=True, haps=False)):
+            outs = dev.get_reference_many(bs, **kw)
+            gpu.torch.cuda.synchronize()
+            for (o, oh), e in zip(outs, exp):
+                if kw["haps"]:
+                    np.testing.assert_array_equal(o.cpu().numpy(), e)
+                if kw["onehot"]:
+                    np.testing.assert_array_equal(oh.cpu().numpy(), oracle.onehot(e))

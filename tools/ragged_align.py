@@ -50,7 +50,10 @@ def measure(Lr, ragged):
 
 
 base = None
-for Lr, rag in ((2048, False), (2048, True), (2052, True), (2064, True), (2080, True), (2112, True), (2048, False)):
+CASES = ((2048, False), (2048, True), (2052, True), (2064, True), (2080, True), (2112, True), (2048, False))
+if os.environ.get("DECIMAL"):      # fixed-length rows whose one-hot is not a multiple of 128 bytes, through the fixed form and through the ragged one
+    CASES = ((2000, False), (2000, True), (1000, False), (1000, True), (500, False), (500, True), (2048, False), (1024, False))
+for Lr, rag in CASES:
     us = measure(Lr, rag)
     out_b = Lr * 4096 * ((4 if W_O else 0) + (1 if W_H else 0))
     per_kb = us / (out_b / 1e6)
