@@ -62,9 +62,12 @@ SYMBOLS = (
     "gvl_loader_start_epoch",
     "gvl_loader_next",
     "gvl_loader_destroy",
+    "gvl_svar2_workspace_bytes",
+    "gvl_svar2_merge",
+    "gvl_svar2_reconstruct",
 )
 
-ABI_VERSION = 10         # include/gvl_hip.h: GVL_ABI_VERSION
+ABI_VERSION = 11         # include/gvl_hip.h: GVL_ABI_VERSION
 TUNE_PIPE_ROWS_X100, TUNE_PIPE_MIN_ROWS, TUNE_LEAN_SUB, TUNE_TRACK_PLAN_MAX_MB, TUNE_RAGGED_SIZING, TUNE_HAP_PLAN_MAX_MB = 0, 1, 2, 3, 4, 5     # GVL_TUNE_*
 GVL_ONEHOT_LC = 0
 GVL_ONEHOT_CL = 1
@@ -89,6 +92,7 @@ class GvlBatch(C.Structure):
         ("regions", _vp), ("regions_stride", _i64), ("shifts", _vp), ("geno_offset_idx", _vp),
         ("batch", _i64), ("ploidy", _i64), ("keep", _vp), ("keep_offsets", _vp), ("to_rc", _vp),
         ("output_length", _i64), ("out_offsets", _vp), ("max_row_len", _i64), ("hap_plan", _vp),
+        ("out_bounds", _vp),
     ]
 
 
@@ -104,6 +108,16 @@ class GvlRefBatch(C.Structure):
     _fields_ = [
         ("regions", _vp), ("regions_stride", _i64), ("n_rows", _i64), ("out_offsets", _vp), ("max_row_len", _i64),
         ("to_rc", _vp), ("out", _vp), ("onehot", _vp),
+    ]
+
+
+class GvlSvar2Batch(C.Structure):
+    """``gvl_svar2_batch``: one batch of DECODED SVAR2 channels (device pointers)."""
+    _fields_ = [
+        ("vk_pos", _vp), ("vk_ilen", _vp), ("vk_alt_off", _vp), ("vk_off", _vp), ("n_vk", _i64),
+        ("dense_pos", _vp), ("dense_ilen", _vp), ("dense_alt_off", _vp), ("n_dense", _i64),
+        ("dense_range", _vp), ("dense_present", _vp), ("dense_present_bits", _i64), ("dense_present_off", _vp),
+        ("alt_bytes", _vp), ("alt_len", _i64), ("filter_exonic", C.c_int32),
     ]
 
 
@@ -210,7 +224,7 @@ def load() -> C.CDLL:
         if fn is None:
             raise GvlError(f"{p} does not export {name}")
         if name not in ("gvl_last_error", "gvl_loader_slot_bytes", "gvl_loader_table_bytes", "gvl_tracks_scratch_bytes",
-                        "gvl_ref4_bytes", "gvl_hap_plan_bytes"):
+                        "gvl_ref4_bytes", "gvl_hap_plan_bytes", "gvl_svar2_workspace_bytes"):
             fn.restype = C.c_int
     lib.gvl_loader_slot_bytes.restype = C.c_int64
     lib.gvl_loader_table_bytes.restype = C.c_int64
@@ -218,6 +232,8 @@ def load() -> C.CDLL:
     lib.gvl_ref4_bytes.restype = C.c_int64
     lib.gvl_hap_plan_bytes.restype = C.c_int64
     lib.gvl_hap_plan_bytes.argtypes = [C.c_int64, C.c_int64]
+    lib.gvl_svar2_workspace_bytes.restype = C.c_int64
+    lib.gvl_svar2_workspace_bytes.argtypes = [C.c_int64] * 5
     lib.gvl_ref4_bytes.argtypes = [C.c_int64]
     lib.gvl_set_tuning.argtypes = [C.c_int32, C.c_int64]
     _LIB = lib

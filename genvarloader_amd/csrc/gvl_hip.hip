@@ -491,6 +491,9 @@ int gvl_async_error(int clear) {
     if (e == 1) return fail(GVL_ERR_INVALID, "%s", "a launch found a row longer than its batch's max_row_len hint: that row was left partly unwritten");
     if (e == 2) return fail(GVL_ERR_INVALID, "%s", "an interval set marked tile_complete has a chunk with overlapping intervals, equal starts or more than 256 candidates: that chunk was left unpainted");
     if (e == 3) return fail(GVL_ERR_INVALID, "%s", "a pipelined launch gave a wave more rows than it can take (grid mis-sized): the surplus rows were left unwritten");
+    if (e == 4) return fail(GVL_ERR_INVALID, "%s", "gvl_svar2_merge: a haplotype with more than 64 entries in a channel is not position-sorted: its records are unspecified");
+    if (e == 5) return fail(GVL_ERR_INVALID, "%s", "gvl_svar2_merge: a negative position (positions are u32 below 2^31)");
+    if (e == 6) return fail(GVL_ERR_INVALID, "%s", "gvl_svar2_merge: channel offsets (vk_off / dense_range / dense_present_off / allele offsets) leave their arrays: that haplotype got no variants");
     return e ? fail(GVL_ERR_INVALID, "%s", "asynchronous device-side error") : GVL_OK;
 }
 
@@ -647,11 +650,13 @@ static int fill_recon_args(const gvl_static *st, const gvl_batch *bt, const gvl_
         return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: NULL variant table (vrec from gvl_pack_variants is required)");
     if (bt->batch > 0 && (!bt->regions || !bt->shifts || !bt->geno_offset_idx || bt->regions_stride < 3))
         return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: NULL/invalid batch array");
-    if (bt->output_length < 0 && !bt->out_offsets)
-        return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: ragged mode needs out_offsets (gvl_hap_offsets)");
+    if (bt->out_bounds && bt->out_offsets)
+        return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: out_offsets and out_bounds are exclusive");
+    if (bt->output_length < 0 && !bt->out_offsets && !bt->out_bounds)
+        return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: ragged mode needs out_offsets (gvl_hap_offsets) or out_bounds");
     if (bt->output_length > 0x7FFFFF00ll || bt->max_row_len > 0x7FFFFF00ll)
         return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: row length must be < 2^31 - 256");
-    if (out->onehot && out->onehot_layout == GVL_ONEHOT_CL && (bt->output_length < 0 || bt->out_offsets))
+    if (out->onehot && out->onehot_layout == GVL_ONEHOT_CL && (bt->output_length < 0 || bt->out_offsets || bt->out_bounds))
         return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_reconstruct: channel-major one-hot needs fixed-length rows");
     if (out->onehot_layout != GVL_ONEHOT_LC && out->onehot_layout != GVL_ONEHOT_CL)
         return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: bad onehot_layout");
@@ -674,21 +679,24 @@ static int fill_recon_args(const gvl_static *st, const gvl_batch *bt, const gvl_
     A.regions = bt->regions; A.regions_stride = bt->regions_stride; A.shifts = bt->shifts;
     A.geno_offset_idx = (const i64 *)bt->geno_offset_idx;
     A.keep = bt->keep; A.keep_offsets = (const i64 *)bt->keep_offsets; A.to_rc = bt->to_rc;
-    A.out_offsets = (const i64 *)bt->out_offsets;
-    A.fixed_len = bt->out_offsets ? -1 : bt->output_length;
+    // (rows at (start, end) pairs -- gvl_batch.out_bounds -- are read through the same pointer with a stride of two)
+    const bool ragged_rows = bt->out_offsets || bt->out_bounds;
+    A.out_offsets = (const i64 *)(bt->out_bounds ? bt->out_bounds : bt->out_offsets);
+    A.oo_shift = bt->out_bounds ? 1 : 0;
+    A.fixed_len = ragged_rows ? -1 : bt->output_length;
     A.n_rows = bt->batch * bt->ploidy; A.ploidy = (int)bt->ploidy; A.ploidy_shift = log2_exact(bt->ploidy);
     // longest row: fixed mode -> output_length; caller-supplied offsets -> the
     // caller's max_row_len hint (must bound every row, or longer rows are left
     // partly unwritten)
-    i64 ml = bt->out_offsets ? bt->max_row_len : bt->output_length;
-    if (bt->out_offsets && bt->output_length > ml) ml = bt->output_length;
+    i64 ml = ragged_rows ? bt->max_row_len : bt->output_length;
+    if (ragged_rows && bt->output_length > ml) ml = bt->output_length;
     if (ml < 0) ml = 0;
     if (pick_chunk(ml, chunks, &A.chunk_len)) return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: too many chunks");
     A.ref_only = 0;
     A.dbg = debug_flags();
     A.pad = st->pad_char;
     A.haps = out->haps; A.onehot = out->onehot;
-    A.av = out->annot_v_idxs; A.ap = out->annot_ref_pos; A.out_offsets_w = (i64 *)out->out_offsets;
+    A.av = out->annot_v_idxs; A.ap = out->annot_ref_pos; A.out_offsets_w = bt->out_bounds ? nullptr : (i64 *)out->out_offsets;
     A.stamps = g_stamps;
     A.async_err = async_err_word();
     const bool annot = out->annot_v_idxs || out->annot_ref_pos;
@@ -779,6 +787,7 @@ int gvl_reconstruct(const gvl_static *st, const gvl_batch *bt, const gvl_out *ou
     int chunks = 1, variant = 0;
     const int rc = fill_recon_args(st, bt, out, A, &chunks, &variant);
     if (rc) return rc;
+    if (bt->out_bounds) return launch_recon(A, chunks, variant, stream);      // (scatter write: the all-purpose kernel's row setup reads the pairs)
     if (A.n_rows > 0 && lean_eligible(st, bt, out, chunks, A.chunk_len)) {
         // (rows of one chunk: only the pipelined kernel has the channel-major and annotated forms and reads keep masks)
         const bool pipe_only = chunks == 1 && (A.oh_cl || A.keep || A.av);
@@ -809,11 +818,11 @@ int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_o
         chunks[i] = 1; variant[i] = 0;
         const int rc = fill_recon_args(st, &bts[i], &outs[i], A[i], &chunks[i], &variant[i]);
         if (rc) return rc;
-        lean[i] = A[i].n_rows > 0 && (lean_eligible(st, &bts[i], &outs[i], chunks[i], A[i].chunk_len) ||
+        lean[i] = A[i].n_rows > 0 && !bts[i].out_bounds && (lean_eligible(st, &bts[i], &outs[i], chunks[i], A[i].chunk_len) ||
                                       (!lean_rag_eligible(st, &bts[i], &outs[i]) && lean_long_rag_eligible(st, &bts[i], &outs[i], chunks[i], A[i].chunk_len)));
         all_one_chunk_lean = all_one_chunk_lean && lean[i] && chunks[i] == 1;
         any_cl = any_cl || (chunks[i] == 1 && (A[i].oh_cl || A[i].keep || A[i].av));
-        all_rag = all_rag && A[i].n_rows > 0 && lean_rag_eligible(st, &bts[i], &outs[i]);
+        all_rag = all_rag && A[i].n_rows > 0 && !bts[i].out_bounds && lean_rag_eligible(st, &bts[i], &outs[i]);
         total += A[i].n_rows;
     }
     if (all_one_chunk_lean && (lean_pipe_wanted(total, n) || any_cl) && lean_pipe_compatible(A, n)) return launch_lean_rows(A, n, stream, 1);
@@ -842,7 +851,7 @@ int64_t gvl_hap_plan_bytes(int64_t n_rows, int64_t output_length) {
 
 int gvl_hap_plan(const gvl_static *st, const gvl_batch *bt, void *plan, void *stream) {
     if (!st || !bt || !plan) return fail(GVL_ERR_INVALID, "%s", "gvl_hap_plan: NULL argument");
-    if (bt->keep || bt->keep_offsets || bt->out_offsets) return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_hap_plan: fixed-length rows without a keep mask only");
+    if (bt->keep || bt->keep_offsets || bt->out_offsets || bt->out_bounds) return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_hap_plan: fixed-length rows without a keep mask only");
     if (bt->batch < 0 || bt->ploidy <= 0 || bt->batch * bt->ploidy > 0x7FFFFFF0ll) return fail(GVL_ERR_INVALID, "%s", "gvl_hap_plan: bad batch / ploidy");
     if (bt->batch == 0) return GVL_OK;
     if (gvl_hap_plan_bytes(bt->batch * bt->ploidy, bt->output_length) <= 0)

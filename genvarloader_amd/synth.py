@@ -491,3 +491,84 @@ def make_genome(scale: str = "small", workload: str = "cfg3", device="cuda", see
     return GenomeDataset(device=device, contigs=contigs or cg, n_queries=n_queries or nq, length=cfg["length"],
                          indel_frac=cfg["indel_frac"], rc_frac=cfg["rc_frac"],
                          seed=20260802 + idx if seed is None else seed)
+
+
+# --- SVAR2 two-source form of a batch ------------------------------------------------
+@dataclass
+class SynthSvar2:
+    """One batch as DECODED SVAR2 channels (``reconstruct_haplotypes_from_svar2``, src/ffi/mod.rs:874-893, with the key
+    arguments in the form ``decode_alt`` gives them, src/svar2/mod.rs:17-30)."""
+
+    vk_pos: np.ndarray
+    vk_ilen: np.ndarray
+    vk_alt_off: np.ndarray
+    vk_off: np.ndarray
+    dense_pos: np.ndarray
+    dense_ilen: np.ndarray
+    dense_alt_off: np.ndarray
+    dense_range: np.ndarray
+    dense_present: np.ndarray
+    dense_present_off: np.ndarray
+    alt_bytes: np.ndarray
+
+    def args(self):
+        """Positional arguments between ``shifts`` and ``ref_`` of the SVAR2 entry points."""
+        return (self.vk_pos, self.vk_ilen, self.vk_alt_off, self.vk_off, self.dense_pos, self.dense_ilen, self.dense_alt_off,
+                self.dense_range, self.dense_present, self.dense_present_off, self.alt_bytes)
+
+
+def _alleles_of(st: SynthStatic, v: np.ndarray, base: int):
+    """Decoded alleles of variants ``v``: ALT bytes, or EMPTY for a deletion (the generator's deletions carry the anchor base
+    only, which is what the SVAR2 provider substitutes for a pure deletion's empty allele).  -> (offsets n + 1 from `base`, bytes)."""
+    v = np.asarray(v, np.int64)
+    a0 = st.alt_offsets[v]
+    ln = np.where(st.ilens[v] < 0, 0, st.alt_offsets[v + 1] - a0).astype(np.int64)
+    off = np.zeros(len(v) + 1, np.int64)
+    np.cumsum(ln, out=off[1:])
+    tot = int(off[-1])
+    src = np.repeat(a0 - off[:-1], ln) + np.arange(tot)
+    return off + base, st.alt_alleles[src] if tot else np.zeros(0, np.uint8)
+
+
+def to_svar2(rng: np.random.Generator, st: SynthStatic, bt: SynthBatch, dense_af: float = 0.35, extra: float = 0.5) -> SynthSvar2:
+    """The same haplotypes as ``(st, bt)`` in two-channel form: per query the variants with AF >= ``dense_af`` carried by any
+    of its haplotypes -- plus ``extra`` x as many neighbours NO haplotype carries (absent bits) -- are its ``dense`` window
+    (presence bits per haplotype); everything else a haplotype carries is a ``var_key`` call.  Windows and calls are in
+    table order = position order inside a contig."""
+    B, P = bt.geno_offset_idx.shape
+    go, gv = bt.geno_offsets, bt.geno_v_idxs
+    vk_l, vk_cnt, d_l, d_rng, bits_l, bits_off = [], [], [], [], [], [0]
+    n_dense = 0
+    nv = len(st.v_starts)
+    for q in range(B):
+        rows = [gv[go[0, o]:go[1, o]].astype(np.int64) for o in bt.geno_offset_idx[q]]
+        union = np.unique(np.concatenate(rows)) if rows else np.zeros(0, np.int64)
+        dense = union[st.af[union] >= dense_af] if len(union) else union
+        if len(union) and extra > 0:
+            lo, hi = int(union[0]), int(union[-1])
+            cand = np.setdiff1d(np.arange(max(lo - 2, 0), min(hi + 3, nv)), union)
+            cand = cand[st.v_contig[cand] == st.v_contig[union[0]]]
+            k = min(len(cand), int(np.ceil(extra * max(len(dense), 1))))
+            if k:
+                dense = np.union1d(dense, rng.choice(cand, k, replace=False))
+        d_l.append(dense)
+        d_rng.append((n_dense, n_dense + len(dense)))
+        n_dense += len(dense)
+        for r in rows:
+            in_d = np.isin(r, dense)
+            vk_l.append(r[~in_d])
+            vk_cnt.append(int((~in_d).sum()))
+            bits_l.append(np.isin(dense, r))
+            bits_off.append(bits_off[-1] + len(dense))
+    vk = np.concatenate(vk_l) if vk_l else np.zeros(0, np.int64)
+    dn = np.concatenate(d_l) if d_l else np.zeros(0, np.int64)
+    bits = np.concatenate(bits_l) if bits_l else np.zeros(0, np.bool_)
+    vk_off = np.zeros(B * P + 1, np.int64)
+    np.cumsum(vk_cnt, out=vk_off[1:])
+    vk_alt_off, vk_bytes = _alleles_of(st, vk, 0)
+    d_alt_off, d_bytes = _alleles_of(st, dn, len(vk_bytes))
+    return SynthSvar2(
+        vk_pos=st.v_starts[vk].astype(np.int32), vk_ilen=st.ilens[vk].astype(np.int32), vk_alt_off=vk_alt_off, vk_off=vk_off,
+        dense_pos=st.v_starts[dn].astype(np.int32), dense_ilen=st.ilens[dn].astype(np.int32), dense_alt_off=d_alt_off,
+        dense_range=np.asarray(d_rng, np.int32).reshape(B, 2), dense_present=np.packbits(bits, bitorder="little"),
+        dense_present_off=np.asarray(bits_off, np.int64), alt_bytes=np.concatenate([vk_bytes, d_bytes]))

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GVL_ABI_VERSION 10
+#define GVL_ABI_VERSION 11
 
 enum {
     GVL_OK = 0,
@@ -150,6 +150,13 @@ typedef struct gvl_batch {
     const void *hap_plan;          /* nullable: the chunk plans of THESE rows (gvl_hap_plan over exactly these
                                       request arrays; fixed-length rows longer than 2048 bases).  NULL: every
                                       chunk-wave of the launch walks its row itself */
+    const int64_t *out_bounds;     /* nullable (ABI 11): i64 (batch*ploidy, 2), row k is written at [start, end) =
+                                      out_bounds[k] of the outputs -- rows anywhere, in any order, pairwise disjoint
+                                      (the scatter write of reconstruct_haplotypes_from_svar2, src/reconstruct/mod.rs:
+                                      619-826, whose spliced callers interleave one contig group's rows with another's).
+                                      Replaces out_offsets (which must then be NULL); max_row_len bounds the rows as for
+                                      out_offsets.  Disjointness is the caller's contract, as it is the Rust core's
+                                      (the PyO3 layer checks it on the host: src/ffi/mod.rs:101-139). */
 } gvl_batch;
 
 /* Outputs; any of the data pointers may be NULL (that output is skipped), but
@@ -597,6 +604,70 @@ int64_t gvl_loader_table_bytes(const gvl_loader_config *cfg, int64_t n, int64_t 
  * for the next batch.  Never blocks the host.  out->slot == -1 when the epoch is over. */
 int gvl_loader_next(gvl_loader *ld, void *consumer_stream, gvl_loader_batch *out);
 int gvl_loader_destroy(gvl_loader *ld);
+
+/* ---- SVAR2 two-source variant provider (ABI 11) ------------------------------------------------------------
+ *
+ * The reference's second genotype source (src/svar2/mod.rs): a haplotype's variants are the merge of its `var_key` calls
+ * (CSR vk_off, one slice per haplotype) with the PRESENT entries of its query's `dense` window (dense_range per query,
+ * LSB-first presence bits per haplotype), position-sorted and stable -- var_key first on ties (merge_hap,
+ * src/svar2/mod.rs:45-72).  In the reference every entry is (position, 32-bit key) and a key is decoded by the third-party
+ * crate svar2-codec (a git dependency, not part of the reference's tree; its bit layout is not stated anywhere in it).
+ * This boundary takes the channels DECODED -- the integrator, who links the codec, runs decode_key once per entry --
+ * in the form the reference itself gives a decoded key (decode_alt, src/svar2/mod.rs:17-30; VariantsSoa, :292-306):
+ *     entry e:  v_diff = ilen[e],  allele = alt_bytes[alt_off[e] .. alt_off[e + 1])
+ * with an EMPTY allele for a pure deletion (the kernels then use the anchor base ref[pos], as the reference's provider
+ * does: src/reconstruct/mod.rs:712-733).  Both channels' alleles live in one pool `alt_bytes`; each channel has its own
+ * n + 1 offsets into it.
+ *
+ * gvl_svar2_merge turns one batch of channels into a per-batch sparse table in the caller's workspace -- per haplotype a
+ * contiguous run of 16-byte records (gvl_grec) + its slot line (gvl_srec), the variant table behind them, and
+ * geno_offset_idx = 0 .. batch*ploidy-1 -- and fills `merged`, a HOST gvl_static that points at it (and at st's
+ * reference arrays).  Every entry point of this header that reads a gvl_static then works on the batch unchanged:
+ *     hap_diffs_svar2 (src/svar2/mod.rs:78-160)                   = gvl_get_diffs_sparse(merged, ...) in query mode
+ *     reconstruct_haplotypes_from_svar2 (src/ffi/mod.rs:874-997)  = gvl_hap_offsets + gvl_reconstruct(merged, ...)
+ *     shift_and_realign_tracks_from_svar2 (src/ffi/mod.rs:1835-)  = gvl_hap_offsets + gvl_realign_tracks(merged, ...)
+ * filter_exonic != 0 drops the entries that do not lie entirely inside their query's [start, end)
+ * (src/reconstruct/mod.rs:699-706, src/svar2/mod.rs:131-133) during the merge.
+ *
+ * Contract (the reference's own: genoray emits position-sorted runs, src/svar2/mod.rs:373-378): inside a haplotype's
+ * var_key slice and inside a dense window positions do not decrease; positions are < 2^31.  A haplotype with at most 64
+ * var_key entries and a window of at most 64 entries is merged by rank counting and needs neither; a longer one that is
+ * not sorted, a negative position, or offsets that leave their arrays are reported by gvl_async_error() (that
+ * haplotype's records are then unspecified, never out of bounds).
+ * The table is valid until the workspace is reused; `merged` holds no ownership.  (The merged table's alt_offsets are
+ * allele STARTS only -- lengths live in the records -- so the gvl_pack_* builders must not be run on it.) */
+typedef struct gvl_svar2_batch {
+    const int32_t *vk_pos;            /* n_vk */
+    const int32_t *vk_ilen;           /* n_vk: decoded v_diff */
+    const int64_t *vk_alt_off;        /* n_vk + 1: allele of entry i = alt_bytes[vk_alt_off[i] .. vk_alt_off[i + 1]) */
+    const int64_t *vk_off;            /* batch*ploidy + 1: haplotype k owns var_key entries [vk_off[k], vk_off[k + 1]) */
+    int64_t n_vk;
+    const int32_t *dense_pos;         /* n_dense */
+    const int32_t *dense_ilen;        /* n_dense */
+    const int64_t *dense_alt_off;     /* n_dense + 1 */
+    int64_t n_dense;
+    const int32_t *dense_range;       /* (batch, 2): query q's window = dense entries [ds, de) */
+    const uint8_t *dense_present;     /* presence bits, LSB first inside a byte (src/svar2/mod.rs:35-39) */
+    int64_t dense_present_bits;       /* bits in dense_present (>= dense_present_off[batch*ploidy]) */
+    const int64_t *dense_present_off; /* batch*ploidy + 1 BIT offsets: bit dense_present_off[k] + j = haplotype k carries
+                                         entry ds + j of its query's window */
+    const uint8_t *alt_bytes;         /* the allele pool */
+    int64_t alt_len;
+    int32_t filter_exonic;
+} gvl_svar2_batch;
+
+int64_t gvl_svar2_workspace_bytes(int64_t batch, int64_t ploidy, int64_t n_vk, int64_t dense_present_bits, int64_t alt_len);
+/* regions i32 (batch, regions_stride >= 3) [contig, start, end]: the contig of a pure deletion's anchor base and the
+ * exonic filter's bounds.  workspace: gvl_svar2_workspace_bytes(...) bytes of device memory, 256-byte aligned.
+ * merged (HOST, out): the batch's table; geno_offset_idx (HOST pointer to a device pointer, out): i64 (batch, ploidy). */
+int gvl_svar2_merge(const gvl_static *st, const gvl_svar2_batch *sv, const int32_t *regions, int64_t regions_stride,
+                    int64_t batch, int64_t ploidy, void *workspace, int64_t workspace_bytes, gvl_static *merged,
+                    const int64_t **geno_offset_idx, void *stream);
+/* gvl_svar2_merge + gvl_reconstruct in one call: bt as for gvl_reconstruct (geno_offset_idx is ignored; fixed-length rows,
+ * rows at out_offsets or at out_bounds; keep masks and annotations are not part of the SVAR2 path:
+ * src/reconstruct/mod.rs:746-749). */
+int gvl_svar2_reconstruct(const gvl_static *st, const gvl_svar2_batch *sv, const gvl_batch *bt, const gvl_out *out,
+                          void *workspace, int64_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

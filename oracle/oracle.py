@@ -438,3 +438,210 @@ def build_splice_plan(lengths, splice_row_offsets, n_samples: int, n_rows: int) 
     inner = tuple(lengths.shape[1:])
     return dict(permutation=perm, permuted_lengths=permuted_lengths, permuted_out_offsets=out_offsets,
                 group_offsets=group_offsets, out_shape=(int(n_rows), int(n_samples), *inner, None))
+
+
+# ----------------------------------------------------------------------------- SVAR2 two-source provider (8 f4)
+# The reference's entry points take (position, 32-bit key) channels and decode keys with the un-vendored crate
+# `svar2-codec`.  What the reference states itself is what a decoded key IS (`decode_alt`, src/svar2/mod.rs:17-30);
+# keys are therefore SYMBOLIC here -- ("inline", b"T"), ("pure_del", -2), ("lookup", row), the three constructors its
+# tests use (encode_alt_inline / encode_pure_del / encode_lookup) -- and the channels cross every boundary DECODED:
+# entry e has v_diff ilen[e] and the allele alt_bytes[alt_off[e] : alt_off[e + 1]] (empty = a pure deletion).
+def decode_alt(key, lut_bytes=b"", lut_off=(0,)):
+    """``decode_alt`` (src/svar2/mod.rs:17-30) over a symbolic key -> (v_diff, allele bytes)."""
+    kind, val = key
+    if kind == "inline":                      # DecodedKey::Inline { alt } -> (alt.len() - 1, alt)
+        alt = bytes(val)
+        return len(alt) - 1, alt
+    if kind == "pure_del":                    # DecodedKey::PureDel { ilen } -> (ilen, empty)
+        return int(val), b""
+    if kind == "lookup":                      # DecodedKey::Lookup { row } -> LUT row
+        s, e = int(lut_off[int(val)]), int(lut_off[int(val) + 1])
+        alt = bytes(bytearray(lut_bytes)[s:e])
+        return len(alt) - 1, alt
+    raise ValueError(f"unknown key kind {kind!r}")
+
+
+def decode_channels(vk_keys, dense_keys, lut_bytes=b"", lut_off=(0,)):
+    """Decode both channels' symbolic keys into the flat form every SVAR2 entry point here takes:
+    ``dict(vk_ilen, vk_alt_off, dense_ilen, dense_alt_off, alt_bytes)`` -- one shared allele pool, var_key alleles first."""
+    pool = bytearray()
+    out = {}
+    for name, keys in (("vk", vk_keys), ("dense", dense_keys)):
+        ilen = np.zeros(len(keys), np.int32)
+        off = np.zeros(len(keys) + 1, np.int64)
+        for i, k in enumerate(keys):
+            d, alt = decode_alt(k, lut_bytes, lut_off)
+            ilen[i] = d
+            off[i] = len(pool)
+            pool += alt
+            off[i + 1] = len(pool)
+        if len(keys) == 0:
+            off[0] = len(pool)
+        out[name + "_ilen"], out[name + "_alt_off"] = ilen, off
+    out["alt_bytes"] = np.frombuffer(bytes(pool), np.uint8).copy()
+    return out
+
+
+def merge_hap(vk_pos, vk_lo, vk_hi, dense_pos, ds, de, dense_present, base_bit):
+    """``merge_hap`` (src/svar2/mod.rs:45-72) -> (positions u32, sources): source >= 0 is var_key entry `source`,
+    source < 0 is dense entry ``-(source + 1)``."""
+    vk_pos, dense_pos = _c(vk_pos, np.int32), _c(dense_pos, np.int32)
+    bits = _c(dense_present, np.uint8)
+    cap = int(vk_hi - vk_lo) + int(de - ds)
+    pos = np.zeros(max(cap, 1), np.uint32)
+    src = np.zeros(max(cap, 1), np.int64)
+    lib().gvlo_svar2_merge_hap.restype = C.c_int64
+    n = lib().gvlo_svar2_merge_hap(_p(vk_pos), C.c_int64(int(vk_lo)), C.c_int64(int(vk_hi)), _p(dense_pos), C.c_int64(int(ds)),
+                                   C.c_int64(int(de)), _p(bits), C.c_int64(int(base_bit)), _p(pos), _p(src))
+    return pos[:n].copy(), src[:n].copy()
+
+
+def _svar2_common(regions, shifts, vk_pos, vk_ilen, vk_off, dense_pos, dense_ilen, dense_range, dense_present,
+                  dense_present_off):
+    a = dict(reg=_c(regions, np.int32), sh=_c(shifts, np.int32), vp=_c(vk_pos, np.int32), vi=_c(vk_ilen, np.int32),
+             vo=_c(vk_off, np.int64), dp=_c(dense_pos, np.int32), di=_c(dense_ilen, np.int32),
+             dr=_c(np.asarray(dense_range).reshape(-1, 2), np.int32), pb=_c(dense_present, np.uint8),
+             po=_c(dense_present_off, np.int64))
+    assert a["reg"].ndim == 2 and a["reg"].shape[1] >= 3
+    return a
+
+
+def hap_diffs_svar2(regions, ploidy, vk_pos, vk_ilen, vk_off, dense_pos, dense_ilen, dense_range, dense_present,
+                    dense_present_off, filter_exonic=False):
+    """``hap_diffs_svar2`` (src/svar2/mod.rs:78-160) over decoded channels -> i32 (n_q, ploidy)."""
+    a = _svar2_common(regions, None, vk_pos, vk_ilen, vk_off, dense_pos, dense_ilen, dense_range, dense_present,
+                      dense_present_off)
+    n_q = a["reg"].shape[0]
+    diffs = np.zeros((n_q, int(ploidy)), np.int32)
+    lib().gvlo_hap_diffs_svar2(_p(a["reg"]), C.c_int64(a["reg"].shape[1]), C.c_int64(n_q), C.c_int64(int(ploidy)), _p(a["vp"]),
+                               _p(a["vi"]), _p(a["vo"]), _p(a["dp"]), _p(a["di"]), _p(a["dr"]), _p(a["pb"]), _p(a["po"]),
+                               C.c_int32(1 if filter_exonic else 0), _p(diffs))
+    return diffs
+
+
+def reconstruct_haplotypes_from_svar2_into(
+    out, out_bounds, regions, shifts, vk_pos, vk_ilen, vk_alt_off, vk_off, dense_pos, dense_ilen, dense_alt_off,
+    dense_range, dense_present, dense_present_off, alt_bytes, ref_, ref_offsets, pad_char, parallel=False,
+    filter_exonic=False,
+):
+    """The core ``reconstruct_haplotypes_from_svar2`` (src/reconstruct/mod.rs:619-826), in place: row k lands at
+    ``out[out_bounds[k, 0] : out_bounds[k, 1]]`` (scatter write)."""
+    assert out.dtype == np.uint8 and out.flags.c_contiguous
+    a = _svar2_common(regions, shifts, vk_pos, vk_ilen, vk_off, dense_pos, dense_ilen, dense_range, dense_present,
+                      dense_present_off)
+    ob = _c(np.asarray(out_bounds).reshape(-1, 2), np.int64)
+    n_q, ploidy = a["sh"].shape
+    assert ob.shape[0] == n_q * ploidy
+    vao, dao, ab = _c(vk_alt_off, np.int64), _c(dense_alt_off, np.int64), _c(alt_bytes, np.uint8)
+    rf, ro = _c(ref_, np.uint8), _c(ref_offsets, np.int64)
+    lib().gvlo_reconstruct_haplotypes_from_svar2(
+        _p(out), _p(ob), _p(a["reg"]), C.c_int64(a["reg"].shape[1]), C.c_int64(n_q), C.c_int64(ploidy), _p(a["sh"]),
+        _p(a["vp"]), _p(a["vi"]), _p(vao), _p(a["vo"]), _p(a["dp"]), _p(a["di"]), _p(dao), _p(a["dr"]), _p(a["pb"]),
+        _p(a["po"]), _p(ab), _p(rf), _p(ro), C.c_uint8(int(pad_char)), C.c_int32(1 if filter_exonic else 0))
+
+
+def reconstruct_haplotypes_from_svar2(
+    regions, shifts, vk_pos, vk_ilen, vk_alt_off, vk_off, dense_pos, dense_ilen, dense_alt_off, dense_range,
+    dense_present, dense_present_off, alt_bytes, ref_, ref_offsets, pad_char, output_length, parallel=False,
+    filter_exonic=False,
+):
+    """The fused PyO3 entry (src/ffi/mod.rs:874-997) over decoded channels -> (out u8, out_offsets i64):
+    ``output_length`` -1 = ragged (region length + diff), >= 0 = fixed."""
+    regions = _c(regions, np.int32)
+    shifts = _c(shifts, np.int32)
+    n_q, ploidy = shifts.shape
+    if output_length >= 0:
+        lens = np.full(n_q * ploidy, int(output_length), np.int64)
+    else:
+        diffs = hap_diffs_svar2(regions, ploidy, vk_pos, vk_ilen, vk_off, dense_pos, dense_ilen, dense_range,
+                                dense_present, dense_present_off, filter_exonic)
+        ref_len = (regions[:, 2].astype(np.int64) - regions[:, 1].astype(np.int64))[:, None]
+        lens = np.maximum(ref_len + diffs.astype(np.int64), 0).reshape(-1)
+    off = np.zeros(n_q * ploidy + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    out = np.zeros(int(off[-1]), np.uint8)
+    bounds = np.stack([off[:-1], off[1:]], axis=1)                  # bounds_from_offsets, reconstruct/mod.rs:830-838
+    reconstruct_haplotypes_from_svar2_into(out, bounds, regions, shifts, vk_pos, vk_ilen, vk_alt_off, vk_off, dense_pos,
+                                           dense_ilen, dense_alt_off, dense_range, dense_present, dense_present_off,
+                                           alt_bytes, ref_, ref_offsets, pad_char, parallel, filter_exonic)
+    return out, off
+
+
+def shift_and_realign_tracks_from_svar2_into(
+    out, out_offsets, regions, shifts, vk_pos, vk_ilen, vk_off, dense_pos, dense_ilen, dense_range, dense_present,
+    dense_present_off, tracks, track_offsets, params, strategy_id=0, base_seed=0, query_seed=None, parallel=False,
+):
+    """The core ``shift_and_realign_tracks_from_svar2`` (src/tracks/mod.rs:705-860), in place."""
+    assert out.dtype == np.float32 and out.flags.c_contiguous
+    a = _svar2_common(regions, shifts, vk_pos, vk_ilen, vk_off, dense_pos, dense_ilen, dense_range, dense_present,
+                      dense_present_off)
+    oo = _c(out_offsets, np.int64)
+    n_q, ploidy = a["sh"].shape
+    tr, to, pr = _c(tracks, np.float32), _c(track_offsets, np.int64), _c(params, np.float64)
+    qs = _c(query_seed, np.int64)
+    lib().gvlo_realign_tracks_from_svar2(
+        _p(out), _p(oo), _p(a["reg"]), C.c_int64(a["reg"].shape[1]), C.c_int64(n_q), C.c_int64(ploidy), _p(a["sh"]),
+        _p(a["vp"]), _p(a["vi"]), _p(a["vo"]), _p(a["dp"]), _p(a["di"]), _p(a["dr"]), _p(a["pb"]), _p(a["po"]),
+        _p(tr), _p(to), _p(pr), C.c_int64(int(strategy_id)), C.c_uint64(int(base_seed) & 0xFFFFFFFFFFFFFFFF), _p(qs))
+
+
+def shift_and_realign_tracks_from_svar2(
+    regions, shifts, vk_pos, vk_ilen, vk_off, dense_pos, dense_ilen, dense_range, dense_present, dense_present_off,
+    tracks, track_offsets, params, strategy_id, base_seed, parallel=False,
+):
+    """The fused PyO3 entry (src/ffi/mod.rs:1835-1966) over decoded channels -> (out f32, out_offsets i64)."""
+    regions = _c(regions, np.int32)
+    shifts = _c(shifts, np.int32)
+    n_q, ploidy = shifts.shape
+    diffs = hap_diffs_svar2(regions, ploidy, vk_pos, vk_ilen, vk_off, dense_pos, dense_ilen, dense_range, dense_present,
+                            dense_present_off, False)
+    ref_len = (regions[:, 2].astype(np.int64) - regions[:, 1].astype(np.int64))[:, None]
+    lens = np.maximum(ref_len + diffs.astype(np.int64), 0).reshape(-1)
+    off = np.zeros(n_q * ploidy + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    out = np.zeros(int(off[-1]), np.float32)
+    shift_and_realign_tracks_from_svar2_into(out, off, regions, shifts, vk_pos, vk_ilen, vk_off, dense_pos, dense_ilen,
+                                             dense_range, dense_present, dense_present_off, tracks, track_offsets, params,
+                                             strategy_id, base_seed, None, parallel)
+    return out, off
+
+
+def split_to_flat(n_regions, ploidy, vk, vk_off, dense_snp, dense_snp_range, dense_snp_present, dense_snp_present_off,
+                  dense_indel, dense_indel_range, dense_indel_present, dense_indel_present_off):
+    """``split_to_flat`` (src/svar2/mod.rs:176-274), plain loops: genoray's per-class split dense channels -> the flat
+    single-dense-channel layout.  ``vk`` / ``dense_*``: lists of (position, key); ranges: lists of (start, end).  Per query
+    the window is snp entries then indel entries; per haplotype the presence bits are snp bits then indel bits, LSB-first."""
+    def get_bit(bits, i):
+        return (bits[i // 8] >> (i % 8)) & 1
+
+    out = dict(vk_pos=[p for p, _ in vk], vk_key=[k for _, k in vk], vk_off=[int(o) for o in vk_off],
+               dense_pos=[], dense_key=[], dense_range=[])
+    for q in range(n_regions):
+        base = len(out["dense_pos"])
+        for j in range(*dense_snp_range[q]):
+            out["dense_pos"].append(dense_snp[j][0]); out["dense_key"].append(dense_snp[j][1])
+        for j in range(*dense_indel_range[q]):
+            out["dense_pos"].append(dense_indel[j][0]); out["dense_key"].append(dense_indel[j][1])
+        out["dense_range"] += [base, len(out["dense_pos"])]
+    total_bits = sum(((dense_snp_range[q][1] - dense_snp_range[q][0]) + (dense_indel_range[q][1] - dense_indel_range[q][0])) * ploidy
+                     for q in range(n_regions))
+    present = [0] * ((total_bits + 7) // 8)
+    off = [0]
+    acc = 0
+    h = 0
+    for q in range(n_regions):
+        (ss, se), (is_, ie) = dense_snp_range[q], dense_indel_range[q]
+        for _ in range(ploidy):
+            for k in range(se - ss):
+                if get_bit(dense_snp_present, dense_snp_present_off[h] + k):
+                    present[acc // 8] |= 1 << (acc % 8)
+                acc += 1
+            for k in range(ie - is_):
+                if get_bit(dense_indel_present, dense_indel_present_off[h] + k):
+                    present[acc // 8] |= 1 << (acc % 8)
+                acc += 1
+            off.append(acc)
+            h += 1
+    out["dense_present"] = present
+    out["dense_present_off"] = off
+    return out

@@ -38,7 +38,7 @@ def test_header_symbols_all_exported(lib):
     assert sorted(_lib.SYMBOLS) == decl
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in gvl_hip.h but not exported"
-    assert lib.gvl_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.gvl_abi_version() == _lib.ABI_VERSION == 11
 
 
 def test_header_enums_match_the_python_mirror(lib):
@@ -65,7 +65,7 @@ def test_ctypes_structs_match_c_layout(tmp_path):
 
     structs = {"gvl_static": _lib.GvlStatic, "gvl_batch": _lib.GvlBatch, "gvl_out": _lib.GvlOut,
                "gvl_loader_config": _lib.GvlLoaderConfig, "gvl_loader_batch": _lib.GvlLoaderBatch,
-               "gvl_track_set": _lib.GvlTrackSet, "gvl_ref_batch": _lib.GvlRefBatch}
+               "gvl_track_set": _lib.GvlTrackSet, "gvl_ref_batch": _lib.GvlRefBatch, "gvl_svar2_batch": _lib.GvlSvar2Batch}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -103,6 +103,17 @@ def test_argument_validation_without_device(lib):
     assert lib.gvl_rc_rows(None, None, None, C.c_int64(3), None) == 1
     with pytest.raises(ValueError):
         _lib.check(1)
+    # the SVAR2 provider: sizes are host arithmetic, arguments are checked before the device is touched
+    assert lib.gvl_svar2_workspace_bytes(4, 2, 10, 64, 100) > 0 and lib.gvl_svar2_workspace_bytes(4, 0, 10, 64, 100) == 0
+    assert lib.gvl_svar2_workspace_bytes(4, 2, 10, 64, 100) % 256 == 0
+    sv, merged, goi = _lib.GvlSvar2Batch(), _lib.GvlStatic(), C.c_void_p()
+    assert lib.gvl_svar2_merge(None, None, None, C.c_int64(3), C.c_int64(0), C.c_int64(1), None, C.c_int64(0), None, None, None) == 1
+    assert lib.gvl_svar2_merge(C.byref(st), C.byref(sv), None, C.c_int64(3), C.c_int64(2), C.c_int64(2), None, C.c_int64(0),
+                               C.byref(merged), C.byref(goi), None) == 1
+    assert b"workspace" in lib.gvl_last_error()
+    bt2 = _lib.GvlBatch(batch=1, ploidy=1, out_offsets=8, out_bounds=8, output_length=-1)
+    out2 = _lib.GvlOut(haps=8)
+    assert lib.gvl_reconstruct(C.byref(st), C.byref(bt2), C.byref(out2), None) == 1      # out_offsets and out_bounds are exclusive
 
 
 def test_no_cpu_fallback_and_oracle_isolation():

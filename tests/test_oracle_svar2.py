@@ -1,0 +1,147 @@
+"""The SVAR2 two-source provider on the CPU: the oracle's restatement against the reference's Rust
+known-answer tests (tests/svar2_kats.py), the SVAR1 == SVAR2 equivalence on synthetic batches, and the host-side
+``split_to_flat``.  Pinned by KATs only: no 200-case golden exists for these entry points."""
+
+import numpy as np
+import pytest
+
+from tests import svar2_kats as K
+
+
+def test_decode_alt_three_cases(oracle):
+    # src/svar2/mod.rs:598-613
+    for key, lut, off, d, allele in K.DECODE_KATS:
+        got_d, got_a = oracle.decode_alt(key, lut, off)
+        assert got_d == d and got_a == allele
+
+
+def test_merge_hap_position_sorted_var_key_before_dense_on_tie(oracle):
+    # src/svar2/mod.rs:615-652
+    k = K.MERGE_KAT
+    bits = np.packbits(np.asarray(k["present"]), bitorder="little")
+    pos, src = oracle.merge_hap(k["vk_pos"], 0, len(k["vk_pos"]), k["dense_pos"], k["ds"], k["de"], bits, 0)
+    keys = [k["vk_key"][s] if s >= 0 else k["dense_key"][-(s + 1)] for s in src]
+    assert list(zip(pos.tolist(), keys)) == k["expected"]
+
+
+def test_merge_hap_absent_bits_and_bit_offset(oracle):
+    # LSB-first presence bits at a non-zero bit offset that straddles a byte (src/svar2/mod.rs:35-39)
+    bits = np.zeros(3, np.uint8)
+    want = [1, 0, 1, 1, 0, 1]
+    for j, b in enumerate(want):
+        if b:
+            bits[(5 + j) // 8] |= 1 << ((5 + j) % 8)
+    pos, src = oracle.merge_hap([7], 0, 1, [1, 2, 3, 7, 8, 9], 0, 6, bits, 5)
+    assert pos.tolist() == [1, 3, 7, 7, 9] and src.tolist() == [-1, -3, 0, -4, -6]
+
+
+def test_hap_diffs_svar2_snp_and_del(oracle):
+    # src/svar2/mod.rs:654-700
+    k = K.DIFFS_KAT
+    ch = K.kat_channels(oracle, k)
+    d = oracle.hap_diffs_svar2(k["regions"], k["ploidy"], ch["vk_pos"], ch["vk_ilen"], ch["vk_off"], ch["dense_pos"], ch["dense_ilen"],
+                               ch["dense_range"], ch["dense_present"], ch["dense_present_off"])
+    assert d.tolist() == k["expected"]
+
+
+@pytest.mark.parametrize("case", K.RECON_KATS, ids=[c[0] for c in K.RECON_KATS])
+def test_reconstruct_haplotypes_from_svar2_kats(oracle, case):
+    # src/reconstruct/mod.rs:1540-1813
+    _, k, init, exp = case
+    ch = K.kat_channels(oracle, k)
+    out = K.S(init)
+    oracle.reconstruct_haplotypes_from_svar2_into(
+        out, k["out_bounds"], np.asarray(k["regions"], np.int32), np.asarray(k["shifts"], np.int32), ch["vk_pos"], ch["vk_ilen"],
+        ch["vk_alt_off"], ch["vk_off"], ch["dense_pos"], ch["dense_ilen"], ch["dense_alt_off"], ch["dense_range"], ch["dense_present"],
+        ch["dense_present_off"], ch["alt_bytes"], K.S(k["ref"]), [0, len(k["ref"])], ord("N"))
+    assert out.tobytes() == exp
+
+
+def test_svar2_track_realign_del(oracle):
+    # src/tracks/mod.rs:2509-2566
+    k = K.TRACK_KAT
+    ch = K.kat_channels(oracle, k)
+    out = np.zeros(4, np.float32)
+    oracle.shift_and_realign_tracks_from_svar2_into(
+        out, k["out_offsets"], np.asarray(k["regions"], np.int32), np.asarray(k["shifts"], np.int32), ch["vk_pos"], ch["vk_ilen"],
+        ch["vk_off"], ch["dense_pos"], ch["dense_ilen"], ch["dense_range"], ch["dense_present"], ch["dense_present_off"],
+        np.asarray(k["track"], np.float32), k["track_offsets"], k["params"], k["strategy_id"], k["base_seed"])
+    assert out.tolist() == k["expected"]
+    got, off = oracle.shift_and_realign_tracks_from_svar2(
+        np.asarray(k["regions"], np.int32), np.asarray(k["shifts"], np.int32), ch["vk_pos"], ch["vk_ilen"], ch["vk_off"],
+        ch["dense_pos"], ch["dense_ilen"], ch["dense_range"], ch["dense_present"], ch["dense_present_off"],
+        np.asarray(k["track"], np.float32), k["track_offsets"], k["params"], k["strategy_id"], k["base_seed"])
+    # the fused entry sizes the row itself: region length 4 + diff -2 = 2 values
+    assert off.tolist() == [0, 2] and got.tolist() == [10.0, 20.0]
+
+
+@pytest.mark.parametrize("case", K.SPLIT_KATS, ids=[c[0] for c in K.SPLIT_KATS])
+def test_split_to_flat(oracle, case):
+    # src/svar2/mod.rs:702-875: the oracle's loops and the product's numpy marshal
+    _, br, exp = case
+    got = oracle.split_to_flat(br["n_regions"], br["ploidy"], br["vk"], br["vk_off"], br["dense_snp"], br["dense_snp_range"],
+                               br["dense_snp_present"], br["dense_snp_present_off"], br["dense_indel"], br["dense_indel_range"],
+                               br["dense_indel_present"], br["dense_indel_present_off"])
+    for name, want in exp.items():
+        assert list(got[name]) == want, name
+    from genvarloader_amd import svar2
+
+    unz = lambda prs: ([p for p, _ in prs], [k for _, k in prs])  # noqa: E731
+    (vp, vk), (sp, sk), (ip, ik) = unz(br["vk"]), unz(br["dense_snp"]), unz(br["dense_indel"])
+    g2 = svar2.split_to_flat(br["n_regions"], br["ploidy"], vp, vk, br["vk_off"], sp, sk, br["dense_snp_range"], br["dense_snp_present"],
+                             br["dense_snp_present_off"], ip, ik, br["dense_indel_range"], br["dense_indel_present"],
+                             br["dense_indel_present_off"])
+    for name, want in exp.items():
+        assert np.asarray(g2[name]).reshape(-1).tolist() == want, name
+
+
+@pytest.mark.parametrize("seed,indel,dense_af,length,out_len", [(1, 0.0, 0.35, 1024, None), (2, 0.2, 0.2, 2048, None),
+                                                                 (3, 0.2, 0.6, 2048, -1), (4, 0.3, 0.0, 512, -1),
+                                                                 (5, 0.15, 1.1, 2048, None)])
+def test_svar1_and_svar2_routes_give_identical_bytes(oracle, seed, indel, dense_af, length, out_len):
+    """The same haplotypes through the SVAR1 table and through two-channel form (synth.to_svar2: the generator's deletions
+    carry the anchor base only = what the SVAR2 provider substitutes for a pure deletion's empty allele)."""
+    from genvarloader_amd import synth
+
+    rng = np.random.default_rng(seed)
+    st = synth.make_static(rng, (200_000,), indel_frac=indel)
+    bt = synth.make_batch(rng, st, 48, 2, length, random_shifts=out_len is None, edge_frac=0.1, output_length=out_len)
+    sv = synth.to_svar2(rng, st, bt, dense_af=dense_af)
+    exp, off = oracle.reconstruct_haplotypes_fused(
+        bt.regions, bt.shifts, bt.geno_offset_idx, bt.geno_offsets, bt.geno_v_idxs, st.v_starts, st.ilens, st.alt_alleles,
+        st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, bt.output_length, None, None, None, False)[:2]
+    got, off2 = oracle.reconstruct_haplotypes_from_svar2(bt.regions, bt.shifts, *sv.args(), st.ref, st.ref_offsets, st.pad_char,
+                                                         bt.output_length)
+    np.testing.assert_array_equal(off, off2)
+    np.testing.assert_array_equal(exp, got)
+    d1 = oracle.get_diffs_sparse(bt.geno_offset_idx, bt.geno_v_idxs, bt.geno_offsets, st.ilens, None, None,
+                                 np.ascontiguousarray(bt.regions[:, 1]), np.ascontiguousarray(bt.regions[:, 2]), st.v_starts)
+    d2 = oracle.hap_diffs_svar2(bt.regions, 2, sv.vk_pos, sv.vk_ilen, sv.vk_off, sv.dense_pos, sv.dense_ilen, sv.dense_range,
+                                sv.dense_present, sv.dense_present_off)
+    np.testing.assert_array_equal(d1, d2)
+
+
+def test_filter_exonic_equals_svar1_keep_mask(oracle):
+    """filter_exonic (src/reconstruct/mod.rs:699-706, src/svar2/mod.rs:131-133) = the SVAR1 path under
+    choose_exonic_variants' keep mask (src/genotypes/mod.rs:127-176): the same predicate on the same variants."""
+    from genvarloader_amd import synth
+
+    rng = np.random.default_rng(11)
+    st = synth.make_static(rng, (150_000,), indel_frac=0.3)
+    bt = synth.make_batch(rng, st, 40, 2, 1024, output_length=-1, lookback=60)
+    sv = synth.to_svar2(rng, st, bt, dense_af=0.3)
+    keep, ko = oracle.choose_exonic_variants(np.ascontiguousarray(bt.regions[:, 1]), np.ascontiguousarray(bt.regions[:, 2]),
+                                             bt.geno_offset_idx, bt.geno_v_idxs, bt.geno_offsets, st.v_starts, st.ilens)
+    assert 0 < keep.sum() < keep.size
+    d1 = oracle.get_diffs_sparse(bt.geno_offset_idx, bt.geno_v_idxs, bt.geno_offsets, st.ilens, keep, ko,
+                                 np.ascontiguousarray(bt.regions[:, 1]), np.ascontiguousarray(bt.regions[:, 2]), st.v_starts)
+    d2 = oracle.hap_diffs_svar2(bt.regions, 2, sv.vk_pos, sv.vk_ilen, sv.vk_off, sv.dense_pos, sv.dense_ilen, sv.dense_range,
+                                sv.dense_present, sv.dense_present_off, filter_exonic=True)
+    np.testing.assert_array_equal(d1, d2)
+    exp, off = oracle.reconstruct_haplotypes_fused(
+        bt.regions, bt.shifts, bt.geno_offset_idx, bt.geno_offsets, bt.geno_v_idxs, st.v_starts, st.ilens, st.alt_alleles,
+        st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, -1, keep, ko, None, False)[:2]
+    got, off2 = oracle.reconstruct_haplotypes_from_svar2(bt.regions, bt.shifts, *sv.args(), st.ref, st.ref_offsets, st.pad_char, -1,
+                                                         filter_exonic=True)
+    np.testing.assert_array_equal(off, off2)
+    np.testing.assert_array_equal(exp, got)
