@@ -277,7 +277,7 @@ def test_long_windows_multi_round_merge(gpu, sv2, oracle, kpath):
     rng = np.random.default_rng(51)
     st = synth.make_static(rng, (2 << 20,), indel_frac=0.15)
     bt = synth.make_batch(rng, st, 16, 2, 131072, random_shifts=True)
-    sv = synth.to_svar2(rng, st, bt, dense_af=0.4, extra=0.3)
+    sv = synth.to_svar2(rng, st, bt, dense_af=0.75, extra=0.3)
     assert (np.diff(sv.vk_off) > 64).any() and (np.diff(sv.dense_range.reshape(-1, 2), axis=1) > 64).any()
     exp, eoff = oracle.reconstruct_haplotypes_from_svar2(bt.regions, bt.shifts, *sv.args(), st.ref, st.ref_offsets, st.pad_char, 131072)
     got, off = sv2.reconstruct_haplotypes_from_svar2(bt.regions, bt.shifts, *sv.args(), st.ref, st.ref_offsets, st.pad_char, 131072)
