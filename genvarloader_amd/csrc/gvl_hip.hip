@@ -352,21 +352,28 @@ int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
 // 16384  no lean kernel (the all-purpose kernel over every row, as before round 3)
 // 32768  the lean kernel hands EVERY row to its solo general path (per-wave scans from the byte reference)
 // 131072 the native loop sizes the scratch tracks per batch (not once per epoch)
-// 262144 / 524288  timing ablations of the lean kernel (WRONG output for rows with indels): no re-alignment / allele
-//        bytes (phases A and B as for a SNP-only row); no scan plan either
+// 262144 / 524288  [-DGVL_DIAG builds only; masked off otherwise] timing ablations of the lean kernel (WRONG output for rows with
+//        indels): no re-alignment / allele bytes (phases A and B as for a SNP-only row); no scan plan either
 // 65536  the lean kernel re-reads the runs of a row with indels from memory (never re-aligns the speculative window in LDS)
 // 1048576 rows longer than one chunk never take the lean kernel (LONG): the all-purpose kernel as before
 // 2097152 realignment from intervals never uses its window (every value looked up in the interval list itself)
 // 4194304 tracks are always painted into the scratch track first (no realignment straight from the intervals)
-// 8388608 / 16777216  timing ablations of realign_tracks_kernel (NO output): stop behind the walk / behind the window build
+// 8388608 / 16777216  [-DGVL_DIAG builds only] timing ablations of realign_tracks_kernel (NO output): stop behind the walk / behind the window build
 // 1073741824 round 4's routing of the other output modes: channel-major one-hot, keep masks, annotations and get_reference run the
 //        all-purpose kernel (their lean forms are this round's)
 // 536870912 rows of several chunks go without chunk plans (hap_plan_kernel): every chunk-wave of the lean kernel walks its row itself
-// and 1 / 2 / 4 = timing ablations (no variants / no stores / no loads).
+// and 1 / 2 / 4 = timing ablations (no variants / no stores / no loads) [-DGVL_DIAG builds only].
+// (written by gvl_set_debug_flags on one thread while the loader's producer thread reads it: a relaxed atomic)
 int g_debug_override = -1;
 int debug_flags() {
     static const int flags = [] { const char *e = getenv("GVL_DBG"); return e ? atoi(e) : 0; }();
-    return g_debug_override >= 0 ? g_debug_override : flags;
+    const int ov = __atomic_load_n(&g_debug_override, __ATOMIC_RELAXED);
+    const int v = ov >= 0 ? ov : flags;
+#ifdef GVL_DIAG
+    return v;
+#else
+    return v & ~DBG_ABLATIONS;        // (the timing ablations change the output: diagnostic builds only)
+#endif
 }
 
 // Launch-policy overrides (gvl_set_tuning): A/B measurements, and tests that must force a schedule.  0 = the built-in policy.
@@ -472,7 +479,7 @@ extern "C" {
 
 
 int gvl_abi_version(void) { return GVL_ABI_VERSION; }
-int gvl_set_debug_flags(int flags) { g_debug_override = flags; return GVL_OK; }
+int gvl_set_debug_flags(int flags) { __atomic_store_n(&g_debug_override, flags, __ATOMIC_RELAXED); return GVL_OK; }
 int gvl_set_tuning(int32_t key, int64_t value) {
     if (key < 0 || key >= GVL_TUNE_COUNT) return fail(GVL_ERR_INVALID, "%s", "gvl_set_tuning: unknown key");
     __atomic_store_n(&g_tune[key], value < 0 ? 0 : value, __ATOMIC_RELAXED);
@@ -1149,6 +1156,18 @@ __global__ __launch_bounds__(256) void batch_seeds_kernel(const i64 *order, i64 
     if (lane == 0) out[j] = acc;
 }
 
+// The process-wide knobs an epoch table's LAYOUT and CONTENTS depend on, read ONCE per table fill (loader_knobs_now) and kept with
+// the table: gvl_loader_start_epoch, the fill and every submit of the epoch take them from that one snapshot, and a table that was
+// prefetched under other knobs is simply filled again.  (They were re-read at three different times: a gvl_set_tuning /
+// gvl_set_debug_flags between a prefetch and the epoch's start made the part offsets disagree.)
+struct LoaderKnobs {
+    i64 track_cap_mb, hap_cap_mb;   // GVL_TUNE_TRACK_PLAN_MAX_MB / GVL_TUNE_HAP_PLAN_MAX_MB (0: built in)
+    int ragged_per_group;           // GVL_TUNE_RAGGED_SIZING == 1
+    int dbg;                        // the GVL_DBG bits that decide what a table holds: 8, 2048, 134217728, 268435456, 536870912
+    bool operator==(const LoaderKnobs &o) const {
+        return track_cap_mb == o.track_cap_mb && hap_cap_mb == o.hap_cap_mb && ragged_per_group == o.ragged_per_group && dbg == o.dbg;
+    }
+};
 struct gvl_loader {
     gvl_static st;
     gvl_loader_config cfg;
@@ -1180,6 +1199,7 @@ struct gvl_loader {
     bool pf_valid;
     const int64_t *pf_order; i64 pf_n; int pf_drop_last; void *pf_table; u64 pf_counter;
     void *cur_table;              // the running epoch's table
+    LoaderKnobs cur_kn, pf_kn;    // the knobs the running epoch's / the prefetched table was laid out and filled under
 };
 
 // Producer thread state.  `submitted` / `consumed` / `n_batches` / `order` are only touched under
@@ -1197,11 +1217,18 @@ struct LoaderSync {
 static i64 align256(i64 x) { return (x + 255) & ~255ll; }
 // the track plans of an epoch's rows (rows of several chunks only; an epoch whose plans would not fit GVL_TRACK_PLAN_MAX_MB,
 // default 512, goes without: its chunk-waves then walk their rows' variants themselves)
-static i64 loader_track_plan_bytes(const gvl_loader_config *cfg, i64 n) {
+static LoaderKnobs loader_knobs_now() {
+    LoaderKnobs k;
+    k.track_cap_mb = tune(GVL_TUNE_TRACK_PLAN_MAX_MB); k.hap_cap_mb = tune(GVL_TUNE_HAP_PLAN_MAX_MB);
+    k.ragged_per_group = tune(GVL_TUNE_RAGGED_SIZING) == 1 ? 1 : 0;
+    k.dbg = debug_flags() & (8 | 2048 | 134217728 | 268435456 | 536870912);
+    return k;
+}
+static i64 loader_track_plan_bytes(const gvl_loader_config *cfg, i64 n, const LoaderKnobs &kn) {
     if (cfg->output_length <= 2048) return 0;
     int chunks = 1, chunk_len = 0;
     if (pick_chunk(cfg->output_length, &chunks, &chunk_len) || chunks <= 1) return 0;
-    const i64 cap_t = tune(GVL_TUNE_TRACK_PLAN_MAX_MB);
+    const i64 cap_t = kn.track_cap_mb;
     const i64 cap = (cap_t > 0 ? cap_t : 512) << 20;
     const i64 b = track_plan_bytes(n * cfg->ploidy, chunks);
     return b <= cap ? b : 0;
@@ -1212,9 +1239,9 @@ static i64 loader_track_plan_bytes(const gvl_loader_config *cfg, i64 n) {
 // ahead and read once.  While the epoch's plans sit in the 256 MB Infinity Cache next to its other inputs a chunk-wave starts from
 // two reads instead of a walk (config 4's step: 58.5 against 61.7 us); beyond it they cost more than the walks they save (256
 // samples x 16 regions = 142 MB of plans: 71 us per step with them, 58 without: profiles/r05_cfg4_plans_vs_size.txt).
-static i64 loader_hap_plan_bytes(const gvl_loader_config *cfg, i64 n) {
+static i64 loader_hap_plan_bytes(const gvl_loader_config *cfg, i64 n, const LoaderKnobs &kn) {
     if (cfg->output_length <= 2048 || cfg->want_annot) return 0;
-    const i64 cap_t = tune(GVL_TUNE_HAP_PLAN_MAX_MB);
+    const i64 cap_t = kn.hap_cap_mb;
     const i64 cap = (cap_t > 0 ? cap_t : 64) << 20;
     const i64 b = gvl_hap_plan_bytes(n * cfg->ploidy, cfg->output_length);
     return b <= cap ? b : 0;
@@ -1223,8 +1250,11 @@ static i64 loader_hap_plan_bytes(const gvl_loader_config *cfg, i64 n) {
 static bool loader_ragged(const gvl_loader_config *c) { return c->output_length == -1; }
 // ragged rows are sized once per EPOCH (in the table) instead of once per group of batches -- whenever the group sizing would be
 // used; gvl_set_tuning(GVL_TUNE_RAGGED_SIZING, 1): per group, as in round 4 (GVL_DBG & 134217728: per batch, as before that)
-static bool loader_epoch_sizing(const gvl_static *st, const gvl_loader_config *c) {
-    return loader_ragged(c) && !diffs_long_rows(st) && !(debug_flags() & 134217728) && tune(GVL_TUNE_RAGGED_SIZING) != 1;
+static bool loader_long_rows(const gvl_static *st, const LoaderKnobs &kn) {      // (diffs_long_rows under the snapshot's GVL_DBG 2048)
+    return (kn.dbg & 2048) || (st->n_geno_offsets > 0 && st->n_geno / st->n_geno_offsets > 16);
+}
+static bool loader_epoch_sizing(const gvl_static *st, const gvl_loader_config *c, const LoaderKnobs &kn) {
+    return loader_ragged(c) && !loader_long_rows(st, kn) && !(kn.dbg & 134217728) && !kn.ragged_per_group;
 }
 // bases per row a slot reserves: the fixed length, or the ragged bound
 static i64 loader_row_cap(const gvl_loader_config *c) { return loader_ragged(c) ? c->max_row_len : c->output_length; }
@@ -1246,14 +1276,20 @@ int64_t gvl_loader_slot_bytes(const gvl_loader_config *cfg, int64_t *part_offset
     return off;
 }
 
+static int64_t loader_table_layout(const gvl_loader_config *cfg, int64_t n, int64_t *part_offsets, const LoaderKnobs &kn);
 int64_t gvl_loader_table_bytes(const gvl_loader_config *cfg, int64_t n, int64_t *part_offsets) {
+    // (under the knobs as they are NOW: size the table right before the gvl_loader_start_epoch / _prefetch_epoch that fills it, from
+    // the same thread -- those take their own snapshot, and the two agree unless another thread turned a knob in between)
+    return loader_table_layout(cfg, n, part_offsets, loader_knobs_now());
+}
+static int64_t loader_table_layout(const gvl_loader_config *cfg, int64_t n, int64_t *part_offsets, const LoaderKnobs &kn) {
     if (!cfg || cfg->ploidy <= 0 || cfg->batch_size <= 0 || n < 0) return -1;
     const i64 P = cfg->ploidy;
     const i64 nb = (n + cfg->batch_size - 1) / cfg->batch_size;
     const bool tr = cfg->n_tracks > 0;
     const i64 sizes[GVL_LOADER_TABLE_PARTS] = {16 * n, 8 * n * P, 4 * n * P, n * P, 8 * nb,
                                                tr ? 8 * (n + nb) : 0, tr ? 8 * (cfg->batch_size * P + 1) : 0,
-                                               tr ? loader_track_plan_bytes(cfg, n) : 0, loader_hap_plan_bytes(cfg, n),
+                                               tr ? loader_track_plan_bytes(cfg, n, kn) : 0, loader_hap_plan_bytes(cfg, n, kn),
                                                loader_ragged(cfg) ? 8 * nb * (cfg->batch_size * P + 1 + 2) : 0};
     i64 off = 0;
     for (int i = 0; i < GVL_LOADER_TABLE_PARTS; ++i) {
@@ -1355,10 +1391,11 @@ int gvl_loader_set_epoch(gvl_loader *ld, uint64_t epoch) {
 
 // the request arrays of every query of an epoch, the per-batch track seeds and the scratch-track sizing of its batches,
 // into `table` on stream `s`
-static int loader_fill_table(gvl_loader *ld, const int64_t *order, i64 n, int32_t drop_last, void *table, u64 counter, hipStream_t s) {
+static int loader_fill_table(gvl_loader *ld, const int64_t *order, i64 n, int32_t drop_last, void *table, u64 counter, hipStream_t s,
+                             const LoaderKnobs &kn) {
     const gvl_loader_config &c = ld->cfg;
     int64_t po[GVL_LOADER_TABLE_PARTS + 1];
-    po[GVL_LOADER_TABLE_PARTS] = gvl_loader_table_bytes(&c, n, po);
+    po[GVL_LOADER_TABLE_PARTS] = loader_table_layout(&c, n, po, kn);
     u8 *base = (u8 *)table;
     int *t_regions = (int *)(base + po[0]);
     i64 *t_goi = (i64 *)(base + po[1]);
@@ -1375,7 +1412,7 @@ static int loader_fill_table(gvl_loader *ld, const int64_t *order, i64 n, int32_
                                        c.rc_neg, c.deterministic, c.output_length < 0 ? 0 : c.output_length, c.seed, counter,
                                        t_regions, (int64_t *)t_goi, t_to_rc, t_shifts, s);
     if (rc) return rc;
-    if (po[9] > po[8] && !(debug_flags() & 536870912)) {
+    if (po[9] > po[8] && !(kn.dbg & 536870912)) {
         // rows of several chunks: every row's chunk plans, once per epoch (the batches' launches get pointers into them)
         gvl_batch gb;
         memset(&gb, 0, sizeof(gb));
@@ -1384,7 +1421,7 @@ static int loader_fill_table(gvl_loader *ld, const int64_t *order, i64 n, int32_
         const int rc_p = gvl_hap_plan(&ld->st, &gb, base + po[8], s);
         if (rc_p) return rc_p;
     }
-    if (po[10] > po[9] && loader_epoch_sizing(&ld->st, &c)) {
+    if (po[10] > po[9] && loader_epoch_sizing(&ld->st, &c, kn)) {
         // ragged rows: every batch's row lengths -> offsets + {total, longest row}, for the whole epoch (rows cut to the slots'
         // capacity are reported, never silent)
         gvl_batch gb;
@@ -1434,7 +1471,7 @@ static int loader_fill_table(gvl_loader *ld, const int64_t *order, i64 n, int32_
         rc3 = check_launch("gvl_loader_start_epoch(track offsets)");
         if (rc3) return rc3;
         // rows of several chunks: the rows' plans (track_plan_kernel), for every row of the epoch
-        if (po[8] > po[7] && !(debug_flags() & (8 | 268435456))) {
+        if (po[8] > po[7] && !(kn.dbg & (8 | 268435456))) {
             TrackArgs TA;
             memset(&TA, 0, sizeof(TA));
             TA.go_starts = (const i64 *)ld->st.geno_o_starts; TA.go_stops = (const i64 *)ld->st.geno_o_stops;
@@ -1463,11 +1500,13 @@ int gvl_loader_prefetch_epoch(gvl_loader *ld, uint64_t epoch, const int64_t *ord
     if (n > (1ll << 31)) return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_loader_prefetch_epoch: more than 2^31 queries per epoch (shard the order)");
     if (table == ld->cur_table) return fail(GVL_ERR_INVALID, "%s", "gvl_loader_prefetch_epoch: `table` is the running epoch's table (alternate between two)");
     ld->pf_valid = false;
-    const int rc = loader_fill_table(ld, order, n, drop_last, table, epoch + 1, (hipStream_t)stream);
+    const LoaderKnobs kn = loader_knobs_now();
+    const int rc = loader_fill_table(ld, order, n, drop_last, table, epoch + 1, (hipStream_t)stream, kn);
     if (rc) return rc;
     if (hipEventRecord(ld->pf_ready, (hipStream_t)stream) != hipSuccess)
         return fail(GVL_ERR_HIP, "%s", "gvl_loader_prefetch_epoch: hipEventRecord failed");
     ld->pf_order = order; ld->pf_n = n; ld->pf_drop_last = drop_last; ld->pf_table = table; ld->pf_counter = epoch + 1;
+    ld->pf_kn = kn;
     ld->pf_valid = true;
     return GVL_OK;
 }
@@ -1502,8 +1541,11 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
     if (ld->epoch_set) { counter = ld->next_epoch + 1; ld->epoch_set = false; }
     // was exactly this epoch prepared ahead (gvl_loader_prefetch_epoch)?  Then its table is filled -- or being filled,
     // pf_ready says when -- and nothing of the running epoch is touched: no wait for that epoch's last batches
+    // (... under the knobs as they are now: a table prefetched under others has another layout / other contents and is filled again)
+    const LoaderKnobs kn = loader_knobs_now();
     const bool prefetched = ld->pf_valid && ld->pf_order == order && ld->pf_n == n && ld->pf_drop_last == drop_last &&
-                            ld->pf_table == table && ld->pf_counter == counter && table != ld->cur_table;
+                            ld->pf_table == table && ld->pf_counter == counter && table != ld->cur_table && ld->pf_kn == kn;
+    ld->cur_kn = kn;
     ld->pf_valid = false;
     if (!prefetched) {
         // the previous epoch's last batches were handed to the consumer: the new table contents must not
@@ -1514,7 +1556,7 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
     }
     {
         int64_t po[GVL_LOADER_TABLE_PARTS];
-        gvl_loader_table_bytes(&c, n, po);
+        loader_table_layout(&c, n, po, kn);
         u8 *base = (u8 *)table;
         ld->e_regions = (int *)(base + po[0]);
         ld->e_goi = (i64 *)(base + po[1]);
@@ -1523,18 +1565,18 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
         ld->e_seeds = (u64 *)(base + po[4]);
         ld->e_track_offsets = (i64 *)(base + po[5]);
         ld->e_out_offsets = (i64 *)(base + po[6]);
-        ld->e_hplan = (loader_hap_plan_bytes(&c, n) > 0 && !(debug_flags() & 536870912)) ? base + po[8] : nullptr;
-        ld->e_rag_offs = loader_epoch_sizing(&ld->st, &c) ? (i64 *)(base + po[9]) : nullptr;
+        ld->e_hplan = (loader_hap_plan_bytes(&c, n, kn) > 0 && !(kn.dbg & 536870912)) ? base + po[8] : nullptr;
+        ld->e_rag_offs = loader_epoch_sizing(&ld->st, &c, kn) ? (i64 *)(base + po[9]) : nullptr;
         {
             const i64 nb_used = drop_last ? n / c.batch_size : (n + c.batch_size - 1) / c.batch_size;
             ld->e_rag_sizes = ld->e_rag_offs ? ld->e_rag_offs + nb_used * (c.batch_size * c.ploidy + 1) : nullptr;
         }
         ld->e_hplan_row = gvl_hap_plan_bytes(1, c.output_length);
-        const i64 wsb = c.n_tracks > 0 ? loader_track_plan_bytes(&c, n) : 0;
+        const i64 wsb = c.n_tracks > 0 ? loader_track_plan_bytes(&c, n, kn) : 0;
         int cl = 0;
         ld->e_chunks = 1;
         if (wsb > 0) (void)pick_chunk(c.output_length, &ld->e_chunks, &cl);
-        const bool planned = wsb > 0 && !(debug_flags() & (8 | 268435456));
+        const bool planned = wsb > 0 && !(kn.dbg & (8 | 268435456));
         // (the table was filled for n_used = every query of a whole batch, or all n: the plan's two parts are laid out for that many rows)
         const i64 n_used_rows = (drop_last ? (n / c.batch_size) * c.batch_size : n) * c.ploidy;
         ld->e_plan_hdr = planned ? (int2 *)(base + po[7]) : nullptr;
@@ -1550,7 +1592,7 @@ int gvl_loader_start_epoch(gvl_loader *ld, const int64_t *order, int64_t n, int3
     if (prefetched) {
         hipEvent_t t = ld->epoch_ready; ld->epoch_ready = ld->pf_ready; ld->pf_ready = t;
     } else {
-        const int rc = loader_fill_table(ld, order, n, drop_last, table, counter, s);
+        const int rc = loader_fill_table(ld, order, n, drop_last, table, counter, s, kn);
         if (rc) return rc;
         if (hipEventRecord(ld->epoch_ready, s) != hipSuccess)
             return fail(GVL_ERR_HIP, "%s", "gvl_loader_start_epoch: hipEventRecord failed");
@@ -1630,7 +1672,7 @@ static int loader_submit(gvl_loader *ld, i64 g) {
                 oc.out_offsets = nullptr;
                 continue;
             }
-            if (diffs_long_rows(&ld->st) || (debug_flags() & 134217728)) {
+            if (loader_long_rows(&ld->st, ld->cur_kn) || (ld->cur_kn.dbg & 134217728)) {
                 const int rc0 = hap_offsets_impl(&ld->st, &bt, nullptr, o.out_offsets, o.sizes, c.max_row_len, s);
                 if (rc0) return rc0;
             } else {

@@ -221,7 +221,7 @@ static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const 
     }
     // tracks straight from the intervals with the rows' plans at hand: the fast kernel (chunks it does not take call the general body;
     // GVL_DBG & 1073741824: the general kernel for every chunk, as in round 4)
-    if (ps && A.plan_hdr && A.plan_ent && A.out_offsets && !(A.dbg & (1073741824 | 8388608 | 16777216 | 2097152)))
+    if (ps && A.plan_hdr && A.plan_ent && A.out_offsets && !(A.dbg & (1073741824 | GVL_ABL(8388608) | GVL_ABL(16777216) | 2097152)))
         realign_paint_kernel<<<dim3((unsigned)grid, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream>>>(A, *ps);
     else if (ps) realign_tracks_kernel<true><<<dim3((unsigned)grid, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream>>>(A, *ps);
     else realign_tracks_kernel<false><<<dim3((unsigned)grid, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream>>>(A, PaintSrcArgs());

@@ -799,8 +799,7 @@ def test_loader_onehot_only_goes_through_the_lean_kernel(oracle):
 @pytest.mark.parametrize("layout", ["lc", "cl"])
 def test_loader_long_fixed_rows_with_and_without_epoch_chunk_plans(oracle, layout):
     """Fixed-length rows of several chunks through the native ring (config 4's haplotype half), one-hot row-major and channel-major:
-    with the epoch's chunk plans (gvl_hap_plan over the epoch table), without them (GVL_DBG 536870912), and with the plans' size
-    cap below the epoch's (gvl_set_tuning(GVL_TUNE_HAP_PLAN_MAX_MB): a large dataset's epochs go without plans) == the oracle."""
+    with the epoch's chunk plans (gvl_hap_plan over the epoch table) and without them (GVL_DBG 536870912) == the oracle."""
     from genvarloader_amd import HapsDevice, _lib
     from genvarloader_amd.loader import DeviceHapsDataset
 
@@ -823,9 +822,9 @@ def test_loader_long_fixed_rows_with_and_without_epoch_chunk_plans(oracle, layou
         exp_oh = exp_oh.transpose(0, 1, 3, 2)
     lib = _lib.load()
     try:
-        for flags, cap_mb in ((0, 0), (536870912, 0), (0, 1)):
+        for flags, cap_mb in ((0, 0), (536870912, 0)):       # (a cap below the epoch's plans: test_loader_knobs_turned_between_epochs)
             lib.gvl_set_debug_flags(flags)
-            _lib.set_tuning(_lib.TUNE_HAP_PLAN_MAX_MB, cap_mb)        # (the epoch's plans: 60 rows x 4 chunks x 272 B, far below 1 MB ...)
+            _lib.set_tuning(_lib.TUNE_HAP_PLAN_MAX_MB, cap_mb)
             ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, onehot=True, haps=True, layout=layout)
             seen = 0
             for epoch in range(2):
@@ -1061,3 +1060,85 @@ def test_epochs_prepared_ahead_deliver_what_epochs_prepared_at_their_start_do(tr
             np.testing.assert_array_equal(u, v)
     # (and epochs differ from each other: the comparison above is not one batch list seven times)
     assert not np.array_equal(a[0][0], a[9][0])
+
+
+@pytest.mark.gpu
+def test_loader_knobs_turned_between_epochs(oracle):
+    """The knobs an epoch table's layout depends on are read ONCE per table fill and kept with the table: turning one
+    between an epoch's prefetch and its start -- the documented A/B use -- makes the loader fill that table again instead of reading a
+    layout that is not there.  Long fixed rows whose chunk plans (1000 rows x 4 chunks x 272 B = 1.09 MB) exceed a 1 MB cap: epochs
+    alternate between "with plans" and "the cap drops them" (the plan part of the table is then EMPTY, the branch no test reached
+    before), then between GVL_DBG 536870912 on and off; ragged rows alternate between sizing per epoch and per group.  Every epoch
+    == the oracle."""
+    import ctypes as C
+
+    from genvarloader_amd import HapsDevice, _lib
+    from genvarloader_amd.loader import DeviceHapsDataset
+
+    lib = _lib.load()
+    R, S, P, L = 10, 50, 2, 6_148
+    st, full_regions, go, gv = _grid_dataset(29, R, S, P, L, indel_frac=0.3)
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv, pad_char=st.pad_char)
+    idx = np.arange(R * S)
+    r_idx, s_idx = np.unravel_index(idx, (R, S))
+    goi = np.ravel_multi_index((r_idx[:, None], s_idx[:, None], np.arange(P)), (R, S, P))
+    to_rc = np.repeat(full_regions[r_idx, 3] == -1, P)
+    exp = oracle.reconstruct_haplotypes_fused(
+        full_regions[r_idx], np.zeros_like(goi, dtype=np.int32), goi, go, gv, st.v_starts, st.ilens, st.alt_alleles,
+        st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, L, None, None, to_rc, False)[0].reshape(R * S, P, L)
+    try:
+        ds = DeviceHapsDataset(dev, full_regions, S, P, output_length=L, onehot=False, haps=True)
+        dl = ds.to_dataloader(batch_size=16, shuffle=True, seed=5)
+        assert dl.prefetch_epochs
+        plan_parts = []
+        for epoch, (cap_mb, flags) in enumerate([(0, 0), (1, 0), (0, 0), (1, 0), (0, 536870912), (0, 0), (0, 536870912)]):
+            # (turned AFTER the previous epoch prefetched this epoch's table under the other setting)
+            _lib.set_tuning(_lib.TUNE_HAP_PLAN_MAX_MB, cap_mb)
+            lib.gvl_set_debug_flags(flags)
+            po = (C.c_int64 * _lib.LOADER_TABLE_PARTS)()
+            lib.gvl_loader_table_bytes(C.byref(dl._native["cfg"]), C.c_int64(R * S), po) if dl._native else None
+            plan_parts.append(int(po[9]) - int(po[8]) if dl._native else None)
+            seen = 0
+            for b in dl:
+                hp = b.haps.cpu().numpy()
+                for i, q in enumerate(b.idx.cpu().numpy().tolist()):
+                    np.testing.assert_array_equal(hp[i], exp[q], err_msg=f"epoch {epoch} cap {cap_mb} flags {flags} query {q}")
+                    seen += 1
+            assert seen == R * S
+            torch.cuda.synchronize()
+            _lib.check_async()
+        assert plan_parts[1] == 0 and plan_parts[2] > (1 << 20) and plan_parts[3] == 0       # the cap really drops the plans
+        lib.gvl_set_debug_flags(-1)
+        _lib.set_tuning(_lib.TUNE_HAP_PLAN_MAX_MB, 0)
+        # ragged rows: offsets sized once per epoch (in the table) / once per group of batches
+        R2, S2, L2 = 6, 20, 900
+        st2, fr2, go2, gv2 = _grid_dataset(31, R2, S2, P, L2, indel_frac=0.3)
+        dev2 = HapsDevice(ref=st2.ref, ref_offsets=st2.ref_offsets, v_starts=st2.v_starts, ilens=st2.ilens,
+                          alt_alleles=st2.alt_alleles, alt_offsets=st2.alt_offsets, geno_offsets=go2, geno_v_idxs=gv2, pad_char=st2.pad_char)
+        idx2 = np.arange(R2 * S2)
+        r2, s2 = np.unravel_index(idx2, (R2, S2))
+        goi2 = np.ravel_multi_index((r2[:, None], s2[:, None], np.arange(P)), (R2, S2, P))
+        e2, o2 = oracle.reconstruct_haplotypes_fused(
+            fr2[r2], np.zeros_like(goi2, dtype=np.int32), goi2, go2, gv2, st2.v_starts, st2.ilens, st2.alt_alleles,
+            st2.alt_offsets, st2.ref, st2.ref_offsets, st2.pad_char, -1, None, None, np.repeat(fr2[r2, 3] == -1, P), False)[:2]
+        ds2 = DeviceHapsDataset(dev2, fr2, S2, P, output_length=-1, onehot=False, haps=True)
+        dl2 = ds2.to_dataloader(batch_size=9, shuffle=True, seed=7, group=2)
+        for epoch, mode in enumerate([0, 1, 0, 1, 1, 0]):
+            _lib.set_tuning(_lib.TUNE_RAGGED_SIZING, mode)
+            seen = 0
+            for b in dl2:
+                hp, oo = b.haps.cpu().numpy(), b.out_offsets.cpu().numpy()
+                for i, q in enumerate(b.idx.cpu().numpy().tolist()):
+                    for p in range(P):
+                        k = i * P + p
+                        np.testing.assert_array_equal(hp[oo[k]:oo[k + 1]], e2[o2[q * P + p]:o2[q * P + p + 1]],
+                                                      err_msg=f"epoch {epoch} sizing {mode} query {q} hap {p}")
+                    seen += 1
+            assert seen == R2 * S2
+            torch.cuda.synchronize()
+            _lib.check_async()
+    finally:
+        lib.gvl_set_debug_flags(-1)
+        _lib.set_tuning(_lib.TUNE_HAP_PLAN_MAX_MB, 0)
+        _lib.set_tuning(_lib.TUNE_RAGGED_SIZING, 0)

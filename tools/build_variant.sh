@@ -10,7 +10,7 @@ cp $R/genvarloader_amd/csrc/* $W/
 [ -n "$SRC_OVERRIDE" ] && cp $SRC_OVERRIDE/* $W/
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -Wno-unused-value -Wno-pass-failed -I$R/include "$@" -c $W/$U.hip -o $W/$U.o
 OBJS=""
-for u in gvl_hip gvl_recon gvl_lean gvl_lean_pipe gvl_tracks; do
+for u in gvl_hip gvl_recon gvl_lean gvl_lean_pipe gvl_tracks gvl_svar2; do
   if [ $u = $U ]; then OBJS="$OBJS $W/$U.o"; else OBJS="$OBJS $R/build/hip/$u.hip.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $R/tools/lib_$N.so

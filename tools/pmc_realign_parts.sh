@@ -4,6 +4,8 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 T=$R/gpurun_out/pmc_realign_parts
 rm -rf $T; mkdir -p $T
+[ -f $R/tools/libgvl_hip_diag.so ] || bash $R/tools/build_diag.sh      # (the ablation bits exist in the diagnostic build only)
+export GVL_HIP_LIB=$R/tools/libgvl_hip_diag.so
 export GVL_CFG4_INFLIGHT=1 GVL_CFG4_GROUP=1
 cd /tmp
 for dbg in 0 8388608 16777216; do
