@@ -709,9 +709,14 @@ def main() -> None:
             if _many(_dref, b_, o_, n_, _sptr[0]):
                 raise RuntimeError("gvl_reconstruct_many failed")
             torch.cuda.synchronize()
-            bad, relaunched = _mismatches(), True
+            bad_first, bad, relaunched = bad, _mismatches(), True
+            # LOUD either way: the pass / fail below then speaks for the relaunch, not for the launch that was timed
+            print(f"bench.py: WARNING: the timed launch's outputs did not equal the oracle ({bad_first} of {len(positions)} batches); "
+                  f"the same arguments launched again, alone, {'DO' if not bad else 'do NOT'} -- see `verified.timed_launch_equal`",
+                  file=sys.stderr, flush=True)
         rows_v = sum(e[2] for e in exp_)
         verified = {"batches": len(positions), "mismatches": bad, "rows": rows_v, "in_group_positions": positions, "relaunched": relaunched,
+                    "timed_launch_equal": not relaunched and not bad,
                     "launch": ("the sustained leg's last launch" if last_call is not None else "the timed region's packed arguments, launched once more")
                               + " (" + what + ")",
                     "against": "oracle.reconstruct_haplotypes_fused (C restatement of the reference), one-hot"

@@ -934,6 +934,17 @@ int gvl_get_reference_many(const gvl_static *st, const gvl_ref_batch *bs, int32_
     bool grouped = n >= 2 && st->ref4 && !((uintptr_t)st->ref4 & 15) && st->ref_offsets && st->ref_len < (1ll << 32) - 8192 &&
                    (debug_flags() & ~(2 | 4 | 32768 | 65536 | 33554432 | 268435456 | 536870912)) == 0;
     int min_chunks = 0x7FFFFFFF;
+    // every batch is validated before anything is launched (as gvl_reconstruct_many does), with gvl_get_reference's own checks
+    for (int i = 0; i < n; ++i) {
+        const gvl_ref_batch &b = bs[i];
+        if (b.n_rows < 0) return fail(GVL_ERR_INVALID, "%s", "gvl_get_reference_many: bad arguments");
+        if (b.n_rows == 0) continue;
+        if ((st->ref_len > 0 && !st->ref) || !st->ref_offsets || !b.regions || !b.out_offsets || b.regions_stride < 3 || (!b.out && !b.onehot))
+            return fail(GVL_ERR_INVALID, "%s", "gvl_get_reference_many: NULL/invalid array");
+        if (b.max_row_len < 0 || b.max_row_len > 0x7FFFFF00ll) return fail(GVL_ERR_INVALID, "%s", "gvl_get_reference_many: bad max_row_len");
+        if (b.n_rows > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_get_reference_many: batch too large");
+    }
+    grouped = grouped && (st->ref_len == 0 || st->ref);
     for (int i = 0; i < n && grouped; ++i) {
         const gvl_ref_batch &b = bs[i];
         if (b.n_rows <= 0 || b.n_rows > 0x7FFFFFF0ll || !b.regions || !b.out_offsets || b.regions_stride < 3 || (!b.out && !b.onehot) ||

@@ -220,6 +220,14 @@ class HapsDevice:
             out_offsets=None if oo is None else oo.data_ptr(), max_row_len=mrl,
             hap_plan=None if hap_plan is None else hap_plan.data_ptr(),
         )
+        if hap_plan is not None:
+            # the kernel trusts the plan blindly (its header words carry no tag): a plan made over other rows, or for another row length
+            # (= another chunk stride), would give silently wrong bytes -- :meth:`hap_plan` leaves what it was made for with the tensor
+            made_for = getattr(hap_plan, "_gvl_plan_of", None)
+            if made_for is not None and made_for != (n_rows, output_length):
+                raise ValueError(f"hap_plan was made for {made_for[0]} rows of {made_for[1]} bases, not {n_rows} rows of {output_length}")
+            if oo is not None or kp is not None:
+                raise ValueError("hap_plan goes with fixed-length rows without a keep mask")
         bt = DeviceBatch(reg, sh, goi, kp, ko, rc, oo, output_length, mrl, c)
         bt._hap_plan = hap_plan          # (kept alive with the batch)
         return bt
@@ -233,6 +241,7 @@ class HapsDevice:
         plan = torch.empty(n, dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.gvl_hap_plan(C.byref(self.c), C.byref(bt.c), _ptr(plan), _stream_ptr()))
+        plan._gvl_plan_of = (bt.n_rows, bt.output_length)      # (checked by prepare_batch)
         return plan
 
     def hap_offsets(self, bt: DeviceBatch, want_diffs=False):
@@ -381,6 +390,8 @@ def _get_reference_many(self, batches, *, onehot=False, haps=True):
     """``gvl_get_reference_many``: up to 16 batches of regions in ONE launch.  ``batches``: a list of ``(regions, out_offsets, to_rc |
     None, total, max_row_len)`` with device tensors (``total`` = ``out_offsets[-1]``, ``max_row_len`` = a bound on the rows' lengths,
     both host ints: no synchronisation here) -> a list of ``(bytes | None, one-hot | None)`` device tensors, one pair per batch."""
+    if not haps and not onehot:
+        raise ValueError("get_reference_many: ask for the bytes, the one-hot or both")
     d = self.device
     n = len(batches)
     arr = (_lib.GvlRefBatch * n)()

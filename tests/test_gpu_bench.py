@@ -57,6 +57,7 @@ def test_bench_contract_single_gpu():
     # the line checks what it timed: two batches of the last timed launch (one at an in-group position >= 11 when the rotation allows)
     v = d["verified"]
     assert v["batches"] >= 1 and v["mismatches"] == 0 and v["rows"] == 4096 * v["batches"]
+    assert v["timed_launch_equal"] and not v["relaunched"]        # (the TIMED launch equalled the oracle, not a relaunch of its arguments)
 
 
 def test_bench_secondary_legs():
