@@ -333,6 +333,122 @@ def secondary_ragged(torch, dev, ds, budget_s: float = 2.5) -> dict:
     }
 
 
+def secondary_svar2(torch, G: int = 16, BQ: int = 2048, n: int = 40) -> dict:
+    """The SVAR2 two-source provider on config 3's shape: gvl_svar2_merge over a GROUP of G batches' decoded channels
+    (one launch over G x 4096 haplotypes) + gvl_reconstruct_many over the merged table (one grid), next to the same haplotypes
+    through the SVAR1 table; HIP events on the launch streams, channels and outputs resident in HBM.  `pipelined`: the schedule a
+    loader would run -- the next group's merge on a side stream under this group's reconstruction (two workspaces)."""
+    import ctypes as C
+
+    from genvarloader_amd import HapsDevice, _lib, svar2, synth
+    from genvarloader_amd.device import _stream_ptr
+
+    L, P = 2048, 2
+    rng = np.random.default_rng(20260806)
+    st = synth.make_static(rng, (16 << 20,), indel_frac=0.15)
+    bt = synth.make_batch(rng, st, G * BQ, P, L, rc_frac=0.5)
+    sv = synth.to_svar2(rng, st, bt, dense_af=0.3)
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens, alt_alleles=st.alt_alleles,
+                     alt_offsets=st.alt_offsets, geno_offsets=bt.geno_offsets, geno_v_idxs=bt.geno_v_idxs, pad_char=st.pad_char)
+    ch = svar2.Svar2Channels(*sv.args())
+    lib = _lib.load()
+    K = BQ * P
+    tabs = [svar2.merge(dev, ch, bt.regions, P) for _ in range(2)]
+    torch.cuda.synchronize()
+    _lib.check_async()
+    reg = tabs[0].regions
+    sh = torch.zeros((G * BQ, P), dtype=torch.int32, device="cuda")
+    rc = torch.from_numpy(bt.to_rc.astype(np.uint8)).cuda()
+    goi1 = torch.from_numpy(bt.geno_offset_idx).cuda()
+    outs = [torch.empty((K * L, 4), dtype=torch.uint8, device="cuda") for _ in range(G)]
+
+    def group(goi):
+        bs, os_ = (_lib.GvlBatch * G)(), (_lib.GvlOut * G)()
+        for i in range(G):
+            bs[i] = _lib.GvlBatch(regions=reg[i * BQ:].data_ptr(), regions_stride=4, shifts=sh[i * BQ:].data_ptr(),
+                                  geno_offset_idx=goi[i * BQ:].data_ptr(), batch=BQ, ploidy=P, to_rc=rc[i * K:].data_ptr(),
+                                  output_length=L, max_row_len=L)
+            os_[i] = _lib.GvlOut(onehot=outs[i].data_ptr(), onehot_layout=0)
+        return bs, os_
+
+    b1, o1 = group(goi1)
+    b2 = [group(t.geno_offset_idx)[0] for t in tabs]
+    nbytes = int(lib.gvl_svar2_workspace_bytes(G * BQ, P, ch.c.n_vk, ch.c.dense_present_bits, ch.c.alt_len))
+    merged, goi_p = _lib.GvlStatic(), C.c_void_p()
+
+    def merge_into(i, sp):
+        w_ = tabs[i].workspace.data_ptr() + (-tabs[i].workspace.data_ptr()) % 256
+        _lib.check(lib.gvl_svar2_merge(C.byref(dev.c), C.byref(ch.c), C.c_void_p(reg.data_ptr()), C.c_int64(4), C.c_int64(G * BQ), C.c_int64(P),
+                                       C.c_void_p(w_), C.c_int64(nbytes), C.byref(merged), C.byref(goi_p), sp))
+
+    def recon(static_c, bs, sp):
+        _lib.check(lib.gvl_reconstruct_many(C.byref(static_c), bs, o1, C.c_int32(G), sp))
+
+    def timeit(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e3
+
+    sp0 = _stream_ptr()
+    t_m = timeit(lambda: merge_into(0, sp0))
+    t_2 = timeit(lambda: recon(tabs[0].c, b2[0], sp0))
+    oh2 = outs[G - 1].clone()
+    t_1 = timeit(lambda: recon(dev.c, b1, sp0))
+    same = bool((oh2 == outs[G - 1]).all())
+    t_b = timeit(lambda: (merge_into(0, sp0), recon(tabs[0].c, b2[0], sp0)))
+    side, main = torch.cuda.Stream(), torch.cuda.current_stream()
+    ev_m, ev_r = [torch.cuda.Event(), torch.cuda.Event()], [torch.cuda.Event(), torch.cuda.Event()]
+    sps = C.c_void_p(side.cuda_stream)
+
+    def pipelined(nn):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        side.wait_stream(main)
+        merge_into(0, sps)
+        ev_m[0].record(side)
+        for i in range(nn):
+            cur, nxt = i % 2, (i + 1) % 2
+            if i + 1 < nn:
+                if i >= 1:
+                    side.wait_event(ev_r[nxt])           # (the table about to be rewritten has been read)
+                merge_into(nxt, sps)
+                ev_m[nxt].record(side)
+            main.wait_event(ev_m[cur])
+            recon(tabs[cur].c, b2[cur], sp0)
+            ev_r[cur].record(main)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / nn * 1e3
+
+    pipelined(10)
+    t_p = pipelined(n)
+    _lib.check_async()
+    n_rec = len(sv.vk_pos) + int(np.unpackbits(sv.dense_present, bitorder="little").sum())
+    alg = G * K * (L * 5 + 61) + 28 * n_rec                        # SURVEY 8(d): L (r + 4 o) + 28 V + 61 per window, one-hot only
+    ch_bytes = sum(int(x.numel()) * x.element_size() for x in (ch.vk_pos, ch.vk_ilen, ch.vk_alt_off, ch.vk_off, ch.dense_pos, ch.dense_ilen,
+                                                                ch.dense_alt_off, ch.dense_range, ch.dense_present, ch.dense_present_off,
+                                                                ch.alt_bytes))
+    frac = lambda t_us: alg / t_us / 1e6 / 8.0          # noqa: E731  (bytes / us = MB/s; / 1e6 = TB/s; / 8 TB/s)
+    return {"workload": f"{G} x ({BQ * P} x {L}) SNP+indel + RC, one-hot, as DECODED SVAR2 channels (var_key {len(sv.vk_pos)} entries, dense "
+                        f"{len(sv.dense_pos)}, {int(sv.dense_present_off[-1])} presence bits, {n_rec} merged records)",
+            "merge_us_per_batch": t_m / G, "merge_launch_us": t_m, "channel_MB": ch_bytes / 1e6, "workspace_MB": nbytes / 1e6,
+            "reconstruct_merged_us_per_batch": t_2 / G, "reconstruct_svar1_us_per_batch": t_1 / G,
+            "ms_per_step": t_p / G * 1e-3, "step_frac": frac(t_p), "back_to_back_us_per_batch": t_b / G, "back_to_back_frac": frac(t_b),
+            "svar1_frac": frac(t_1), "equal_to_svar1_route": same,
+            "how": "ms_per_step: group g + 1's gvl_svar2_merge on a side stream under group g's gvl_reconstruct_many (two workspaces, events); "
+                   "the same launches back to back on one stream: back_to_back; channels resident in HBM (warm: one group's channels, "
+                   f"{ch_bytes / 1e6:.1f} MB)"}
+
+
+
 def secondary_random_shifts(torch, dev, ds, budget_s: float = 2.5) -> dict:
     """cfg3 in TRAINING mode (SURVEY 8d's cfg3 variant; _haps.py:678-768, _query.py:160-187): ``deterministic=False`` -- every haplotype's
     shift drawn from U[0, max_shift], max_shift from its query-mode length delta -- and ``jitter=16``, fixed-length one-hot rows, from
@@ -764,6 +880,14 @@ def main() -> None:
         except Exception as exc:      # (a secondary leg never takes the headline down)
             secondary["ragged"] = {"error": repr(exc)}
         secondary["ragged_s"] = round(time.perf_counter() - t_s, 2)
+        t_s = time.perf_counter()
+        try:
+            if "svar2" in skip:
+                raise RuntimeError("skipped (GVL_BENCH_SKIP)")
+            secondary["svar2"] = secondary_svar2(torch)
+        except Exception as exc:
+            secondary["svar2"] = {"error": repr(exc)}
+        secondary["svar2_s"] = round(time.perf_counter() - t_s, 2)
         t_s = time.perf_counter()
         try:
             if "cfg4" in skip:

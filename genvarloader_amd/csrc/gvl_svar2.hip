@@ -6,10 +6,12 @@
 // unchanged.  A haplotype's run lives at [vk_off[k] + dense_present_off[k], ...): the two prefix sums the caller already
 // has bound every haplotype's record count, so no counting pass, no scan and no host round trip are needed.
 //
-// A wave per haplotype.  Tiles of 64 var_key entries and 64 window entries are merged round by round: a round emits every
-// loaded entry that no entry still unloaded can precede (var_key first on ties), ranks the emitted entries by counting
-// (readlane broadcast: exact stable-sort semantics whatever the order inside a tile), and writes the records.  A haplotype
-// with <= 64 entries per channel is one round and needs no sortedness at all.
+// Two forms, picked per haplotype (svar2_merge_kernel): PACKED -- four haplotypes per wave, one per DPP row of 16 lanes, for
+// haplotypes with at most 16 entries in both channels together (a training batch's 2 kb windows) -- and GENERAL -- one haplotype on all
+// 64 lanes: tiles of 64 var_key entries and 64 window entries are merged round by round, a round emits every loaded entry
+// that no entry still unloaded can precede (var_key first on ties), ranks the emitted entries by counting (readlane
+// broadcast) and writes the records.  Ranks by counting are exact stable-sort semantics whatever the order inside a tile: a
+// haplotype with <= 64 entries per channel needs no sortedness at all.
 #include "gvl_internal.inc"
 
 namespace {
@@ -28,6 +30,7 @@ struct Svar2Args {
     i64 *go_starts, *go_stops, *goi; gvl_srec *srec; u8 *alt_out;
     i64 cap;
     int *async_err;
+    unsigned merge_blocks;      // workgroups [0, merge_blocks) merge; the ones behind them copy the allele pool into the table
 };
 
 struct Svar2Row {
@@ -53,10 +56,12 @@ __device__ __forceinline__ bool svar2_emit(const Svar2Args &A, const Svar2Row &R
         const int n4 = alen < 4 ? (int)alen : 4;
         for (int i = 0; i < n4; ++i) inl |= (u32)A.alt_in[a0 + i] << (8 * i);
     }
+#if !defined(SVAR2_AB) || SVAR2_AB != 1
     A.v_starts[m] = pos;
     A.ilens[m] = il;
     A.alt_offsets[m] = a_start;
     A.geno_v_idxs[m] = (int)m;
+#endif
     i32x4 v;
     v.x = pos; v.y = il; v.z = (int)(alen > 2147483647ll ? 2147483647ll : alen); v.w = (int)inl;
     *reinterpret_cast<i32x4 *>(A.vrec + m) = v;
@@ -73,10 +78,8 @@ __device__ __forceinline__ bool svar2_emit(const Svar2Args &A, const Svar2Row &R
     return alen >= 0xFFFFFFll;          // an allele too long for a slot record: the slot goes through the CSR
 }
 
-__global__ __launch_bounds__(256) void svar2_merge_kernel(const Svar2Args A) {
-    const int lane = threadIdx.x & (WAVE - 1);
-    const i64 k = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (k >= A.n_rows) return;
+// ---- the general form: ONE haplotype on all 64 lanes, any number of entries, round by round -------------------------------
+__device__ __forceinline__ void svar2_merge_one(const Svar2Args &A, const i64 k, const int lane) {
     const i64 q = k / A.ploidy;
     const int *reg = A.regions + q * A.regions_stride;
     Svar2Row R;
@@ -84,8 +87,10 @@ __global__ __launch_bounds__(256) void svar2_merge_kernel(const Svar2Args A) {
     int c = rfl(reg[0]);
     R.rs = rfl(reg[1]); R.re = rfl(reg[2]);
     c = (c >= 0 && c < A.n_contigs) ? c : 0;                       // (out of contract otherwise: clamp, like the kernels)
-    R.c_s = rfl64(A.ref_offsets[c]);
-    R.c_len = rfl64(A.ref_offsets[c + 1]) - R.c_s;
+    // (every lane reads the contig's bounds itself -- the same two words -- and nothing waits for them before a record is emitted: the
+    // channel tiles below are requested in the same round trip)
+    R.c_s = A.ref_offsets[c];
+    R.c_len = A.ref_offsets[c + 1] - R.c_s;
     i64 vk_lo = rfl64(A.vk_off[k]), vk_hi = rfl64(A.vk_off[k + 1]);
     i64 ds = rfl(A.dense_range[2 * q]), de = rfl(A.dense_range[2 * q + 1]);
     const i64 bb = rfl64(A.dense_present_off[k]), bb1 = rfl64(A.dense_present_off[k + 1]);
@@ -97,7 +102,6 @@ __global__ __launch_bounds__(256) void svar2_merge_kernel(const Svar2Args A) {
     }
     R.go_start = ok ? vk_lo + bb : 0;
     const bool multi = (vk_hi - vk_lo > WAVE) || (de - ds > WAVE);
-    const u64 below = (1ull << lane) - 1ull;
     i64 ia = vk_lo, jb = ds;
     int outn = 0;
     bool anybig = false;
@@ -108,9 +112,14 @@ __global__ __launch_bounds__(256) void svar2_merge_kernel(const Svar2Args A) {
         const bool hasA = lane < nA, hasB = lane < nB;
         int posA = 0, ilA = 0, posB = 0, ilB = 0;
         u32 bit = 0;
-        if (hasA) { posA = A.vk_pos[ia + lane]; ilA = A.vk_ilen[ia + lane]; }
+        i64 a0A = 0, a1A = 0, a0B = 0, a1B = 0;        // (the alleles' bounds: requested with the tile, not behind the ranks)
+        if (hasA) {
+            posA = A.vk_pos[ia + lane]; ilA = A.vk_ilen[ia + lane];
+            a0A = A.vk_alt_off[ia + lane]; a1A = A.vk_alt_off[ia + lane + 1];
+        }
         if (hasB) {
             posB = A.dense_pos[jb + lane]; ilB = A.dense_ilen[jb + lane];
+            a0B = A.dense_alt_off[jb + lane]; a1B = A.dense_alt_off[jb + lane + 1];
             const i64 b = bb + (jb - ds) + lane;
             bit = ((u32)A.dense_present[b >> 3] >> (u32)(b & 7)) & 1u;                  // LSB first (src/svar2/mod.rs:35-39)
         }
@@ -149,14 +158,8 @@ __global__ __launch_bounds__(256) void svar2_merge_kernel(const Svar2Args A) {
             }
         }
         bool big = false;
-        if (emitA && eligA) {
-            const i64 e = ia + lane;
-            big = svar2_emit(A, R, R.go_start + outn + rA, outn + rA, posA, ilA, A.vk_alt_off[e], A.vk_alt_off[e + 1]) || big;
-        }
-        if (emitB && eligB) {
-            const i64 e = jb + lane;
-            big = svar2_emit(A, R, R.go_start + outn + rB, outn + rB, posB, ilB, A.dense_alt_off[e], A.dense_alt_off[e + 1]) || big;
-        }
+        if (emitA && eligA) big = svar2_emit(A, R, R.go_start + outn + rA, outn + rA, posA, ilA, a0A, a1A) || big;
+        if (emitB && eligB) big = svar2_emit(A, R, R.go_start + outn + rB, outn + rB, posB, ilB, a0B, a1B) || big;
         anybig = anybig || __builtin_amdgcn_ballot_w64(big) != 0;
         outn += __builtin_popcountll(EA) + __builtin_popcountll(EB);
         int doneA = __builtin_popcountll(__builtin_amdgcn_ballot_w64(emitA)), doneB = __builtin_popcountll(__builtin_amdgcn_ballot_w64(emitB));
@@ -165,7 +168,6 @@ __global__ __launch_bounds__(256) void svar2_merge_kernel(const Svar2Args A) {
         if (doneB > 0) prevB = (u32)rdl(posB, doneB - 1);
         ia += doneA; jb += doneB;
     }
-    (void)below;
     if (__builtin_amdgcn_ballot_w64(err != 0) != 0 && A.async_err) {
         const int e = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(err == 5) ? 5 : 4);
         if (lane == 0) *A.async_err = e;
@@ -189,6 +191,128 @@ __global__ __launch_bounds__(256) void svar2_merge_kernel(const Svar2Args A) {
             s.x = 0; s.y = 0; s.z = (int)GVL_SREC_OVERFLOW; s.w = 0;
             *reinterpret_cast<i32x4 *>(A.srec + k * GVL_SLOT_RECS) = s;
         }
+    }
+}
+
+// ---- the packed form: FOUR haplotypes per wave, one per DPP row of 16 lanes -- lanes 0..7 of a row hold the haplotype's var_key
+// entries, lanes 8..15 its window's entries.  What a training batch looks like (a 2 kb window sees a handful of variants): a wave
+// per haplotype spent its 64 lanes and ~600 instructions on five records.  A lane holds at most one entry (the row's first lanes
+// the var_key entries, the next ones the window's: at most 16 together); an entry's rank is counted over the 15 other lanes of
+// its row (row_ror: a v_mov_dpp each), order = (position, lane): var_key lanes sit below the dense lanes, so ties come out
+// var_key first and in channel order -- merge_hap's stable sort, whatever the order inside the channels.  A haplotype that does
+// not fit a row (more than 16 entries, offsets out of range) takes the general form behind the wave's packed rows.
+template <int N>
+__device__ __forceinline__ int row_ror(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xf, 0xf, false); }
+
+template <int N>
+__device__ __forceinline__ void svar2_rank_step(int &rank, const u32 pos, const int sub, const int key) {
+    // key of a lane: (eligible << 31 is not needed: ineligible lanes carry position 0xFFFFFFFF and the flag in `key`'s low bit)
+    const int o = row_ror<N>(key);                  // the lane N places below (cyclically) inside the row
+    const u32 opos = (u32)row_ror<N>((int)pos);
+    const int osub = (sub - N) & 15;
+    rank += ((o & 1) && (opos < pos || (opos == pos && osub < sub))) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void svar2_merge_kernel(const Svar2Args A) {
+    if (blockIdx.x >= A.merge_blocks) {
+        // the table's allele pool = the caller's (allele starts stay what they are; the anchor bytes of pure deletions go behind it):
+        // copied by the launch's last workgroups, 16 bytes a lane (a separate hipMemcpyAsync was 5 of the launch's 25 us)
+        const i64 t = (i64)(blockIdx.x - A.merge_blocks) * blockDim.x + threadIdx.x;
+        const i64 b0 = t * 16;
+        if (b0 >= A.alt_len) return;
+        if (b0 + 16 <= A.alt_len && (((uintptr_t)A.alt_in) & 15) == 0) {
+            *reinterpret_cast<u32x4 *>(A.alt_out + b0) = *reinterpret_cast<const u32x4 *>(A.alt_in + b0);
+        } else {
+            for (i64 i = b0; i < b0 + 16 && i < A.alt_len; ++i) A.alt_out[i] = A.alt_in[i];
+        }
+        return;
+    }
+    const int lane = threadIdx.x & (WAVE - 1);
+    const i64 w = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const i64 k0 = w * 4;
+    if (k0 >= A.n_rows) return;
+    const int g = lane >> 4, sub = lane & 15;
+    const i64 k = k0 + g;
+    const bool valid = k < A.n_rows;
+    const i64 kk = valid ? k : k0;
+    const i64 q = kk / A.ploidy;
+    const int *reg = A.regions + q * A.regions_stride;
+    int c = reg[0];
+    const i64 rs = reg[1], re = reg[2];
+    c = (c >= 0 && c < A.n_contigs) ? c : 0;
+    const i64 vk_lo = A.vk_off[kk], vk_hi = A.vk_off[kk + 1];
+    const i64 ds = A.dense_range[2 * q], de = A.dense_range[2 * q + 1];
+    const i64 bb = A.dense_present_off[kk], bb1 = A.dense_present_off[kk + 1];
+    const bool ok = vk_lo >= 0 && vk_hi >= vk_lo && vk_hi <= A.n_vk && ds >= 0 && de >= ds && de <= A.n_dense && bb >= 0 &&
+                    bb + (de - ds) <= A.present_bits && bb1 - bb >= de - ds && vk_lo + bb + (vk_hi - vk_lo) + (de - ds) <= A.cap;
+    // (a row holds a haplotype whose two channels have at most 16 entries together: var_key entries first, then the window's)
+    const int nA = (int)(vk_hi - vk_lo);
+    const bool fits = valid && ok && vk_hi - vk_lo <= 16 && de - ds <= 16 && (vk_hi - vk_lo) + (de - ds) <= 16;
+    const u64 nofit = __builtin_amdgcn_ballot_w64(valid && !fits);
+    Svar2Row R;
+    R.k = kk; R.rs = rs; R.re = re;
+    R.c_s = A.ref_offsets[c];
+    R.c_len = A.ref_offsets[c + 1] - R.c_s;
+    R.go_start = vk_lo + bb;
+    // ---- this lane's entry
+    const bool isA = sub < nA;
+    const int e = isA ? sub : sub - nA;
+    const bool has = fits && (isA || ds + e < de);
+    int pos = -1, il = 0;
+    i64 a0 = 0, a1 = 0;
+    u32 bit = 1;
+    if (has) {
+        if (isA) {
+            const i64 i = vk_lo + e;
+            pos = A.vk_pos[i]; il = A.vk_ilen[i]; a0 = A.vk_alt_off[i]; a1 = A.vk_alt_off[i + 1];
+        } else {
+            const i64 j = ds + e;
+            pos = A.dense_pos[j]; il = A.dense_ilen[j]; a0 = A.dense_alt_off[j]; a1 = A.dense_alt_off[j + 1];
+            const i64 b = bb + e;
+            bit = ((u32)A.dense_present[b >> 3] >> (u32)(b & 7)) & 1u;                  // LSB first (src/svar2/mod.rs:35-39)
+        }
+    }
+    bool elig = has && bit;
+    if (elig && pos < 0 && A.async_err) *A.async_err = 5;
+    if (A.filter_exonic) {
+        const i64 end = (i64)(u32)pos - (il < 0 ? (i64)il : 0) + 1;
+        elig = elig && (i64)(u32)pos >= R.rs && end <= R.re;
+    }
+    const int key = elig ? 1 : 0;
+    const u32 upos = (u32)pos;
+    int rank = 0;
+    svar2_rank_step<1>(rank, upos, sub, key);  svar2_rank_step<2>(rank, upos, sub, key);  svar2_rank_step<3>(rank, upos, sub, key);
+    svar2_rank_step<4>(rank, upos, sub, key);  svar2_rank_step<5>(rank, upos, sub, key);  svar2_rank_step<6>(rank, upos, sub, key);
+    svar2_rank_step<7>(rank, upos, sub, key);  svar2_rank_step<8>(rank, upos, sub, key);  svar2_rank_step<9>(rank, upos, sub, key);
+    svar2_rank_step<10>(rank, upos, sub, key); svar2_rank_step<11>(rank, upos, sub, key); svar2_rank_step<12>(rank, upos, sub, key);
+    svar2_rank_step<13>(rank, upos, sub, key); svar2_rank_step<14>(rank, upos, sub, key); svar2_rank_step<15>(rank, upos, sub, key);
+    const u64 E = __builtin_amdgcn_ballot_w64(elig);
+    const int total = __builtin_popcount((u32)(E >> (16 * g)) & 0xFFFFu);
+    bool big = false;
+    if (elig) big = svar2_emit(A, R, R.go_start + rank, rank, pos, il, a0, a1);
+    const bool over = total > GVL_SLOT_RECS || ((__builtin_amdgcn_ballot_w64(big) >> (16 * g)) & 0xFFFFull) != 0;
+    if (fits && sub == 0) {
+        A.go_starts[k] = R.go_start;
+        A.go_stops[k] = R.go_start + total;
+        A.goi[k] = k;
+    }
+    if (fits && sub < GVL_SLOT_RECS && sub >= total) {
+        i32x4 sr;
+        sr.x = 0; sr.y = 0; sr.z = (int)GVL_SREC_EMPTY; sr.w = 0;
+        *reinterpret_cast<i32x4 *>(A.srec + k * GVL_SLOT_RECS + sub) = sr;
+    }
+    if (__builtin_amdgcn_ballot_w64(over) != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (fits && over && sub == 0) {
+            i32x4 sr;
+            sr.x = 0; sr.y = 0; sr.z = (int)GVL_SREC_OVERFLOW; sr.w = 0;
+            *reinterpret_cast<i32x4 *>(A.srec + k * GVL_SLOT_RECS) = sr;
+        }
+    }
+    // the haplotypes of this wave that did not fit a row (more than 16 entries, offsets out of range): the general form, one by one
+    if (nofit != 0) {
+        for (int j = 0; j < 4; ++j)
+            if ((nofit >> (16 * j)) & 1ull) svar2_merge_one(A, k0 + j, lane);
     }
 }
 
@@ -263,12 +387,13 @@ int gvl_svar2_merge(const gvl_static *st, const gvl_svar2_batch *sv, const int32
     A.srec = (gvl_srec *)(w + L.srec); A.alt_out = w + L.alt;
     A.cap = cap;
     A.async_err = async_err_word();
-    // the table's allele pool = the caller's (allele starts stay what they are) + one anchor byte per record behind it
-    if (sv->alt_len > 0 && hipMemcpyAsync(A.alt_out, sv->alt_bytes, (size_t)sv->alt_len, hipMemcpyDeviceToDevice, s) != hipSuccess)
-        return fail(GVL_ERR_HIP, "gvl_svar2_merge: %s", hipGetErrorString(hipGetLastError()));
-    if (n_rows > 0) {
-        const i64 grid = (n_rows * WAVE + 255) / 256;
-        svar2_merge_kernel<<<dim3((unsigned)grid), dim3(256), 0, s>>>(A);
+    {
+        const i64 mb = (((n_rows + 3) / 4) * WAVE + 255) / 256;        // (a wave per four haplotypes)
+        const i64 cb = (sv->alt_len + 4095) / 4096;                      // ... and the pool's copy behind them, 4 KB a workgroup
+        if (mb + cb > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_svar2_merge: batch too large for one launch");
+        A.merge_blocks = (unsigned)mb;
+        const i64 grid = mb + cb;
+        if (grid > 0) svar2_merge_kernel<<<dim3((unsigned)grid), dim3(256), 0, s>>>(A);
         const int rc = check_launch("gvl_svar2_merge");
         if (rc) return rc;
     }
