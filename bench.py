@@ -242,7 +242,7 @@ class Timer:
         spans = self.allmax(spans)
         return float(np.median(spans)), n, spans
 
-    def sustained(self, calls, fn, streams, seconds, est_ms_per_step):
+    def sustained(self, calls, fn, streams, seconds, est_ms_per_step, final=None):
         """>= `seconds` of back-to-back steps on the streams' round-robin schedule between ONE event pair
         (recorded on streams[0]; the other streams are joined into it at the end).  `calls[i]` = the ctypes
         arguments of step i (cycled).  -> (GPU ms per step, steps, host seconds spent enqueueing)."""
@@ -267,7 +267,8 @@ class Timer:
         t_burst = time.perf_counter() - t0
         marks = {n // 3: torch.cuda.Event(enable_timing=True), 2 * n // 3: torch.cuda.Event(enable_timing=True)}
         for i in range(burst, n):
-            bad |= fn(*calls[i % m])
+            # (`final`: the leg's last launch with its own output set -- the same work, written where no other launch writes)
+            bad |= fn(*(final(i % m) if final is not None and i == n - 1 else calls[i % m]))
             if i in marks:                    # (two more events on streams[0]: the rate of each third of the leg)
                 marks[i].record(streams[0])
         t_host = time.perf_counter() - t0
@@ -615,6 +616,10 @@ def main() -> None:
     if args.out_slots > 0:                     # (more slots than the 256 MiB Infinity Cache holds: see DESIGN 5)
         n_slots = args.out_slots
     slots = [dev.alloc_output(batches[0], K * L, haps=args.haps, onehot=True) for _ in range(n_slots)]
+    # ... and one output set of their own for the sustained leg's LAST launch (what `verified` reads): the leg's launches rotate over
+    # streams + 1 sets on free-running streams, which drift apart over seconds of queued work -- the launch that finishes last into a
+    # shared set need not be the one issued last (round 5's check met exactly that, and relaunched)
+    vslots = [dev.alloc_output(batches[0], K * L, haps=args.haps, onehot=True) for _ in range(G)]
     mean_v = float(np.mean([float((dev.geno_offsets[1][b.geno_offset_idx.reshape(-1)]
                                    - dev.geno_offsets[0][b.geno_offset_idx.reshape(-1)]).double().mean())
                             for b in batches[: min(8, n_rot)]]))
@@ -746,14 +751,24 @@ def main() -> None:
             packs = [step_pipelined.pack(j, G) for j in range(period)]
             calls = [(C.byref(dev.c), packs[j][0], packs[j][1], packs[j][2], sp[j % len(streams)]) for j in range(period)]
             sus_fn = dev.lib.gvl_reconstruct_many
+            _vkeep = []
+
+            def sus_final(j):
+                key = step_pipelined.key(j, G)
+                p_ = dev.pack_many([batches[(key[0] * G + i_) % n_rot] for i_ in range(G)], [vslots[i_][1] for i_ in range(G)])
+                _vkeep.append(p_)
+                return (C.byref(dev.c), p_[0], p_[1], p_[2], sp[j % len(streams)])
         else:
             period = math.lcm(n_rot, n_slots, len(streams))
             period = min(period, 4096 - 4096 % len(streams))
             calls = [(C.byref(dev.c), C.byref(batches[j % n_rot].c), C.byref(slots[j % n_slots][1]), sp[j % len(streams)])
                      for j in range(period)]
             sus_fn = dev.lib.gvl_reconstruct
+
+            def sus_final(j):
+                return (C.byref(dev.c), C.byref(batches[j % n_rot].c), C.byref(vslots[0][1]), sp[j % len(streams)])
         clk0 = gpu_clocks(dev_index)
-        sus_ms, sus_n, sus_host, sus_launch = tm.sustained(calls, sus_fn, streams, args.sustained_s, region_ms / steps * G)
+        sus_ms, sus_n, sus_host, sus_launch = tm.sustained(calls, sus_fn, streams, args.sustained_s, region_ms / steps * G, final=sus_final)
         last_call = (sus_n - 1) % period              # (the leg's last launch: its outputs are what `verified` reads below)
         sus_ms /= G                                   # (a call = G steps)
         sus_n *= G
@@ -780,20 +795,23 @@ def main() -> None:
     if rank == 0 and not args.no_cpu_baseline and not args.strong:
         from oracle import oracle as _orc
 
+        # (with the sustained leg: its last launch wrote the dedicated set `vslots`; without it: the timed region's packed arguments,
+        # launched once more into the same dedicated set)
         if G > 1:
             g_v = last_call if last_call is not None else 0
-            if last_call is None:
-                b_, o_, n_ = step_pipelined.pack(g_v, G)
-                if _many(_dref, b_, o_, n_, _sptr[0]):
-                    raise RuntimeError("gvl_reconstruct_many failed")
             key = step_pipelined.key(g_v, G)
-            b0, s0 = key[0] * G, key[2] * G
+            b0 = key[0] * G
+            if last_call is None:
+                p_ = dev.pack_many([batches[(b0 + i_) % n_rot] for i_ in range(G)], [vslots[i_][1] for i_ in range(G)])
+                if _many(_dref, p_[0], p_[1], p_[2], _sptr[0]):
+                    raise RuntimeError("gvl_reconstruct_many failed")
             positions = sorted({0, min(G - 1, 13)})
             what = "gvl_reconstruct_many, %d batches in one grid" % G
         else:
-            step_single(0)
-            j_ = counter[0] - 1
-            b0, s0, positions = j_ % n_rot, j_ % n_slots, [0]
+            b0 = (last_call if last_call is not None else 0) % n_rot
+            if last_call is None:
+                dev.launch(batches[b0], vslots[0][1], stream)
+            positions = [0]
             what = "gvl_reconstruct, one batch"
         torch.cuda.synchronize()
         hs_ = ds.host_static()
@@ -809,30 +827,28 @@ def main() -> None:
         def _mismatches():
             n_bad = 0
             for i_, (e_h, e_oh, _) in zip(positions, exp_):
-                got = slots[s0 + i_][0]
-                ok_ = np.array_equal(got.onehot.cpu().numpy(), e_oh)
+                got = vslots[i_][0]
+                g_oh = got.onehot.cpu().numpy()
+                ok_ = np.array_equal(g_oh, e_oh)
+                if not ok_:          # (say what differs: rows, where in the row -- the first thing anyone will ask)
+                    diff = (g_oh.reshape(-1, L * 4) != np.asarray(e_oh).reshape(-1, L * 4))
+                    rows_bad = np.nonzero(diff.any(axis=1))[0]
+                    first = int(rows_bad[0]) if len(rows_bad) else -1
+                    cols = np.nonzero(diff[first])[0] if first >= 0 else []
+                    print(f"bench.py: verified: group position {i_}: {len(rows_bad)} of {diff.shape[0]} rows differ; first row {first}, "
+                          f"bytes {cols[:4].tolist() if len(cols) else []} .. {int(cols[-1]) if len(cols) else -1} ({len(cols)} bytes); rows {rows_bad[:8].tolist()}",
+                          file=sys.stderr, flush=True)
                 if args.haps:
                     ok_ = ok_ and np.array_equal(got.haps.cpu().numpy(), e_h)
                 n_bad += 0 if ok_ else 1
             return n_bad
 
-        bad, relaunched = _mismatches(), False
-        if bad and G > 1 and last_call is not None:
-            # (the leg's launches rotate over streams + 1 output sets WITHOUT an event between the launch that last wrote a set and
-            # the one that writes it next -- they sit on different streams; should the older one ever have finished last, its
-            # bytes are what the set holds: launch the same arguments once more, alone, before calling it a mismatch)
-            b_, o_, n_ = step_pipelined.pack(g_v, G)
-            if _many(_dref, b_, o_, n_, _sptr[0]):
-                raise RuntimeError("gvl_reconstruct_many failed")
-            torch.cuda.synchronize()
-            bad_first, bad, relaunched = bad, _mismatches(), True
-            # LOUD either way: the pass / fail below then speaks for the relaunch, not for the launch that was timed
-            print(f"bench.py: WARNING: the timed launch's outputs did not equal the oracle ({bad_first} of {len(positions)} batches); "
-                  f"the same arguments launched again, alone, {'DO' if not bad else 'do NOT'} -- see `verified.timed_launch_equal`",
-                  file=sys.stderr, flush=True)
+        bad = _mismatches()
         rows_v = sum(e[2] for e in exp_)
-        verified = {"batches": len(positions), "mismatches": bad, "rows": rows_v, "in_group_positions": positions, "relaunched": relaunched,
-                    "timed_launch_equal": not relaunched and not bad,
+        verified = {"batches": len(positions), "mismatches": bad, "rows": rows_v, "in_group_positions": positions, "relaunched": False,
+                    "timed_launch_equal": not bad,
+                    "outputs": "an output set of its own (no other launch of the leg writes it: the free-running streams drift, and a shared set "
+                               "may hold an earlier launch's bytes)",
                     "launch": ("the sustained leg's last launch" if last_call is not None else "the timed region's packed arguments, launched once more")
                               + " (" + what + ")",
                     "against": "oracle.reconstruct_haplotypes_fused (C restatement of the reference), one-hot"
@@ -935,8 +951,16 @@ def main() -> None:
         # channel-major one-hot (K, 4, L) (docs/source/index.md:114-115), the reference-only fetch (a9, src/reference/mod.rs:56-120),
         # and training mode through the native loader (shifts + jitter)
         tm2 = Timer(torch, dist, backend, streams, 250.0, 2000, 2.0)
-        nb2 = max(G, min(64, n_rot) // G * G)
+        # (the headline's own rotation, all of it: 256 batches = 690 MB of windows + slot lines, 2.7 x the Infinity Cache.  Round 5 rotated
+        # these legs over 32-64 batches -- 86-172 MB, inside the cache -- and still called them cold.)
+        nb2 = max(G, n_rot // G * G)
         bl2 = batches[:nb2] if nb2 <= n_rot else batches
+
+        def temperature(n_batches, bytes_per_row):
+            fp = int(n_batches) * K * bytes_per_row
+            return {"rotating_batches": int(n_batches), "rotation_footprint_bytes": fp,
+                    "inputs": ("cold: the rotation's inputs exceed the 256 MiB Infinity Cache" if fp > (320 << 20)
+                               else "Infinity-Cache-warm: the rotation's inputs fit the 256 MiB cache")}
 
         def mode_leg(bl, make_out, bytes_per_window, kernel):
             sl = [make_out(bl[0]) for _ in range((len(streams) + 1) * G)]
@@ -954,7 +978,8 @@ def main() -> None:
             del sl
             return {"ms_per_step": per, "windows_per_s": K / (per * 1e-3), "algorithmic_bytes_per_step": ab,
                     "step_frac": ab / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, "regions": n_, "kernel": kernel,
-                    "how": "median of %d-step regions: gvl_reconstruct_many calls of %d batches on %d streams, %d rotating cold batches, HIP events"
+                    **temperature(len(bl), 128 + L // 2 + 48),
+                    "how": "median of %d-step regions: gvl_reconstruct_many calls of %d batches on %d streams, %d rotating batches, HIP events"
                            % (k2, G, len(streams), len(bl))}
 
         def leg(name, fn):
@@ -981,7 +1006,7 @@ def main() -> None:
 
         def keep_leg():
             bl = []
-            for b in bl2[:min(len(bl2), 2 * G)]:
+            for b in bl2:
                 kp, ko = dev.choose_exonic_variants(b.regions[:, 1].contiguous(), b.regions[:, 2].contiguous(), b.geno_offset_idx)
                 bl.append(dev.prepare_batch(b.regions, b.shifts, b.geno_offset_idx, L, keep=kp, keep_offsets=ko, to_rc=b.to_rc))
             return dict(mode_leg(bl, lambda b: dev.alloc_output(b, K * L, haps=False, onehot=True),
@@ -994,7 +1019,7 @@ def main() -> None:
 
             from genvarloader_amd._lib import GvlRefBatch
 
-            n_sets = max(G, min(32, n_rot // 2) // G * G)
+            n_sets = max(G, (n_rot // 2) // G * G)          # (128 region sets x 4096 rows x 1 KB of packed reference: 0.5 GB of windows)
             regs, rcs, outs_ = [], [], []
             oo = (torch.arange(K + 1, dtype=torch.int64, device=dev.device) * L).contiguous()
             for i_ in range(n_sets):
@@ -1049,7 +1074,7 @@ def main() -> None:
             ab = (L * (1 + 1 + 4) + 16 + 8 + 1) * K
             return {"workload": f"reference-only fetch (get_reference): {K} rows x {L} bp, reverse-complement on half the rows, bytes + one-hot (K, L, 4)",
                     "ms_per_step": per, "windows_per_s": K / (per * 1e-3), "algorithmic_bytes_per_step": ab,
-                    "step_frac": ab / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, "regions": n_,
+                    "step_frac": ab / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, "regions": n_, **temperature(n_sets, L // 2 + 16),
                     "how": "median of %d-step regions: gvl_get_reference_many calls of %d batches on %d streams, %d rotating region sets, HIP events" % (k2, G, len(streams), n_sets)}
         leg("reference", reference_leg)
         leg("random_shifts", lambda: secondary_random_shifts(torch, dev, ds))

@@ -140,6 +140,18 @@ def all_gather_rows(local, row_lengths=None, group=None):
     dist.all_gather(counts, n_local, group=group)
     counts = [int(c.item()) for c in counts]
     mx = max(counts) if counts else 0
+    if counts and min(counts) == mx:
+        # equal shards (fixed-length rows of an evenly split batch: the usual case): ONE collective straight into the result --
+        # no padded copy per rank, no list of per-rank buffers to concatenate (all_gather_into_tensor; on ROCm the nccl backend's
+        # ncclAllGather over xGMI).  gloo has no such collective for every dtype / device: fall back to the list form below.
+        out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
+        try:
+            dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+            if row_lengths is None:
+                return out
+            return out, all_gather_rows(row_lengths.to(dev), None, group)
+        except (RuntimeError, NotImplementedError, AttributeError):
+            pass
     pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
     pad[: local.shape[0]] = local
     bufs = [torch.empty_like(pad) for _ in range(world)]
