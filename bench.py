@@ -919,6 +919,10 @@ def main() -> None:
                 "step_frac": c4["roofline"]["step_frac"], "step_GBps": c4["roofline"]["step_GBps"],
                 "step_algorithmic_bytes": c4["roofline"]["step_algorithmic_bytes"],
                 "kernel_ms": c4["roofline"]["kernel_ms"], "kernel": c4["roofline"]["kernel"], "kernel_frac": c4["roofline"]["frac"],
+                "step_frac_no_scratch_track": c4["roofline"]["step_frac_no_scratch_track"],
+                "step_algorithmic_bytes_no_scratch_track": c4["roofline"]["step_algorithmic_bytes_no_scratch_track"],
+                "traffic": c4["roofline"]["step_traffic"], "step_frac_of_copy_ceiling": c4["roofline"]["step_frac_of_copy_ceiling"],
+                "traffic_how": c4["roofline"]["traffic_how"],
                 "kernels": c4["kernels"], "loop": c4["config"]["loop"], "steps": c4["steps"], "regions": c4["timing"]["regions"],
             }
         except Exception as exc:

@@ -254,7 +254,19 @@ def measure(args, init_dist=True):
                          # scratch track the painter writes when it runs is this design's own traffic, not counted)
                          "step_algorithmic_bytes": hap_bytes + realign_bytes,
                          "step_GBps": (hap_bytes + realign_bytes) / (ms_step * 1e-3) / 1e9,
-                         "step_frac": (hap_bytes + realign_bytes) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "step_frac": (hap_bytes + realign_bytes) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         # ... SURVEY's formula charges the realignment a 4 L_track READ of a scratch track; the fused step never
+                         # writes or reads one (values come straight from the intervals): the same step priced on what it has to
+                         # touch -- the haplotype half + 4 L written per track + 12 B per interval of the batch's lists
+                         "step_algorithmic_bytes_no_scratch_track": hap_bytes + 4.0 * K * L + 12.0 * n_itv_batch,
+                         "step_frac_no_scratch_track": (hap_bytes + 4.0 * K * L + 12.0 * n_itv_batch) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         # bytes MOVED at the memory side (PMC, this round's build): both kernels of the step
+                         "step_traffic": (None if not fused or _traffic("cfg4@r06:recon") is None or _traffic("cfg4@r06:paint") is None
+                                          else _traffic("cfg4@r06:recon") + _traffic("cfg4@r06:paint")),
+                         "step_frac_of_copy_ceiling": (None if not fused or _traffic("cfg4@r06:recon") is None or _traffic("cfg4@r06:paint") is None
+                                                       else (_traffic("cfg4@r06:recon") + _traffic("cfg4@r06:paint")) / (ms_step * 1e-3) / 1e9 / 6290.0),
+                         "traffic_how": "profiles/traffic.json cfg4@r06:* = rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE per launch "
+                                        "(profiles/r06_pmc_cfg4.txt); copy ceiling 6.29 TB/s = the part's measured float4 copy rate"},
             "kernels": {
                 "recon_lean_kernel<long>, chunk plans made ahead (the step's way)": {"ms": t_recon, "algorithmic_bytes": hap_bytes, "frac": hap_bytes / (t_recon * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "recon_lean_kernel<long> behind its own hap_plan_kernel (a stand-alone gvl_reconstruct)": {"ms": t_recon_self, "algorithmic_bytes": hap_bytes, "frac": hap_bytes / (t_recon_self * 1e-3) / 1e9 / HBM_PEAK_GBS},
