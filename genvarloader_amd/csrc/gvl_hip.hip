@@ -720,16 +720,18 @@ static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_o
     if (!st->ref4 || (!out->onehot && !out->haps)) return false;
     // (annotated haplotypes: bytes + BOTH annotation streams (+ a one-hot in either layout), rows of one chunk, the slot records' variant indices present;
     // only the pipelined kernel has the form)
+    // ... rows of several chunks (round 6): the chunked kernel's form, variant indices from the CSR's inline records
     if (out->annot_v_idxs || out->annot_ref_pos) {
-        if (!out->annot_v_idxs || !out->annot_ref_pos || !out->haps || !st->slot_vidx || chunks != 1 ||
-            ((uintptr_t)st->slot_vidx & 15) || (debug_flags() & (67108864 | 1073741824))) return false;
+        if (!out->annot_v_idxs || !out->annot_ref_pos || !out->haps || (debug_flags() & 1073741824)) return false;
+        if (chunks == 1 && (!st->slot_vidx || ((uintptr_t)st->slot_vidx & 15) || (debug_flags() & 67108864))) return false;
     }
     // (channel-major one-hot: the pipelined kernel's form for rows of one chunk, the chunked kernel's for long rows)
     if (out->onehot && out->onehot_layout != GVL_ONEHOT_LC && ((chunks == 1 && (debug_flags() & 67108864)) || (debug_flags() & 1073741824))) return false;
     if (bt->out_offsets) return false;
     // (a keep mask: both arrays or neither; rows of one chunk only, and only the pipelined kernel reads one)
     if ((bt->keep != nullptr) != (bt->keep_offsets != nullptr)) return false;
-    if (bt->keep && (chunks != 1 || (debug_flags() & (67108864 | 1073741824)))) return false;
+    // (rows of one chunk: the pipelined kernel reads the mask; longer rows: the chunked kernel's walk and the chunk plans do, round 6)
+    if (bt->keep && ((chunks == 1 && (debug_flags() & 67108864)) || (debug_flags() & 1073741824))) return false;
     if (bt->output_length <= 0 || (bt->output_length & 3)) return false;
     const i64 n_rows = bt->batch * bt->ploidy;
     if (chunks == 1) {
@@ -748,7 +750,8 @@ static bool lean_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_o
 static bool lean_long_rag_eligible(const gvl_static *st, const gvl_batch *bt, const gvl_out *out, int chunks, int chunk_len) {
     if (!st->ref4 || !st->geno_rec || (!out->onehot && !out->haps) || !bt->out_offsets) return false;
     if (out->annot_v_idxs || out->annot_ref_pos || (out->onehot && out->onehot_layout != GVL_ONEHOT_LC)) return false;
-    if (bt->keep || bt->keep_offsets) return false;
+    if ((bt->keep != nullptr) != (bt->keep_offsets != nullptr)) return false;
+    if (bt->keep && (debug_flags() & 1073741824)) return false;           // (round 5's routing: rows under a keep mask on the all-purpose kernel)
     if (chunks < 2 || chunk_len != LEAN_MAX_TRIPS * TRIP || (debug_flags() & (1048576 | 16))) return false;
     const i64 n_rows = bt->batch * bt->ploidy;
     if (n_rows <= 0 || n_rows * chunks > 0x7FFFFFF0ll) return false;
@@ -858,7 +861,8 @@ int64_t gvl_hap_plan_bytes(int64_t n_rows, int64_t output_length) {
 
 int gvl_hap_plan(const gvl_static *st, const gvl_batch *bt, void *plan, void *stream) {
     if (!st || !bt || !plan) return fail(GVL_ERR_INVALID, "%s", "gvl_hap_plan: NULL argument");
-    if (bt->keep || bt->keep_offsets || bt->out_offsets || bt->out_bounds) return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_hap_plan: fixed-length rows without a keep mask only");
+    if (bt->out_offsets || bt->out_bounds) return fail(GVL_ERR_UNSUPPORTED, "%s", "gvl_hap_plan: fixed-length rows only");
+    if ((bt->keep != nullptr) != (bt->keep_offsets != nullptr)) return fail(GVL_ERR_INVALID, "%s", "gvl_hap_plan: keep and keep_offsets go together");
     if (bt->batch < 0 || bt->ploidy <= 0 || bt->batch * bt->ploidy > 0x7FFFFFF0ll) return fail(GVL_ERR_INVALID, "%s", "gvl_hap_plan: bad batch / ploidy");
     if (bt->batch == 0) return GVL_OK;
     if (gvl_hap_plan_bytes(bt->batch * bt->ploidy, bt->output_length) <= 0)
@@ -874,6 +878,7 @@ int gvl_hap_plan(const gvl_static *st, const gvl_batch *bt, void *plan, void *st
     A.n_contigs = (int)(st->n_contigs < 0 ? 0 : (st->n_contigs > 0x7FFFFFFFll ? 0x7FFFFFFF : st->n_contigs));
     A.regions = bt->regions; A.regions_stride = bt->regions_stride; A.shifts = bt->shifts;
     A.geno_offset_idx = (const i64 *)bt->geno_offset_idx;
+    A.keep = bt->keep; A.keep_offsets = (const i64 *)bt->keep_offsets;       // (a plan made under a keep mask is that mask's)
     A.fixed_len = bt->output_length;
     A.n_rows = bt->batch * bt->ploidy; A.ploidy = (int)bt->ploidy; A.ploidy_shift = log2_exact(bt->ploidy);
     A.dbg = debug_flags();

@@ -19,6 +19,8 @@ static void fill_lean_args(LeanArgs &A, const ReconArgs &RA, int chunks) {
     A.ploidy_shift = RA.ploidy_shift; A.ploidy = RA.ploidy; A.L = (int)RA.fixed_len; A.dbg = RA.dbg;
     A.chunks = chunks;
     A.ref_only = RA.ref_only;
+    A.keep = RA.keep; A.keep_offsets = RA.keep_offsets;       // (read by the LONG forms and hap_plan_kernel only)
+    A.av = RA.av; A.ap = RA.ap;
 }
 
 // The chunk plans of a batch's rows (hap_plan_kernel; rows of 2 .. HP_MAX_CHUNKS chunks, fixed length): `plan` holds
@@ -38,7 +40,9 @@ int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
     // the rows' chunk plans, when the caller brings them (gvl_batch.hap_plan: made once per epoch by the native loader; GVL_DBG &
     // 536870912: ignored).  A stand-alone launch does NOT make them for itself: measured (profiles/r05_cfg4_plans.txt), the
     // planner in front of every launch costs more than the walks it saves (7 us + a stream-ordered allocation against 2.7 us)
-    if (chunks > 1 && !RA.out_offsets && chunks <= HP_MAX_CHUNKS && !(debug_flags() & 536870912)) A.hplan = RA.hplan;
+    // (annotated rows take no plans: a plan's entries have no room for the variant index and position the annotations need)
+    const bool ann = chunks > 1 && RA.av && RA.ap;
+    if (chunks > 1 && !RA.out_offsets && !ann && chunks <= HP_MAX_CHUNKS && !(debug_flags() & 536870912)) A.hplan = RA.hplan;
     // rows of several chunks: a wave takes `sub` consecutive chunks.  Without plans 2 -- the second chunk resumes the first one's
     // walk; BASELINE config 4's 256 rows x 64 chunks are then 8 192 waves, every wave slot of the part once --, with plans 1: there
     // is no walk to share, and 16 384 short waves start their reads under each other's stores (34.9 against 37.6 us,
@@ -57,6 +61,10 @@ int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
         if (A.onehot && A.haps) recon_lean_kernel<true, true, true, true><<<g, b, 0, s>>>(A, RA);
         else if (A.onehot) recon_lean_kernel<true, false, true, true><<<g, b, 0, s>>>(A, RA);
         else recon_lean_kernel<false, true, true, true><<<g, b, 0, s>>>(A, RA);
+    } else if (ann) {      // annotated haplotypes of several chunks (round 6): bytes + both streams (+ a one-hot in either layout)
+        if (A.onehot && RA.oh_cl) recon_lean_kernel<true, true, true, false, true, true><<<g, b, 0, s>>>(A, RA);
+        else if (A.onehot) recon_lean_kernel<true, true, true, false, false, true><<<g, b, 0, s>>>(A, RA);
+        else recon_lean_kernel<false, true, true, false, false, true><<<g, b, 0, s>>>(A, RA);
     } else if (chunks > 1 && RA.oh_cl) {      // channel-major one-hot (rows, 4, L)
         if (A.haps) recon_lean_kernel<true, true, true, false, true><<<g, b, 0, s>>>(A, RA);
         else recon_lean_kernel<true, false, true, false, true><<<g, b, 0, s>>>(A, RA);

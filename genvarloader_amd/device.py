@@ -226,8 +226,8 @@ class HapsDevice:
             made_for = getattr(hap_plan, "_gvl_plan_of", None)
             if made_for is not None and made_for != (n_rows, output_length):
                 raise ValueError(f"hap_plan was made for {made_for[0]} rows of {made_for[1]} bases, not {n_rows} rows of {output_length}")
-            if oo is not None or kp is not None:
-                raise ValueError("hap_plan goes with fixed-length rows without a keep mask")
+            if oo is not None:
+                raise ValueError("hap_plan goes with fixed-length rows")
         bt = DeviceBatch(reg, sh, goi, kp, ko, rc, oo, output_length, mrl, c)
         bt._hap_plan = hap_plan          # (kept alive with the batch)
         return bt

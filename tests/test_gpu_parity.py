@@ -1166,3 +1166,56 @@ def test_ablation_bits_from_the_environment_do_not_change_results():
         r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=REPO, capture_output=True, text=True,
                            env={**os.environ, "GVL_DBG": v}, timeout=600)
         assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------ round 6: long rows with keep masks / annotations on the chunked lean kernel
+def _with_keep(rng, bt, frac=0.7):
+    """A random keep mask over the batch's variants (what choose_exonic_variants hands the spliced path), rows in k order."""
+    goi = bt.geno_offset_idx.reshape(-1)
+    n = (bt.geno_offsets[1, goi] - bt.geno_offsets[0, goi]).astype(np.int64)
+    bt.keep_offsets = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+    bt.keep = rng.random(int(bt.keep_offsets[-1])) < frac
+    return bt
+
+
+@pytest.mark.parametrize("layout", ["lc", "cl"])
+def test_long_rows_annotated(gpu, oracle, kpath, layout):
+    """Annotated haplotypes of several chunks (src/ffi/mod.rs:2237-2397 at any length): recon_lean_kernel<.., LONG, .., ANN> -- variant
+    indices and positions from the walk's entries -- with reverse-complemented rows, windows over contig edges (the all-purpose body's
+    rows), shifts, next to a one-hot in either layout; GVL_DBG 1073741824 = round 5's routing (the all-purpose kernel) for A/B."""
+    from genvarloader_amd import synth
+
+    rng = np.random.default_rng(61)
+    st = synth.make_static(rng, (500_000,), indel_frac=0.3)
+    for n_q, length, edge in ((5, 20480, 0.0), (3, 6148, 0.3), (2, 131072, 0.0)):
+        bt = synth.make_batch(rng, st, n_q, 2, length, rc_frac=0.5, random_shifts=True, edge_frac=edge)
+        check_batch(gpu, oracle, st, bt, layout=layout, annotate=True)
+
+
+@pytest.mark.parametrize("ragged", [False, True], ids=["fixed", "ragged"])
+def test_long_rows_under_a_keep_mask(gpu, oracle, kpath, ragged):
+    """Rows of several chunks under a keep mask (the spliced path's exonic filter on long exons): the chunked lean kernel's walk skips
+    masked variants (src/reconstruct/mod.rs:86-90) -- fixed-length rows (with and without chunk plans made under the SAME mask) and
+    ragged rows (recon_lean_kernel<.., LONG, RAGL>); annotated too."""
+    from genvarloader_amd import synth
+
+    rng = np.random.default_rng(62)
+    st = synth.make_static(rng, (500_000,), indel_frac=0.3)
+    for n_q, length in ((6, 20480), (3, 7000)):
+        bt = _with_keep(rng, synth.make_batch(rng, st, n_q, 2, length, rc_frac=0.5, random_shifts=not ragged, edge_frac=0.1,
+                                              output_length=-1 if ragged else None))
+        check_batch(gpu, oracle, st, bt)
+        if not ragged and length % 4 == 0:
+            check_batch(gpu, oracle, st, bt, annotate=True)
+            # ... and with the rows' chunk plans, made under the mask (gvl_hap_plan reads bt.keep)
+            dev = make_dev(gpu, st, bt)
+            b0 = dev.prepare_batch(bt.regions, bt.shifts, bt.geno_offset_idx, bt.output_length, bt.keep, bt.keep_offsets, bt.to_rc)
+            plan = dev.hap_plan(b0)
+            assert plan is not None
+            b1 = dev.prepare_batch(bt.regions, bt.shifts, bt.geno_offset_idx, bt.output_length, bt.keep, bt.keep_offsets, bt.to_rc, hap_plan=plan)
+            out, out_c = dev.alloc_output(b1, b1.n_rows * bt.output_length, haps=True, onehot=True)
+            dev.launch(b1, out_c)
+            gpu.torch.cuda.synchronize()
+            exp, _, exp_oh = oracle_fused(oracle, st, bt, onehot=True)
+            np.testing.assert_array_equal(out.haps.cpu().numpy(), exp)
+            np.testing.assert_array_equal(out.onehot.cpu().numpy(), exp_oh)
