@@ -450,6 +450,72 @@ def secondary_svar2(torch, G: int = 16, BQ: int = 2048, n: int = 40) -> dict:
 
 
 
+def secondary_long_modes(torch, n: int = 12) -> dict:
+    """Rows of 131 072 bases (BASELINE config 4's 256-window batches) in the reference's other output modes, which until round 6 ran the
+    all-purpose kernel: annotated haplotypes (bytes + 2 x i32 per base, src/ffi/mod.rs:2237-2397) and rows under the exonic keep mask
+    (src/genotypes/mod.rs:127-176 -> the spliced path's filter), one gvl_reconstruct launch per batch, `n` launches back to back on one
+    stream between HIP events, rotating over the dataset's 8 batches (inputs resident, like secondary.cfg4).  `r05_routing_*`: the same
+    launches under GVL_DBG 1073741824 (round 5's routing = the all-purpose kernel), for A/B on the same box."""
+    import bench_cfg4
+    from genvarloader_amd import _lib
+
+    R, S, P, L, bs = 16, 64, 2, 131072, 128
+    st, dev, ds, tracks, mean_v = bench_cfg4.build("cuda:0", R, S, P, L)
+    lib = _lib.load()
+    K = bs * P
+    order = np.random.default_rng(1).permutation(R * S)
+    reqs = [ds.request(order[i:i + bs].astype(np.int64)) for i in range(0, len(order), bs)]
+
+    def timeit(bts, out_c, flags):
+        lib.gvl_set_debug_flags(flags)
+        try:
+            for i in range(3):
+                dev.launch(bts[i % len(bts)], out_c)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(n):
+                dev.launch(bts[i % len(bts)], out_c)
+            e1.record()
+            torch.cuda.synchronize()
+            _lib.check_async()
+            return e0.elapsed_time(e1) / n
+        finally:
+            lib.gvl_set_debug_flags(-1)
+
+    res = {}
+    # annotated: bytes + annot_v_idxs + annot_ref_pos
+    # (with the rows' chunk plans, as the native loader brings them per epoch: one walk per row, ahead of the launches)
+    bts = [dev.prepare_batch(r[1], r[2], r[3], L, to_rc=r[4]) for r in reqs]
+    bts = [dev.prepare_batch(r[1], r[2], r[3], L, to_rc=r[4], hap_plan=dev.hap_plan(b)) for r, b in zip(reqs, bts)]
+    out, out_c = dev.alloc_output(bts[0], K * L, haps=True, onehot=False, annotate=True)
+    ab = (L * (1 + 1 + 8) + 28.0 * mean_v + 61.0) * K
+    ms, ms5 = timeit(bts, out_c, -1), timeit(bts, out_c, 1073741824)
+    res["annotated_long"] = {"workload": f"{K} windows x {L} bp, annotated haplotypes (bytes + 2 x i32 per base), SNP+indel + RC",
+                             "ms_per_step": ms, "windows_per_s": K / (ms * 1e-3), "algorithmic_bytes_per_step": ab,
+                             "step_frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "recon_lean_kernel<haps, long, annotated>",
+                             "r05_routing_ms": ms5, "r05_routing_frac": ab / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "how": f"{n} gvl_reconstruct launches back to back on one stream, HIP events; 8 rotating batches (inputs resident)"}
+    del out, out_c
+    torch.cuda.empty_cache()
+    # under the exonic keep mask: one-hot + bytes
+    btk = []
+    for r in reqs:
+        kp, ko = dev.choose_exonic_variants(r[1][:, 1].contiguous(), r[1][:, 2].contiguous(), r[3])
+        b0 = dev.prepare_batch(r[1], r[2], r[3], L, keep=kp, keep_offsets=ko, to_rc=r[4])
+        btk.append(dev.prepare_batch(r[1], r[2], r[3], L, keep=kp, keep_offsets=ko, to_rc=r[4], hap_plan=dev.hap_plan(b0)))
+    out, out_c = dev.alloc_output(btk[0], K * L, haps=True, onehot=True)
+    ab = (L * 6 + 29.0 * mean_v + 61.0) * K
+    ms, ms5 = timeit(btk, out_c, -1), timeit(btk, out_c, 1073741824)
+    res["keep_mask_long"] = {"workload": f"{K} windows x {L} bp under the exonic keep mask (choose_exonic_variants on the rows' own regions), one-hot (K, L, 4) + bytes",
+                             "ms_per_step": ms, "windows_per_s": K / (ms * 1e-3), "algorithmic_bytes_per_step": ab,
+                             "step_frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "recon_lean_kernel<onehot, haps, long> with a keep mask",
+                             "r05_routing_ms": ms5, "r05_routing_frac": ab / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "how": f"{n} gvl_reconstruct launches back to back on one stream, HIP events; 8 rotating batches (inputs resident)"}
+    return res
+
+
+
 def secondary_random_shifts(torch, dev, ds, budget_s: float = 2.5) -> dict:
     """cfg3 in TRAINING mode (SURVEY 8d's cfg3 variant; _haps.py:678-768, _query.py:160-187): ``deterministic=False`` -- every haplotype's
     shift drawn from U[0, max_shift], max_shift from its query-mode length delta -- and ``jitter=16``, fixed-length one-hot rows, from
@@ -1082,6 +1148,14 @@ def main() -> None:
                     "how": "median of %d-step regions: gvl_get_reference_many calls of %d batches on %d streams, %d rotating region sets, HIP events" % (k2, G, len(streams), n_sets)}
         leg("reference", reference_leg)
         leg("random_shifts", lambda: secondary_random_shifts(torch, dev, ds))
+        t_l = time.perf_counter()
+        try:
+            if "long_modes" in skip:
+                raise RuntimeError("skipped (GVL_BENCH_SKIP)")
+            secondary.update(secondary_long_modes(torch))
+        except Exception as exc:
+            secondary["annotated_long"] = {"error": repr(exc)}
+        secondary["long_modes_s"] = round(time.perf_counter() - t_l, 2)
 
     lean = (dev.ref4 is not None and dev.slot_rec is not None and L <= 2048 and L % 4 == 0
             and (int(os.environ.get("GVL_DBG", "0")) & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 33554432 | 67108864)) == 0)

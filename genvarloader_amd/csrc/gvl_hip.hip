@@ -1251,12 +1251,12 @@ static i64 loader_track_plan_bytes(const gvl_loader_config *cfg, i64 n, const Lo
 }
 
 // the haplotype kernel's chunk plans of an epoch's rows (fixed-length rows of several chunks the lean kernel takes, either one-hot layout).
-// Under a cap of their own, 64 MB (gvl_set_tuning(GVL_TUNE_HAP_PLAN_MAX_MB)): a plan is 272 bytes per 2048-base chunk, written an epoch
+// Under a cap of their own, 64 MB (gvl_set_tuning(GVL_TUNE_HAP_PLAN_MAX_MB)): a plan is 336 bytes per 2048-base chunk (272 + the annotated rows' annex), written an epoch
 // ahead and read once.  While the epoch's plans sit in the 256 MB Infinity Cache next to its other inputs a chunk-wave starts from
 // two reads instead of a walk (config 4's step: 58.5 against 61.7 us); beyond it they cost more than the walks they save (256
 // samples x 16 regions = 142 MB of plans: 71 us per step with them, 58 without: profiles/r05_cfg4_plans_vs_size.txt).
 static i64 loader_hap_plan_bytes(const gvl_loader_config *cfg, i64 n, const LoaderKnobs &kn) {
-    if (cfg->output_length <= 2048 || cfg->want_annot) return 0;
+    if (cfg->output_length <= 2048) return 0;          // (annotated epochs too, since round 6: the plans' annex)
     const i64 cap_t = kn.hap_cap_mb;
     const i64 cap = (cap_t > 0 ? cap_t : 64) << 20;
     const i64 b = gvl_hap_plan_bytes(n * cfg->ploidy, cfg->output_length);

@@ -40,15 +40,16 @@ int launch_lean(const ReconArgs &RA, int chunks, void *stream) {
     // the rows' chunk plans, when the caller brings them (gvl_batch.hap_plan: made once per epoch by the native loader; GVL_DBG &
     // 536870912: ignored).  A stand-alone launch does NOT make them for itself: measured (profiles/r05_cfg4_plans.txt), the
     // planner in front of every launch costs more than the walks it saves (7 us + a stream-ordered allocation against 2.7 us)
-    // (annotated rows take no plans: a plan's entries have no room for the variant index and position the annotations need)
     const bool ann = chunks > 1 && RA.av && RA.ap;
-    if (chunks > 1 && !RA.out_offsets && !ann && chunks <= HP_MAX_CHUNKS && !(debug_flags() & 536870912)) A.hplan = RA.hplan;
+    if (chunks > 1 && !RA.out_offsets && chunks <= HP_MAX_CHUNKS && !(debug_flags() & 536870912)) A.hplan = RA.hplan;
     // rows of several chunks: a wave takes `sub` consecutive chunks.  Without plans 2 -- the second chunk resumes the first one's
     // walk; BASELINE config 4's 256 rows x 64 chunks are then 8 192 waves, every wave slot of the part once --, with plans 1: there
     // is no walk to share, and 16 384 short waves start their reads under each other's stores (34.9 against 37.6 us,
     // profiles/r05_cfg4_plans.txt).  gvl_set_tuning(GVL_TUNE_LEAN_SUB) overrides.
     const i64 sub_t = tune(GVL_TUNE_LEAN_SUB);
-    A.sub = chunks > 1 ? (sub_t > 0 ? (int)(sub_t > 64 ? 64 : sub_t) : (A.hplan ? 1 : 2)) : 1;
+    // (annotated rows: 1 with or without plans -- their waves spend two thirds of their time storing, and twice as many of them overlap
+    // that with each other's walks: 66 against 75 us for 256 x 131 072 annotated rows without plans, tools/ann_parts.py)
+    A.sub = chunks > 1 ? (sub_t > 0 ? (int)(sub_t > 64 ? 64 : sub_t) : ((A.hplan || ann) ? 1 : 2)) : 1;
     const i64 per_row = (chunks + A.sub - 1) / A.sub;
     const unsigned grid = (unsigned)(((i64)A.n_rows * per_row + LEAN_WAVES - 1) / LEAN_WAVES);
     const dim3 g(grid), b(LEAN_THREADS);

@@ -521,7 +521,7 @@ def test_long_rows_with_the_callers_chunk_plans(gpu, oracle):
         plan = dev.hap_plan(full)
         per_row = int(lib.gvl_hap_plan_bytes(1, L))
         assert plan is not None and plan.numel() == per_row * bt.n_windows
-        hdr = plan.view(gpu.torch.int32).view(bt.n_windows, -1, 4 + 8 * 8)[:, :, 1].cpu().numpy()
+        hdr = plan.view(gpu.torch.int32).view(bt.n_windows, -1, 4 + 8 * 8 + 2 * 8)[:, :, 1].cpu().numpy()      # (header, 8 entries, the annotated rows' annex)
         planned = (hdr & 0x100) != 0
         assert planned.any() and (seed != 4 or (~planned).any())
         P = 2

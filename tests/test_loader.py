@@ -1066,7 +1066,7 @@ def test_epochs_prepared_ahead_deliver_what_epochs_prepared_at_their_start_do(tr
 def test_loader_knobs_turned_between_epochs(oracle):
     """The knobs an epoch table's layout depends on are read ONCE per table fill and kept with the table: turning one
     between an epoch's prefetch and its start -- the documented A/B use -- makes the loader fill that table again instead of reading a
-    layout that is not there.  Long fixed rows whose chunk plans (1000 rows x 4 chunks x 272 B = 1.09 MB) exceed a 1 MB cap: epochs
+    layout that is not there.  Long fixed rows whose chunk plans (1000 rows x 4 chunks x 336 B = 1.34 MB) exceed a 1 MB cap: epochs
     alternate between "with plans" and "the cap drops them" (the plan part of the table is then EMPTY, the branch no test reached
     before), then between GVL_DBG 536870912 on and off; ragged rows alternate between sizing per epoch and per group.  Every epoch
     == the oracle."""
