@@ -776,9 +776,16 @@ static bool lean_rag_eligible(const gvl_static *st, const gvl_batch *bt, const g
     if ((bt->keep != nullptr) != (bt->keep_offsets != nullptr)) return false;
     if (bt->keep && (debug_flags() & 1073741824)) return false;
     const i64 ml = bt->max_row_len > bt->output_length ? bt->max_row_len : bt->output_length;
-    if (ml <= 0 || ml > (i64)PIPE_RAG_MAXT * TRIP) return false;
     const i64 n_rows = bt->batch * bt->ploidy;
     if (n_rows <= 0 || n_rows > 0x7FFFFFF0ll) return false;
+    if (ml <= 0) return false;
+    if (ml > (i64)PIPE_RAG_MAXT * TRIP) {
+        // a batch of MOSTLY short rows with a few long ones (a spliced batch: exons of a few hundred bases and the odd 3' UTR of several
+        // thousand): the pipelined kernel still takes it -- a row beyond its 2560 bases is marked and written by its wave's solo path,
+        // chunk by chunk -- when the caller's total says the mean row is short (gvl_batch.total_len_hint) and no row is longer than 64 Kb.
+        // Anything else with long rows is the chunked kernel's (lean_long_rag_eligible).
+        if (bt->total_len_hint <= 0 || bt->total_len_hint / n_rows > (i64)PIPE_RAG_MAXT * TRIP / 2 || ml > 65536) return false;
+    }
     if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;
     return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 268435456 | 536870912 | 1073741824)) == 0;
 }

@@ -185,7 +185,7 @@ class HapsDevice:
 
     # ------------------------------------------------------------------ batches
     def prepare_batch(self, regions, shifts, geno_offset_idx, output_length, keep=None,
-                      keep_offsets=None, to_rc=None, out_offsets=None, max_row_len=None, hap_plan=None) -> DeviceBatch:
+                      keep_offsets=None, to_rc=None, out_offsets=None, max_row_len=None, hap_plan=None, total_len=None) -> DeviceBatch:
         d = self.device
         reg = _dev(regions, torch.int32, d)
         goi = _dev(geno_offset_idx, torch.int64, d)
@@ -219,6 +219,7 @@ class HapsDevice:
             to_rc=None if rc is None else rc.data_ptr(), output_length=output_length,
             out_offsets=None if oo is None else oo.data_ptr(), max_row_len=mrl,
             hap_plan=None if hap_plan is None else hap_plan.data_ptr(),
+            total_len_hint=0 if (total_len is None or oo is None) else int(total_len),
         )
         if hap_plan is not None:
             # the kernel trusts the plan blindly (its header words carry no tag): a plan made over other rows, or for another row length
@@ -347,13 +348,16 @@ class HapsDevice:
             n = bt.n_rows
             if bt.out_offsets is not None:
                 total = int(bt.out_offsets[-1].item()) if n else 0
+                # (the total this call reads anyway tells the dispatch whether a batch with a few long rows is mostly short ones)
+                bt = self.prepare_batch(bt.regions, bt.shifts, bt.geno_offset_idx, bt.output_length, bt.keep, bt.keep_offsets,
+                                        bt.to_rc, bt.out_offsets, max_row_len=bt.max_row_len, total_len=total)
             elif bt.output_length >= 0:
                 total = n * bt.output_length
             else:
                 oo, tm, _ = self.hap_offsets(bt)
                 total, mx = (int(v) for v in tm.cpu().tolist())  # host sync (allocation size)
                 bt = self.prepare_batch(bt.regions, bt.shifts, bt.geno_offset_idx, bt.output_length,
-                                        bt.keep, bt.keep_offsets, bt.to_rc, oo, max_row_len=mx)
+                                        bt.keep, bt.keep_offsets, bt.to_rc, oo, max_row_len=mx, total_len=total)
             out, out_c = self.alloc_output(bt, total, haps=haps, onehot=onehot, layout=layout,
                                            annotate=annotate)
             if n == 0 or total == 0:

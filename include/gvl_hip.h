@@ -157,6 +157,11 @@ typedef struct gvl_batch {
                                       Replaces out_offsets (which must then be NULL); max_row_len bounds the rows as for
                                       out_offsets.  Disjointness is the caller's contract, as it is the Rust core's
                                       (the PyO3 layer checks it on the host: src/ffi/mod.rs:101-139). */
+    int64_t total_len_hint;        /* rows at out_offsets (ABI 11): the SUM of the rows' lengths when the caller knows it (it sized the
+                                      output: out_offsets[-1]), else 0.  Tells a batch of mostly short rows with a few long ones -- a
+                                      spliced batch's exons: the pipelined kernel takes it, rows longer than its 2560 bases by its
+                                      solo path -- from a batch of long rows (the chunked kernel).  Without it every batch whose
+                                      max_row_len exceeds 2560 takes the chunked kernel.  Results never depend on it. */
 } gvl_batch;
 
 /* Outputs; any of the data pointers may be NULL (that output is skipped), but

@@ -1219,3 +1219,47 @@ def test_long_rows_under_a_keep_mask(gpu, oracle, kpath, ragged):
             exp, _, exp_oh = oracle_fused(oracle, st, bt, onehot=True)
             np.testing.assert_array_equal(out.haps.cpu().numpy(), exp)
             np.testing.assert_array_equal(out.onehot.cpu().numpy(), exp_oh)
+
+
+@pytest.mark.parametrize("mode", ["plain", "keep", "annotated"])
+def test_ragged_batch_of_short_rows_with_a_few_long_ones(gpu, oracle, mode):
+    """A spliced batch's shape: hundreds of rows of a few hundred bases and a handful of several thousand (ragged, at out_offsets).  With
+    the caller's total (gvl_batch.total_len_hint: HapsDevice.reconstruct passes what it reads for the allocation) the pipelined kernel
+    takes the batch -- the long rows by its waves' solo path, chunk by chunk -- instead of handing every row to the chunked kernel.
+    == the oracle; the solo path saw exactly the long rows (+ whatever else the lean path defers)."""
+    import ctypes as C
+
+    from genvarloader_amd import synth
+
+    rng = np.random.default_rng(71)
+    st = synth.make_static(rng, (400_000,), indel_frac=0.3)
+    bt = synth.make_batch(rng, st, 700, 2, 300, rc_frac=0.5, output_length=-1, slack=10)
+    long_q = rng.choice(700, 9, replace=False)
+    bt.regions[long_q, 2] = bt.regions[long_q, 1] + rng.integers(2600, 9000, 9).astype(np.int32)
+    bt.regions[long_q, 2] = np.minimum(bt.regions[long_q, 2], 399_000)
+    if mode == "keep":
+        _with_keep(rng, bt, 0.6)
+    dev = make_dev(gpu, st, bt)
+    stamps = gpu.torch.zeros(64, dtype=gpu.torch.int64, device="cuda")
+    dev.lib.gvl_diag_set_stamps(C.c_void_p(stamps.data_ptr()))
+    try:
+        out = dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, -1, bt.keep, bt.keep_offsets, bt.to_rc, haps=True,
+                              onehot=mode != "annotated", annotate=mode == "annotated")
+        gpu.torch.cuda.synchronize()
+    finally:
+        dev.lib.gvl_diag_set_stamps(None)
+    from genvarloader_amd import _lib
+
+    _lib.check_async()
+    if mode == "annotated":
+        exp, av, ap, exp_off = oracle_fused(oracle, st, bt, annotate=True)
+        np.testing.assert_array_equal(out.annot_v_idxs.cpu().numpy(), av)
+        np.testing.assert_array_equal(out.annot_ref_pos.cpu().numpy(), ap)
+    else:
+        exp, exp_off, exp_oh = oracle_fused(oracle, st, bt, onehot=True)
+        np.testing.assert_array_equal(out.onehot.cpu().numpy(), exp_oh)
+    np.testing.assert_array_equal(out.out_offsets.cpu().numpy(), exp_off)
+    np.testing.assert_array_equal(out.haps.cpu().numpy(), exp)
+    n_long = int((np.diff(exp_off) > 2560).sum())
+    deferred = int(stamps[0])
+    assert n_long >= 12 and n_long <= deferred < 200, (n_long, deferred)       # (the pipelined kernel ran: its solo path counts what it takes)
