@@ -516,6 +516,96 @@ def secondary_long_modes(torch, n: int = 12) -> dict:
 
 
 
+def secondary_spliced(torch, n_tx: int = 1500, S: int = 8, pairs: int = 256, n: int = 20) -> dict:
+    """Spliced haplotypes under the exonic keep mask (Dataset with a splice map + `filter_exonic`: _dataset/_query.py:207-313,
+    src/genotypes/mod.rs:127-176, src/ffi/mod.rs:1981-2076): transcripts of 3-14 exons, exon lengths log-normal (median 160 bases,
+    one in thirty longer than the pipelined kernel's 2560), batches of `pairs` (transcript, sample) pairs through
+    DeviceSplicedHapsDataset.  `ms_per_step`: batches through the dataset object (Python submit loop: request prep, lengths, plan, keep
+    mask, one launch -- host clock, synchronised at the end); `kernel_ms`: that batch's ONE reconstruct launch on its own (HIP events),
+    next to the same launch under GVL_DBG 1073741824 (round 5's routing: the all-purpose kernel)."""
+    from genvarloader_amd import HapsDevice, _lib, synth
+    from genvarloader_amd.loader import DeviceSplicedHapsDataset
+
+    rng = np.random.default_rng(20260807)
+    st = synth.make_static(rng, (32 << 20,), indel_frac=0.15)
+    P = 2
+    n_ex = rng.integers(3, 15, n_tx)
+    ex_len = np.clip(np.exp(rng.normal(np.log(160.0), 0.95, int(n_ex.sum()))), 30, 9000).astype(np.int64)
+    intron = rng.integers(200, 3000, len(ex_len))
+    so = np.concatenate([[0], np.cumsum(n_ex)]).astype(np.int64)
+    starts = np.zeros(len(ex_len), np.int64)
+    strand = np.zeros(len(ex_len), np.int64)
+    for t in range(n_tx):
+        a, b = so[t], so[t + 1]
+        span = int((ex_len[a:b] + intron[a:b]).sum())
+        t0 = int(rng.integers(1000, (32 << 20) - span - 1000))
+        pos = t0 + np.concatenate([[0], np.cumsum(ex_len[a:b] + intron[a:b])[:-1]])
+        starts[a:b] = pos
+        strand[a:b] = 1 if rng.random() < 0.5 else -1
+    regions = np.stack([np.zeros(len(ex_len), np.int64), starts, starts + ex_len, strand], 1).astype(np.int32)
+    R = len(regions)
+    go, gv = synth.sample_genotypes(rng, st, np.repeat(regions[:, 0], S), np.repeat(regions[:, 1], S), np.repeat(regions[:, 2], S), P)
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens, alt_alleles=st.alt_alleles,
+                     alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv, pad_char=st.pad_char)
+    ds = DeviceSplicedHapsDataset(dev, regions, S, P, splice_offsets=so, splice_region_idx=np.arange(R), onehot=True, haps=True, exonic=True)
+    dl = ds.to_dataloader(batch_size=pairs, shuffle=True, seed=3)
+    it = iter(dl)
+    b = None
+    for _ in range(3):
+        b = next(it)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tot_bases = 0
+    for _ in range(n):
+        try:
+            b = next(it)
+        except StopIteration:
+            it = iter(dl)
+            b = next(it)
+        tot_bases += int(b.haps.numel())
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    _lib.check_async()
+    # the last batch's launch on its own
+    bt = b._keep._keepalive
+    oo = bt.out_offsets.cpu().numpy()
+    lens = np.diff(oo)
+    oc = _lib.GvlOut(haps=b.haps.data_ptr(), onehot=b.onehot.data_ptr(), onehot_layout=_lib.GVL_ONEHOT_LC)
+    goi = bt.geno_offset_idx.reshape(-1)
+    nv = float((dev.geno_offsets[1][goi] - dev.geno_offsets[0][goi]).double().mean())
+    ab = float(lens.sum()) * 6 + len(lens) * (29.0 * nv + 61.0)
+    lib = _lib.load()
+
+    def kern(flags):
+        lib.gvl_set_debug_flags(flags)
+        try:
+            for _ in range(3):
+                dev.launch(bt, oc)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                dev.launch(bt, oc)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n
+        finally:
+            lib.gvl_set_debug_flags(-1)
+
+    k_ms, k5_ms = kern(-1), kern(1073741824)
+    return {"workload": f"spliced haplotypes under the exonic keep mask: {pairs} (transcript, sample) pairs per batch = {len(lens)} exon rows "
+                        f"(mean {lens.mean():.0f} bases, {int((lens > 2560).sum())} longer than 2560, longest {int(lens.max())}), one-hot + bytes",
+            "ms_per_step": ms, "rows_per_s": len(lens) / (ms * 1e-3), "algorithmic_bytes_per_step": ab,
+            "step_frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "kernel_ms": k_ms, "kernel_frac": ab / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "r05_routing_kernel_ms": k5_ms, "r05_routing_kernel_frac": ab / (k5_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "kernel": "a batch of a few thousand short rows + a few long ones: the all-purpose kernel (launch-latency-bound: 7 MB of work); from 16 384 "
+                      "rows on recon_lean_rows_kernel<onehot, haps, ragged, keep mask> with the long rows by its solo path (tools/spliced_bench.py 4096)",
+            "how": "ms_per_step: batches through DeviceSplicedHapsDataset.to_dataloader (a Python submit loop with two host reads per batch: "
+                   "the keep mask's and the output's sizes), host clock; kernel_ms: the batch's one gvl_reconstruct launch, HIP events"}
+
+
+
 def secondary_random_shifts(torch, dev, ds, budget_s: float = 2.5) -> dict:
     """cfg3 in TRAINING mode (SURVEY 8d's cfg3 variant; _haps.py:678-768, _query.py:160-187): ``deterministic=False`` -- every haplotype's
     shift drawn from U[0, max_shift], max_shift from its query-mode length delta -- and ``jitter=16``, fixed-length one-hot rows, from
@@ -1156,6 +1246,7 @@ def main() -> None:
         except Exception as exc:
             secondary["annotated_long"] = {"error": repr(exc)}
         secondary["long_modes_s"] = round(time.perf_counter() - t_l, 2)
+        leg("spliced", lambda: secondary_spliced(torch))
 
     lean = (dev.ref4 is not None and dev.slot_rec is not None and L <= 2048 and L % 4 == 0
             and (int(os.environ.get("GVL_DBG", "0")) & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 33554432 | 67108864)) == 0)

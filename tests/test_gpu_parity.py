@@ -1233,8 +1233,8 @@ def test_ragged_batch_of_short_rows_with_a_few_long_ones(gpu, oracle, mode):
 
     rng = np.random.default_rng(71)
     st = synth.make_static(rng, (400_000,), indel_frac=0.3)
-    bt = synth.make_batch(rng, st, 700, 2, 300, rc_frac=0.5, output_length=-1, slack=10)
-    long_q = rng.choice(700, 9, replace=False)
+    bt = synth.make_batch(rng, st, 8300, 2, 300, rc_frac=0.5, output_length=-1, slack=10)      # (16 600 rows: the route needs >= 16 384)
+    long_q = rng.choice(8300, 9, replace=False)
     bt.regions[long_q, 2] = bt.regions[long_q, 1] + rng.integers(2600, 9000, 9).astype(np.int32)
     bt.regions[long_q, 2] = np.minimum(bt.regions[long_q, 2], 399_000)
     if mode == "keep":
@@ -1262,4 +1262,4 @@ def test_ragged_batch_of_short_rows_with_a_few_long_ones(gpu, oracle, mode):
     np.testing.assert_array_equal(out.haps.cpu().numpy(), exp)
     n_long = int((np.diff(exp_off) > 2560).sum())
     deferred = int(stamps[0])
-    assert n_long >= 12 and n_long <= deferred < 200, (n_long, deferred)       # (the pipelined kernel ran: its solo path counts what it takes)
+    assert n_long >= 12 and n_long <= deferred < 2000, (n_long, deferred)       # (the pipelined kernel ran: its solo path counts what it takes)
