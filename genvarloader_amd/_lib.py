@@ -92,7 +92,7 @@ class GvlBatch(C.Structure):
         ("regions", _vp), ("regions_stride", _i64), ("shifts", _vp), ("geno_offset_idx", _vp),
         ("batch", _i64), ("ploidy", _i64), ("keep", _vp), ("keep_offsets", _vp), ("to_rc", _vp),
         ("output_length", _i64), ("out_offsets", _vp), ("max_row_len", _i64), ("hap_plan", _vp),
-        ("out_bounds", _vp), ("total_len_hint", _i64),
+        ("out_bounds", _vp), ("total_len_hint", _i64), ("query_seed", _vp),
     ]
 
 

@@ -206,6 +206,7 @@ static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const 
     A.out = out;
     A.dbg = debug_flags();
     A.stamps = g_stamps;
+    A.query_seed = (const i64 *)bt->query_seed;
     if (A.n_rows > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: batch too large");
     const i64 grid = (A.n_rows + 3) / 4;
     // rows of several chunks: the rows' plans, once per batch (the caller's scratch; every track of the batch reads the same

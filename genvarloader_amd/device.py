@@ -548,12 +548,17 @@ def intervals_to_tracks(offset_idxs, starts, itv_starts, itv_ends, itv_values, i
 
 
 def realign_tracks(dev: "HapsDevice", regions, shifts, geno_offset_idx, out_offsets, tracks, track_offsets,
-                   params, strategy_id=0, base_seed=0, keep=None, keep_offsets=None, to_rc=None) -> torch.Tensor:
+                   params, strategy_id=0, base_seed=0, keep=None, keep_offsets=None, to_rc=None, query_seed=None) -> torch.Tensor:
     """shift_and_realign_tracks_sparse (src/tracks/mod.rs:495-667) + the reversal of negative-strand
     rows (src/ffi/mod.rs:2657-2668) -> f32[out_offsets[-1]] device tensor."""
     d = dev.device
     with torch.cuda.device(d):
         bt = dev.prepare_batch(regions, shifts, geno_offset_idx, -1, keep, keep_offsets, to_rc, out_offsets)
+        qs = _dev(query_seed, torch.int64, d)        # (src/tracks/mod.rs:754-760: the FlankSample seed's query component, per local query)
+        if qs is not None:
+            if qs.numel() != bt.regions.shape[0]:
+                raise ValueError("query_seed must have one entry per query")
+            bt.c.query_seed = qs.data_ptr()
         tr, to = _dev(tracks, torch.float32, d), _dev(track_offsets, torch.int64, d)
         total = int(bt.out_offsets[-1].item()) if bt.n_rows else 0
         out = torch.empty(total, dtype=torch.float32, device=d)
@@ -564,5 +569,5 @@ def realign_tracks(dev: "HapsDevice", regions, shifts, geno_offset_idx, out_offs
                                               C.c_int64(int(strategy_id)),
                                               C.c_uint64(int(base_seed) & 0xFFFFFFFFFFFFFFFF), _ptr(out),
                                               _stream_ptr()))
-        out._keepalive = (bt, tr, to)
+        out._keepalive = (bt, tr, to, qs)
         return out

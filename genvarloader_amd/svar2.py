@@ -237,6 +237,30 @@ def reconstruct_haplotypes_from_svar2_into(
         out[...] = ffi._np(buf)
 
 
+def shift_and_realign_tracks_from_svar2_into(
+    out, out_offsets, regions, shifts, vk_pos, vk_ilen, vk_off, dense_pos, dense_ilen, dense_range, dense_present,
+    dense_present_off, tracks, track_offsets, params, strategy_id=0, base_seed=0, query_seed=None, parallel=False,
+):
+    """The core (src/tracks/mod.rs:705-860), in place: rows at the caller's ``out_offsets``; ``query_seed`` (n_q,) maps the local
+    query index to the batch row the FlankSample fill is seeded with (a logical batch that arrives in several calls)."""
+    from . import ffi
+
+    if not (isinstance(out, np.ndarray) and out.dtype == np.float32 and out.flags.c_contiguous):
+        raise ValueError("`out` must be a C-contiguous float32 array")
+    regions = np.ascontiguousarray(regions, np.int32)
+    shifts = np.ascontiguousarray(shifts, np.int32)
+    n_vk, n_dense = len(np.asarray(vk_pos).reshape(-1)), len(np.asarray(dense_pos).reshape(-1))
+    dev = _ref_static(np.zeros(1, np.uint8), np.array([0, 1], np.int64), ord("N"))
+    ch = _channels(vk_pos, vk_ilen, np.zeros(n_vk + 1, np.int64), vk_off, dense_pos, dense_ilen, np.zeros(n_dense + 1, np.int64),
+                   dense_range, dense_present, dense_present_off, np.zeros(0, np.uint8), False, dev.device)
+    reg0 = regions.copy()
+    reg0[:, 0] = 0
+    m = merge(dev, ch, reg0, shifts.shape[1])
+    res = _device.realign_tracks(m, m.regions, shifts, m.geno_offset_idx, np.ascontiguousarray(out_offsets, np.int64), tracks,
+                                 track_offsets, params, strategy_id, base_seed, query_seed=query_seed)
+    out[...] = ffi._np(res)
+
+
 def shift_and_realign_tracks_from_svar2(
     regions, shifts, vk_pos, vk_ilen, vk_off, dense_pos, dense_ilen, dense_range, dense_present, dense_present_off,
     tracks, track_offsets, params, strategy_id, base_seed, parallel=False,

@@ -162,6 +162,11 @@ typedef struct gvl_batch {
                                       spliced batch's exons: the pipelined kernel takes it, rows longer than its 2560 bases by its
                                       solo path -- from a batch of long rows (the chunked kernel).  Without it every batch whose
                                       max_row_len exceeds 2560 takes the chunked kernel.  Results never depend on it. */
+    const int64_t *query_seed;     /* tracks only (ABI 11), nullable: i64 (batch): the GLOBAL batch row of local query q -- the `query`
+                                      component of the FlankSample fill's per-position seed (src/tracks/mod.rs:744-760: callers that
+                                      split one logical batch across several calls, as the SVAR2 read-bound path's per-contig-group
+                                      loop does, pass the group's global rows so that seed-dependent fills match the single fused
+                                      call).  NULL: the local index (exact for one call per batch). */
 } gvl_batch;
 
 /* Outputs; any of the data pointers may be NULL (that output is skipped), but

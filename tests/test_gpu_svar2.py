@@ -415,3 +415,28 @@ def test_c_abi_fused_entry_and_refusals(gpu, sv2, oracle):
     with pytest.raises(_lib.GvlError, match="no keep masks or annotations"):
         _lib.check(lib.gvl_svar2_reconstruct(C.byref(dev.c), C.byref(ch.c), C.byref(b), C.byref(o2), C.c_void_p(wp), C.c_int64(nbytes), _stream_ptr()))
     _ = _ptr
+
+
+def test_tracks_query_seed_map(gpu, sv2, oracle):
+    """The FlankSample fill's seed takes the GLOBAL batch row through `query_seed` (src/tracks/mod.rs:754-760, gvl_batch.query_seed):
+    one logical batch realigned in two calls with the groups' global rows == the single fused call; and == the oracle."""
+    st, bt, sv = _synth(91, 40, 1024, 0.4, 0.3, out_len=-1, rc=0.0, edge=0.0)
+    rng = np.random.default_rng(9)
+    d = oracle.hap_diffs_svar2(bt.regions, 2, sv.vk_pos, sv.vk_ilen, sv.vk_off, sv.dense_pos, sv.dense_ilen, sv.dense_range,
+                               sv.dense_present, sv.dense_present_off)
+    reg_len = (bt.regions[:, 2] - bt.regions[:, 1]).astype(np.int64)
+    tlen = reg_len - np.minimum(d.min(axis=1), 0)
+    toff = np.concatenate([[0], np.cumsum(tlen)]).astype(np.int64)
+    tracks = rng.random(int(toff[-1])).astype(np.float32)
+    lens = np.maximum(reg_len[:, None] + d, 0).reshape(-1)
+    ooff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    common = (sv.vk_pos, sv.vk_ilen, sv.vk_off, sv.dense_pos, sv.dense_ilen, sv.dense_range, sv.dense_present, sv.dense_present_off)
+    qmap = rng.permutation(1000)[:40].astype(np.int64)            # an arbitrary local -> global map
+    exp = np.zeros(int(ooff[-1]), np.float32)
+    oracle.shift_and_realign_tracks_from_svar2_into(exp, ooff, bt.regions, bt.shifts, *common, tracks, toff, [6.0], 3, 777, qmap)
+    got = np.zeros_like(exp)
+    sv2.shift_and_realign_tracks_from_svar2_into(got, ooff, bt.regions, bt.shifts, *common, tracks, toff, [6.0], 3, 777, qmap)
+    np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32))
+    plain = np.zeros_like(exp)
+    sv2.shift_and_realign_tracks_from_svar2_into(plain, ooff, bt.regions, bt.shifts, *common, tracks, toff, [6.0], 3, 777, None)
+    assert (plain.view(np.uint32) != got.view(np.uint32)).any()    # (the map matters: the draws differ)
