@@ -124,3 +124,15 @@ def test_fuzz_lean_kernel_many_batches_one_grid(ragged):
     """FUZZ_MANY=1: 4-16 batches of 1 500-6 000 queries in ONE multi-workgroup grid on default flags (what bench.py times and the
     native loader launches), 1 / 1.5 / 2 / 3 / 8 rows per wave, every batch of every launch against the oracle."""
     _run("fuzz_lean.py", 24, 250 + ragged, FUZZ_MANY=1, FUZZ_RAGGED=ragged)
+
+
+def test_fuzz_svar2_provider():
+    """tools/fuzz_svar2.py: random two-source batches (windows across the packed form's 16 entries and the general form's 64-entry
+    tiles, filter_exonic, ragged / fixed, shifts, RC) -- gvl_svar2_merge + the kernels over the merged table vs the oracle's provider."""
+    _run("fuzz_svar2.py", 250, 201)
+
+
+def test_fuzz_svar2_provider_csr_routes():
+    """... with the slot lines ignored (GVL_DBG 64: records through the merged table's CSR) and through the vrec gather (80)."""
+    _run("fuzz_svar2.py", 120, 202, dbg=64)
+    _run("fuzz_svar2.py", 120, 203, dbg=80)
