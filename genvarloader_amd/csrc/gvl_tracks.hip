@@ -170,7 +170,7 @@ int gvl_paint_tracks(const gvl_track_set *ts, const int64_t *offset_idxs, const 
 static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const float *tracks,
                                const int64_t *track_offsets, const double *params, int64_t strategy_id,
                                uint64_t base_seed, const u64 *seed_ptr, float *out, void *stream, const PaintSrcArgs *ps = nullptr,
-                               int2 *plan_hdr = nullptr, i32x4 *plan_ent = nullptr, bool plan_make = false);
+                               int2 *plan_hdr = nullptr, i32x4 *plan_ent = nullptr, bool plan_make = false, int to_shift = 0);
 int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *tracks,
                        const int64_t *track_offsets, const double *params, int64_t strategy_id,
                        uint64_t base_seed, float *out, void *stream) {
@@ -179,7 +179,7 @@ int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *t
 static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const float *tracks,
                                const int64_t *track_offsets, const double *params, int64_t strategy_id,
                                uint64_t base_seed, const u64 *seed_ptr, float *out, void *stream, const PaintSrcArgs *ps,
-                               int2 *plan_hdr, i32x4 *plan_ent, bool plan_make) {
+                               int2 *plan_hdr, i32x4 *plan_ent, bool plan_make, int to_shift) {
     if (!st || !bt) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: NULL struct");
     if (bt->batch < 0 || bt->ploidy <= 0) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: bad batch/ploidy");
     if (bt->batch == 0) return GVL_OK;
@@ -207,6 +207,7 @@ static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const 
     A.dbg = debug_flags();
     A.stamps = g_stamps;
     A.query_seed = (const i64 *)bt->query_seed;
+    A.to_shift = to_shift;
     if (A.n_rows > 0x7FFFFFFFll) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: batch too large");
     const i64 grid = (A.n_rows + 3) / 4;
     // rows of several chunks: the rows' plans, once per batch (the caller's scratch; every track of the batch reads the same
@@ -234,7 +235,7 @@ static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const 
 // chunk records (16 B x batch * chunks) | scratch tracks f32 (batch * stride) | row plans (track_plan_bytes)
 static void tracks_scratch_parts(i64 batch, i64 ploidy, i64 stride, i64 part[6]) {
     const i64 n_chunks = (stride + 2047) / 2048;
-    const i64 sz[5] = {8 * (batch + 1), 8 * (batch * ploidy + 1), batch * n_chunks * (i64)sizeof(PaintTodo), 4 * batch * stride,
+    const i64 sz[5] = {16 * (batch + 1), 8 * (batch * ploidy + 1), batch * n_chunks * (i64)sizeof(PaintTodo), 4 * batch * stride,
                        n_chunks > 1 ? track_plan_bytes(batch * ploidy, n_chunks) : 0};
     i64 off = 0;
     for (int i = 0; i < 5; ++i) { part[i] = off; off += (sz[i] + 255) & ~255ll; }
@@ -296,17 +297,30 @@ int gvli::tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const int
     int rc = fill_diff_args(D, st, bt, "gvl_tracks_batch");
     if (rc) return rc;
     D.keep = nullptr; D.keep_offsets = nullptr;
+    // (every track realigned straight from its intervals: nobody reads a scratch track, so only the LENGTHS are needed -- stored as
+    // (0, length) pairs, no scan launch)
+    bool all_fused = !(debug_flags() & 4194304);
+    for (int t = 0; t < n_tracks && all_fused; ++t) {
+        const gvl_track_set &T = tracks[t];
+        all_fused = T.tile_complete != 0 && T.bkt_offsets && T.bkt_base && T.bkt_lo && T.bkt_hi && !(debug_flags() & 1024) && T.itv_pmax_ends;
+    }
+    int to_shift = 0;
     if (pre_track_offsets && pre_out_offsets) {
         track_offsets = const_cast<i64 *>(pre_track_offsets);
         out_offsets = const_cast<i64 *>(pre_out_offsets);
     } else {
-        const i64 grid = (B * WAVE + 255) / 256;            // one wave per query (covers the K + 1 offsets too)
-        track_lengths_kernel<<<dim3((unsigned)grid), dim3(256), 0, s>>>(D, bt->regions, (i64)bt->regions_stride, B, L, track_offsets, out_offsets);
+        const bool per_hap = P == 1 || P == 2 || P == 4;      // a wave per (query, haplotype), 4 / P queries per workgroup
+        const i64 grid = per_hap ? (B * P + 3) / 4 : (B * WAVE + 255) / 256;
+        // (the kernel also writes the K + 1 row offsets, grid-stride: any grid covers them)
+        to_shift = all_fused ? 1 : 0;
+        track_lengths_kernel<<<dim3((unsigned)grid), dim3(256), 0, s>>>(D, bt->regions, (i64)bt->regions_stride, B, L, track_offsets, out_offsets, to_shift);
         rc = check_launch("gvl_tracks_batch(lengths)");
         if (rc) return rc;
-        offsets_scan_kernel<<<dim3(1), dim3(1024), 0, s>>>(track_offsets, B, (i64 *)nullptr);
-        rc = check_launch("gvl_tracks_batch(scan)");
-        if (rc) return rc;
+        if (!all_fused) {
+            offsets_scan_kernel<<<dim3(1), dim3(1024), 0, s>>>(track_offsets, B, (i64 *)nullptr);
+            rc = check_launch("gvl_tracks_batch(scan)");
+            if (rc) return rc;
+        }
     }
     // 2. per track: paint the query's intervals into its scratch track, realign it to every haplotype
     gvl_batch rb = *bt;
@@ -331,7 +345,7 @@ int gvli::tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const int
             PaintSrcArgs ps{(const i64 *)offset_idxs, T.list_div > 1 ? T.list_div : 1, T.itv_starts, T.itv_ends, T.itv_values,
                             (const i64 *)T.itv_offsets, T.itv_pmax_ends, X};
             rc = realign_tracks_impl(st, &rb, nullptr, (const int64_t *)track_offsets, T.has_fill ? t_par : params, t_strategy, base_seed,
-                                     seed_ptr, out + (i64)t * out_track_stride, stream, &ps, plan_hdr, plan_ent, !plan_made);
+                                     seed_ptr, out + (i64)t * out_track_stride, stream, &ps, plan_hdr, plan_ent, !plan_made, to_shift);
             if (rc) return rc;
             plan_made = true;
             continue;
