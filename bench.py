@@ -659,6 +659,8 @@ def main() -> None:
     ap.add_argument("--queries", type=int, default=None, help="override the number of queries in the dataset")
     ap.add_argument("--haps", action="store_true", help="also materialise haplotype bytes (h=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the `verified` block (two batches of the last timed launch rebuilt by the oracle and compared byte for byte)")
     ap.add_argument("--cpu-only", action="store_true", help="time the CPU oracle only (cfg1 plumbing case); no GPU")
     ap.add_argument("--cpu-budget", type=float, default=8.0)
     ap.add_argument("--streams", type=int, default=3,
@@ -948,7 +950,7 @@ def main() -> None:
     # arguments launched once more); two of its batches, one at an in-group position >= 11 -- where the second rows of the two-row
     # waves live -- are rebuilt on the host and compared byte for byte with what the kernel left in the output slots.
     verified = None
-    if rank == 0 and not args.no_cpu_baseline and not args.strong:
+    if rank == 0 and not args.no_verify and not args.strong:      # (round 6: with or without the cpu_baseline leg -- every line checks what it timed)
         from oracle import oracle as _orc
 
         # (with the sustained leg: its last launch wrote the dedicated set `vslots`; without it: the timed region's packed arguments,
