@@ -123,6 +123,36 @@ def shard_batch(rank: int, world: int, regions, shifts, geno_offset_idx, to_rc=N
     return out
 
 
+def shard_svar2_batch(rank: int, world: int, regions, shifts, vk_pos, vk_ilen, vk_alt_off, vk_off, dense_pos, dense_ilen, dense_alt_off,
+                      dense_range, dense_present, dense_present_off, alt_bytes) -> dict:
+    """This rank's contiguous block of QUERIES of a SVAR2 two-source batch (decoded channels, ``genvarloader_amd.svar2``): the
+    haplotypes' var_key slices, the queries' dense windows and the haplotypes' presence bits are cut out and re-based, so that the
+    shard is a batch of its own -- same bytes for its rows as the full batch gives them (rows are independent:
+    ``src/reconstruct/mod.rs:654-757``).  The allele pool is shared by reference (offsets into it stay what they are)."""
+    regions, shifts = np.asarray(regions), np.asarray(shifts)
+    B, P = shifts.shape
+    lo, hi = shard_bounds(B, world, rank)
+    k0, k1 = lo * P, hi * P
+    vo = np.asarray(vk_off, np.int64)
+    dr = np.asarray(dense_range, np.int64).reshape(-1, 2)
+    po = np.asarray(dense_present_off, np.int64)
+    v0, v1 = int(vo[k0]), int(vo[k1])
+    d0 = int(dr[lo:hi, 0].min()) if hi > lo else 0
+    d1 = int(dr[lo:hi, 1].max()) if hi > lo else 0
+    d1 = max(d1, d0)
+    b0, b1 = int(po[k0]), int(po[k1])
+    bits = np.unpackbits(np.asarray(dense_present, np.uint8).reshape(-1), bitorder="little")[b0:b1]
+    return dict(
+        regions=regions[lo:hi], shifts=shifts[lo:hi],
+        vk_pos=np.asarray(vk_pos)[v0:v1], vk_ilen=np.asarray(vk_ilen)[v0:v1], vk_alt_off=np.asarray(vk_alt_off, np.int64)[v0:v1 + 1],
+        vk_off=vo[k0:k1 + 1] - v0,
+        dense_pos=np.asarray(dense_pos)[d0:d1], dense_ilen=np.asarray(dense_ilen)[d0:d1],
+        dense_alt_off=np.asarray(dense_alt_off, np.int64)[d0:d1 + 1],
+        dense_range=(dr[lo:hi] - d0).astype(np.int32), dense_present=np.packbits(bits, bitorder="little"),
+        dense_present_off=po[k0:k1 + 1] - b0, alt_bytes=np.asarray(alt_bytes, np.uint8),
+        query_range=(lo, hi), row_range=(k0, k1))
+
+
 def all_gather_rows(local, row_lengths=None, group=None):
     """Gather every rank's rows on every rank, in rank order.
 

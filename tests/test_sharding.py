@@ -186,3 +186,27 @@ def test_shard_genotypes_by_sample_partitions_the_csr():
     lo_n, lv_n, rng_n = sharding.shard_genotypes_by_sample(go, gv, R, S, P, 3, 1)
     assert rng_t == rng_n and torch.equal(lo_t, torch.from_numpy(lo_n)) and torch.equal(lv_t, torch.from_numpy(lv_n))
     np.testing.assert_array_equal(sharding.shard_genotypes_by_sample(off, gv, R, S, P, 3, 1)[0], lo_n)    # (n + 1,) offsets too
+
+
+def test_shard_svar2_batch_rows_equal_the_full_batch(oracle):
+    """A SVAR2 two-source batch cut into per-rank query blocks (shard_svar2_batch re-bases var_key slices, dense windows and presence
+    bits): every rank's rows == the same rows of the full batch (oracle), for 1 .. 5 ranks, ragged output."""
+    from genvarloader_amd import synth
+
+    rng = np.random.default_rng(17)
+    st = synth.make_static(rng, (150_000,), indel_frac=0.3)
+    bt = synth.make_batch(rng, st, 23, 2, 700, output_length=-1)
+    sv = synth.to_svar2(rng, st, bt, dense_af=0.3)
+    full, foff = oracle.reconstruct_haplotypes_from_svar2(bt.regions, bt.shifts, *sv.args(), st.ref, st.ref_offsets, st.pad_char, -1)
+    for world in (1, 2, 3, 5):
+        got = []
+        for rank in range(world):
+            sh = sharding.shard_svar2_batch(rank, world, bt.regions, bt.shifts, *sv.args())
+            out, off = oracle.reconstruct_haplotypes_from_svar2(
+                sh["regions"], sh["shifts"], sh["vk_pos"], sh["vk_ilen"], sh["vk_alt_off"], sh["vk_off"], sh["dense_pos"], sh["dense_ilen"],
+                sh["dense_alt_off"], sh["dense_range"], sh["dense_present"], sh["dense_present_off"], sh["alt_bytes"], st.ref,
+                st.ref_offsets, st.pad_char, -1)
+            k0, k1 = sh["row_range"]
+            np.testing.assert_array_equal(np.diff(off), np.diff(foff[k0:k1 + 1]))
+            got.append(out)
+        np.testing.assert_array_equal(np.concatenate(got), full)
