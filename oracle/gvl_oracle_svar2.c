@@ -17,9 +17,11 @@
  * turns symbolic keys (the reference's test inputs: encode_alt_inline / encode_pure_del / encode_lookup) into
  * that form.  Nothing here guesses the codec's bits.
  *
- * Parity status: pinned by the reference's Rust known-answer tests only (src/svar2/mod.rs:598-700,
+ * Parity status: pinned by the reference's Rust known-answer tests (src/svar2/mod.rs:598-700,
  * src/reconstruct/mod.rs:1540-1813, src/tracks/mod.rs:2480-2567; no 200-case golden exists for these entry
- * points), transcribed in tests/test_oracle_kats.py -- and, through the shared cores, by everything that pins
+ * points), transcribed in tests/svar2_kats.py; by 192 haplotypes of the reference's INDEPENDENT Python consensus
+ * (tests/test_svar2_reconstruct.py:66-93, run at fixture-generation time: tests/golden/pyref_svar2_consensus.npz)
+ * -- and, through the shared cores, by everything that pins
  * gvlo_reconstruct_row / gvlo_realign_track_row (the SVAR2 drivers call the same `reconstruct_haplotype_core` /
  * `shift_and_realign_track_core` the SVAR1 drivers call).
  */

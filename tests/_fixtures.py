@@ -35,3 +35,12 @@ def load_pyref(name: str) -> dict:
     for k in ("to_rc", "keep", "keep_offsets", "expected_annot_v_idxs", "expected_annot_ref_pos"):
         d.setdefault(k, None)
     return d
+
+
+def load_svar2_consensus():
+    """tests/golden/pyref_svar2_consensus.npz (make_svar2_fixture.py): decoded two-source channels + the bytes of the reference's
+    independent ``_consensus`` (tests/test_svar2_reconstruct.py:66-93) -> list of dicts."""
+    z = np.load(GOLDEN / "pyref_svar2_consensus.npz")
+    keys = ("ref", "ref_offsets", "regions", "ploidy", "vk_pos", "vk_ilen", "vk_alt_off", "vk_off", "dense_pos", "dense_ilen",
+            "dense_alt_off", "dense_range", "dense_present", "dense_present_off", "alt_bytes", "expected", "expected_offsets")
+    return [{k: _unbox(z[f"{i}/{k}"]) for k in keys} for i in range(int(z["n"]))]

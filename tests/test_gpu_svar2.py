@@ -440,3 +440,15 @@ def test_tracks_query_seed_map(gpu, sv2, oracle):
     plain = np.zeros_like(exp)
     sv2.shift_and_realign_tracks_from_svar2_into(plain, ooff, bt.regions, bt.shifts, *common, tracks, toff, [6.0], 3, 777, None)
     assert (plain.view(np.uint32) != got.view(np.uint32)).any()    # (the map matters: the draws differ)
+
+
+def test_reference_consensus_vectors(gpu, sv2, kpath):
+    """tests/golden/pyref_svar2_consensus.npz -- the reference's independent `_consensus` over its own VCF fixture and 176 synthetic
+    haplotypes -- through the HIP path, down every kernel path."""
+    from tests._fixtures import load_svar2_consensus
+    from tests.test_oracle_svar2 import _consensus_args
+
+    for i, c in enumerate(load_svar2_consensus()):
+        got, off = sv2.reconstruct_haplotypes_from_svar2(*_consensus_args(c))
+        np.testing.assert_array_equal(off, c["expected_offsets"], err_msg=f"case {i}")
+        np.testing.assert_array_equal(got, c["expected"], err_msg=f"case {i}")

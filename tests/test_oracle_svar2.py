@@ -145,3 +145,27 @@ def test_filter_exonic_equals_svar1_keep_mask(oracle):
                                                          filter_exonic=True)
     np.testing.assert_array_equal(off, off2)
     np.testing.assert_array_equal(exp, got)
+
+
+def _consensus_args(c):
+    B, P = c["regions"].shape[0], int(c["ploidy"])
+    return (c["regions"], np.zeros((B, P), np.int32), c["vk_pos"], c["vk_ilen"], c["vk_alt_off"], c["vk_off"], c["dense_pos"],
+            c["dense_ilen"], c["dense_alt_off"], c["dense_range"], c["dense_present"], c["dense_present_off"], c["alt_bytes"], c["ref"],
+            c["ref_offsets"], ord("N"), -1)
+
+
+def test_reference_consensus_vectors(oracle):
+    """The reference's INDEPENDENT consensus (tests/test_svar2_reconstruct.py:66-93, run at fixture-generation time over its own VCF
+    fixture and 176 synthetic haplotypes: tests/golden/make_svar2_fixture.py): the oracle's SVAR2 provider gives its bytes at its
+    lengths (ragged output = region length + hap_diffs_svar2)."""
+    from tests._fixtures import load_svar2_consensus
+
+    cases = load_svar2_consensus()
+    assert len(cases) == 13 and sum(len(c["expected_offsets"]) - 1 for c in cases) == 192
+    for i, c in enumerate(cases):
+        got, off = oracle.reconstruct_haplotypes_from_svar2(*_consensus_args(c))
+        np.testing.assert_array_equal(off, c["expected_offsets"], err_msg=f"case {i}")
+        np.testing.assert_array_equal(got, c["expected"], err_msg=f"case {i}")
+    # the reference test's own expectation, spelled out (S0 hap 0: SNP A>G at 2, DEL GTA>G at 11)
+    c = cases[0]
+    assert c["expected"][:int(c["expected_offsets"][1])].tobytes() == b"ACGGTACATGGGCTAGCTAGGCTAACCGGTTAACCGGT"

@@ -22,3 +22,5 @@ run tools/fuzz_tracks.py 0 "" $((N / 4)) 4006; run tools/fuzz_tracks.py 8 "" $((
 run tools/fuzz_fused_tracks.py 0 "" $((N / 10)) 4008; run tools/fuzz_fused_tracks.py 2097152 "" $((N / 10)) 4009
 run tools/fuzz_fused_tracks.py 268435456 "" $((N / 10)) 4013      # (no row plans: every chunk walks)
 run tools/fuzz_fused_tracks.py 1073741824 "" $((N / 10)) 4014     # (the general track kernel for every chunk)
+echo "== fuzz_svar2.py (round 6: the SVAR2 two-source provider -- merge + the kernels over the merged table vs the oracle's provider)"
+for d in 0 64 80 8 16384 67108864; do run tools/fuzz_svar2.py $d "" $N 4030; done
