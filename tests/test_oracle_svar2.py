@@ -169,3 +169,59 @@ def test_reference_consensus_vectors(oracle):
     # the reference test's own expectation, spelled out (S0 hap 0: SNP A>G at 2, DEL GTA>G at 11)
     c = cases[0]
     assert c["expected"][:int(c["expected_offsets"][1])].tobytes() == b"ACGGTACATGGGCTAGCTAGGCTAACCGGTTAACCGGT"
+
+
+@pytest.mark.parametrize("strategy", [0, 3, 4])
+def test_svar2_tracks_equal_the_svar1_realign(oracle, strategy):
+    """What the reference's own end-to-end test asserts (tests/test_svar2_realign_tracks.py:1-9): the SVAR2 track driver == the SVAR1
+    realign (shift_and_realign_tracks_sparse, pinned by the reference's 200 goldens + its numpy fallback's vectors) fed the same
+    haplotypes -- on that test's DEL-only records (POS 4 GTA>G, POS 10 GGG>G; S0 1|0 0|1, S1 1|1 1|0) and on synthetic batches."""
+    from genvarloader_amd import synth
+
+    # the reference test's store as decode records: pure DELs at 3 and 9, ilen -2 (empty alleles)
+    haps = [[0], [1], [0, 1], [0]]                           # S0 hap0: DEL@3; S0 hap1: DEL@9; S1 hap0: both; S1 hap1: DEL@3
+    v_starts, ilens = np.array([3, 9], np.int32), np.array([-2, -2], np.int32)
+    regions = np.array([[0, 0, 40], [0, 0, 40]], np.int32)
+    go = np.concatenate([[0], np.cumsum([len(h) for h in haps])]).astype(np.int64)
+    gv = np.concatenate(haps).astype(np.int32)
+    rng = np.random.default_rng(3)
+    tracks = rng.random(80).astype(np.float32)
+    toff = np.array([0, 40, 80], np.int64)
+    shifts = np.zeros((2, 2), np.int32)
+    d1 = oracle.get_diffs_sparse(np.arange(4).reshape(2, 2), gv, go, ilens, None, None, regions[:, 1].copy(), regions[:, 2].copy(), v_starts)
+    lens = (40 + d1).reshape(-1).astype(np.int64)
+    ooff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    exp = np.zeros(int(ooff[-1]), np.float32)
+    oracle.shift_and_realign_tracks_sparse(exp, ooff, regions, shifts, np.arange(4).reshape(2, 2), gv, go, v_starts, ilens, tracks, toff,
+                                           [2.0], None, None, strategy, 11)
+    # two-source form: everything in var_key / everything dense
+    for dense in (False, True):
+        if dense:
+            args = (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(5, np.int64), v_starts, ilens, [[0, 2], [0, 2]],
+                    np.packbits(np.array([1, 0, 0, 1, 1, 1, 1, 0], bool), bitorder="little"), [0, 2, 4, 6, 8])
+        else:
+            args = (v_starts[gv], ilens[gv], go, np.zeros(0, np.int32), np.zeros(0, np.int32), [[0, 0], [0, 0]], np.zeros(0, np.uint8),
+                    [0, 0, 0, 0, 0])
+        got, off = oracle.shift_and_realign_tracks_from_svar2(regions, shifts, *args, tracks, toff, [2.0], strategy, 11)
+        np.testing.assert_array_equal(off, ooff)
+        np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32))
+    # synthetic
+    rng = np.random.default_rng(40 + strategy)
+    st = synth.make_static(rng, (120_000,), indel_frac=0.4)
+    bt = synth.make_batch(rng, st, 30, 2, 900, output_length=-1)
+    sv = synth.to_svar2(rng, st, bt, dense_af=0.3)
+    d = oracle.get_diffs_sparse(bt.geno_offset_idx, bt.geno_v_idxs, bt.geno_offsets, st.ilens, None, None,
+                                np.ascontiguousarray(bt.regions[:, 1]), np.ascontiguousarray(bt.regions[:, 2]), st.v_starts)
+    reg_len = (bt.regions[:, 2] - bt.regions[:, 1]).astype(np.int64)
+    tlen = reg_len - np.minimum(d.min(axis=1), 0)
+    toff = np.concatenate([[0], np.cumsum(tlen)]).astype(np.int64)
+    tracks = rng.random(int(toff[-1])).astype(np.float32)
+    ooff = np.concatenate([[0], np.cumsum(np.maximum(reg_len[:, None] + d, 0).reshape(-1))]).astype(np.int64)
+    exp = np.zeros(int(ooff[-1]), np.float32)
+    oracle.shift_and_realign_tracks_sparse(exp, ooff, bt.regions, bt.shifts, bt.geno_offset_idx, bt.geno_v_idxs, bt.geno_offsets,
+                                           st.v_starts, st.ilens, tracks, toff, [3.0], None, None, strategy, 99)
+    got, off = oracle.shift_and_realign_tracks_from_svar2(bt.regions, bt.shifts, sv.vk_pos, sv.vk_ilen, sv.vk_off, sv.dense_pos,
+                                                          sv.dense_ilen, sv.dense_range, sv.dense_present, sv.dense_present_off,
+                                                          tracks, toff, [3.0], strategy, 99)
+    np.testing.assert_array_equal(off, ooff)
+    np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32))
