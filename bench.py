@@ -516,7 +516,7 @@ def secondary_long_modes(torch, n: int = 12) -> dict:
 
 
 
-def secondary_spliced(torch, n_tx: int = 1500, S: int = 8, pairs: int = 256, n: int = 20) -> dict:
+def secondary_spliced(torch, n_tx: int = 1500, S: int = 8, pairs: int = 256, n: int = 20, max_exon: int = 9000, exonic: bool = True) -> dict:
     """Spliced haplotypes under the exonic keep mask (Dataset with a splice map + `filter_exonic`: _dataset/_query.py:207-313,
     src/genotypes/mod.rs:127-176, src/ffi/mod.rs:1981-2076): transcripts of 3-14 exons, exon lengths log-normal (median 160 bases,
     one in thirty longer than the pipelined kernel's 2560), batches of `pairs` (transcript, sample) pairs through
@@ -530,7 +530,7 @@ def secondary_spliced(torch, n_tx: int = 1500, S: int = 8, pairs: int = 256, n: 
     st = synth.make_static(rng, (32 << 20,), indel_frac=0.15)
     P = 2
     n_ex = rng.integers(3, 15, n_tx)
-    ex_len = np.clip(np.exp(rng.normal(np.log(160.0), 0.95, int(n_ex.sum()))), 30, 9000).astype(np.int64)
+    ex_len = np.clip(np.exp(rng.normal(np.log(160.0), 0.95, int(n_ex.sum()))), 30, max_exon).astype(np.int64)
     intron = rng.integers(200, 3000, len(ex_len))
     so = np.concatenate([[0], np.cumsum(n_ex)]).astype(np.int64)
     starts = np.zeros(len(ex_len), np.int64)
@@ -547,7 +547,7 @@ def secondary_spliced(torch, n_tx: int = 1500, S: int = 8, pairs: int = 256, n: 
     go, gv = synth.sample_genotypes(rng, st, np.repeat(regions[:, 0], S), np.repeat(regions[:, 1], S), np.repeat(regions[:, 2], S), P)
     dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens, alt_alleles=st.alt_alleles,
                      alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv, pad_char=st.pad_char)
-    ds = DeviceSplicedHapsDataset(dev, regions, S, P, splice_offsets=so, splice_region_idx=np.arange(R), onehot=True, haps=True, exonic=True)
+    ds = DeviceSplicedHapsDataset(dev, regions, S, P, splice_offsets=so, splice_region_idx=np.arange(R), onehot=True, haps=True, exonic=exonic)
     dl = ds.to_dataloader(batch_size=pairs, shuffle=True, seed=3)
     it = iter(dl)
     b = None

@@ -342,12 +342,14 @@ int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
 // one way a row can reach its output, so that the GPU suite can be run down every path:
 //     8  every row through the scalar walk (haplotypes and tracks)
 //    32  no scan-free plan for SNP-only rows (they join the packed plan)
+//   256  a mixed ragged launch's long rows by the wave that meets them, chunk after chunk (no front workgroups: lean_solo_rows' crews)
 //   512  no packable rows at all (every row runs the per-wave scans)
 //    16  ignore gvl_static.geno_rec (records come from geno_v_idxs -> vrec)
 //    64  ignore gvl_static.slot_rec (rows find their records through the CSR)
 //   128  no speculative reference reads in front of the plan
 //  1024  painter ignores the per-list bucket index (exact 64-ary searches per chunk)
 //  2048  length deltas (get_diffs_sparse, ragged sizing) always one wave per row
+//  4096  gvl_tracks_batch sizes its scratch tracks in a launch of its own (not inside the first track's row-plan launch)
 //  8192  painter always paints an LDS image (no start-bitmap lookup for non-overlapping candidates)
 // 16384  no lean kernel (the all-purpose kernel over every row, as before round 3)
 // 32768  the lean kernel hands EVERY row to its solo general path (per-wave scans from the byte reference)

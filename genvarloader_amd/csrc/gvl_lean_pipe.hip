@@ -70,7 +70,10 @@ int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks) 
         rpw = rpw > PIPE_MAX_ROWS ? PIPE_MAX_ROWS : (rpw < 1 ? 1 : rpw);
         waves = (total + rpw - 1) / rpw;
     }
-    const unsigned grid = (unsigned)((waves + LEAN_WAVES - 1) / LEAN_WAVES);
+    // ragged rows beyond the streaming loop's trips (the caller's bound says there may be some): one front workgroup per 256 rows finds
+    // them and runs their chunks in parallel (lean_solo_rows' crews); GVL_DBG & 256: by the wave that meets them, as before
+    if (RA.out_offsets && A.max_row_len > PIPE_RAG_MAXT * TRIP && !(debug_flags() & 256)) A.front = (int)((total + LEAN_THREADS - 1) / LEAN_THREADS);
+    const unsigned grid = (unsigned)((waves + LEAN_WAVES - 1) / LEAN_WAVES) + (unsigned)A.front;
     const dim3 g(grid), b(LEAN_THREADS);
     hipStream_t s = (hipStream_t)stream;
     // (launches without a keep mask that are not gvl_get_reference's: the forms with both compiled out; GVL_DBG & 1073741824 keeps the general ones)

@@ -1221,12 +1221,14 @@ def test_long_rows_under_a_keep_mask(gpu, oracle, kpath, ragged):
             np.testing.assert_array_equal(out.onehot.cpu().numpy(), exp_oh)
 
 
+@pytest.mark.parametrize("crews", [True, False], ids=["front-workgroups", "solo-at-the-wave's-end"])
 @pytest.mark.parametrize("mode", ["plain", "keep", "annotated"])
-def test_ragged_batch_of_short_rows_with_a_few_long_ones(gpu, oracle, mode):
+def test_ragged_batch_of_short_rows_with_a_few_long_ones(gpu, oracle, mode, crews):
     """A spliced batch's shape: hundreds of rows of a few hundred bases and a handful of several thousand (ragged, at out_offsets).  With
     the caller's total (gvl_batch.total_len_hint: HapsDevice.reconstruct passes what it reads for the allocation) the pipelined kernel
-    takes the batch -- the long rows by its waves' solo path, chunk by chunk -- instead of handing every row to the chunked kernel.
-    == the oracle; the solo path saw exactly the long rows (+ whatever else the lean path defers)."""
+    takes the batch -- the long rows by its FRONT workgroups, their chunks in parallel (round 6; GVL_DBG 256: by the solo path of the
+    wave that meets them, chunk after chunk) -- instead of handing every row to the chunked kernel.
+    == the oracle; the crews (the solo path) saw exactly the long rows (+ whatever else the lean path defers)."""
     import ctypes as C
 
     from genvarloader_amd import synth
@@ -1242,12 +1244,14 @@ def test_ragged_batch_of_short_rows_with_a_few_long_ones(gpu, oracle, mode):
     dev = make_dev(gpu, st, bt)
     stamps = gpu.torch.zeros(64, dtype=gpu.torch.int64, device="cuda")
     dev.lib.gvl_diag_set_stamps(C.c_void_p(stamps.data_ptr()))
+    dev.lib.gvl_set_debug_flags(0 if crews else 256)
     try:
         out = dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, -1, bt.keep, bt.keep_offsets, bt.to_rc, haps=True,
                               onehot=mode != "annotated", annotate=mode == "annotated")
         gpu.torch.cuda.synchronize()
     finally:
         dev.lib.gvl_diag_set_stamps(None)
+        dev.lib.gvl_set_debug_flags(-1)
     from genvarloader_amd import _lib
 
     _lib.check_async()
@@ -1261,5 +1265,9 @@ def test_ragged_batch_of_short_rows_with_a_few_long_ones(gpu, oracle, mode):
     np.testing.assert_array_equal(out.out_offsets.cpu().numpy(), exp_off)
     np.testing.assert_array_equal(out.haps.cpu().numpy(), exp)
     n_long = int((np.diff(exp_off) > 2560).sum())
-    deferred = int(stamps[0])
-    assert n_long >= 12 and n_long <= deferred < 2000, (n_long, deferred)       # (the pipelined kernel ran: its solo path counts what it takes)
+    deferred, by_crews = int(stamps[0]), int(stamps[15])
+    # (the pipelined kernel ran: its solo path and its crews count what they take)
+    if crews:
+        assert n_long >= 12 and by_crews == n_long and 0 < deferred + 1 < 2000, (n_long, deferred, by_crews)
+    else:
+        assert n_long >= 12 and by_crews == 0 and n_long <= deferred < 2000, (n_long, deferred)

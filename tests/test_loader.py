@@ -491,7 +491,8 @@ def test_tracks_batch_long_rows_jitter_and_dense_lists(oracle, dbg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dbg", [0, 268435456, 1073741824], ids=["row-plans", "every-chunk-walks", "row-plans-general-track-kernel"])
+@pytest.mark.parametrize("dbg", [0, 268435456, 1073741824, 4096],
+                         ids=["row-plans", "every-chunk-walks", "row-plans-general-track-kernel", "sizing-launch-of-its-own"])
 @pytest.mark.parametrize("python_loop", [False, True], ids=["epoch-table-plans", "per-call-plans"])
 @pytest.mark.parametrize("strategy,param", [(0, 0.0), (4, 3.0)], ids=["repeat5p", "interpolate"])
 def test_tracks_row_plans_rows_of_many_trips(oracle, dbg, python_loop, strategy, param):
@@ -543,6 +544,62 @@ def test_tracks_row_plans_rows_of_many_trips(oracle, dbg, python_loop, strategy,
         assert n > 0                      # (some rows start inside their shift)
     finally:
         _lib.load().gvl_set_debug_flags(-1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [1, 2, 3, 4])
+def test_tracks_batch_sized_inside_the_row_plan_launch(oracle, P):
+    """A stand-alone gvl_tracks_batch (the Python submit loop's call) on rows of several chunks sizes its scratch tracks inside the
+    first track's row-plan launch (ploidy 1 / 2 / 4: a query's haplotypes share a workgroup; 3: a sizing launch of its own, like
+    GVL_DBG 4096): two tracks, batches that do not fill their last workgroup -- both ways against the oracle, and bit-equal."""
+    from genvarloader_amd import HapsDevice, _lib
+    from genvarloader_amd.loader import DeviceHapsTracksDataset
+
+    R, S, L = 3, 5, 9000
+    st, full_regions, go, gv = _grid_dataset(500 + P, R, S, P, L, contig=300_000, indel_frac=0.6, slack=120)
+    rng = np.random.default_rng(P)
+    tracks = {}
+    for name in ("a", "b"):
+        starts, ends, vals, offs = [], [], [], [0]
+        for r in range(R):
+            for s_ in range(S):
+                pos = int(full_regions[r, 1]) - 150
+                while pos < int(full_regions[r, 2]) + 300:
+                    w, gap = int(rng.geometric(1 / 30)), int(rng.geometric(1 / 6))
+                    starts.append(pos + gap); ends.append(pos + gap + w); vals.append(float(rng.random() * 5)); pos += gap + w
+                offs.append(len(starts))
+        tracks[name] = (np.array(starts, np.int32), np.array(ends, np.int32), np.array(vals, np.float32), np.array(offs, np.int64))
+    dev = HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens,
+                     alt_alleles=st.alt_alleles, alt_offsets=st.alt_offsets, geno_offsets=go, geno_v_idxs=gv,
+                     pad_char=st.pad_char)
+    seen = {}
+    try:
+        for dbg in (0, 4096):
+            _lib.load().gvl_set_debug_flags(dbg)
+            ds = DeviceHapsTracksDataset(dev, full_regions, S, P, tracks=tracks, strategy_id=4, param=2.0, output_length=L,
+                                         jitter=21, onehot=False, haps=True, seed=3)
+            assert all(ds._tile_complete)
+            for bi, batch in enumerate(ds.to_dataloader(batch_size=7, shuffle=True, seed=2, python_loop=True)):
+                idx = batch.idx.cpu().numpy()
+                regions, shifts = batch.regions.cpu().numpy(), batch.shifts.cpu().numpy()
+                goi = batch.geno_offset_idx.cpu().numpy()
+                to_rc = batch.to_rc.cpu().numpy().astype(bool)
+                diffs = oracle.get_diffs_sparse(goi, gv, go, st.ilens, None, None, regions[:, 1], regions[:, 2], st.v_starts)
+                tlen = (regions[:, 2] - regions[:, 1]).astype(np.int64) - np.minimum(diffs.min(axis=1), 0)
+                track_offsets = np.concatenate([[0], np.cumsum(tlen)]).astype(np.int64)
+                out_offsets = np.arange(len(idx) * P + 1, dtype=np.int64) * L
+                for t, name in enumerate(("a", "b")):
+                    a, e, v, io = tracks[name]
+                    exp = np.zeros(len(idx) * P * L, np.float32)
+                    oracle.intervals_and_realign_track_fused(exp, out_offsets, regions, shifts, goi, gv, go, st.v_starts, st.ilens,
+                                                             idx.astype(np.int64), a, e, v, io, track_offsets, np.array([2.0]), 4,
+                                                             0, None, None, to_rc)
+                    got = batch.tracks[:, t].contiguous().cpu().numpy().ravel()
+                    np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32), err_msg=f"dbg {dbg} batch {bi} track {name}")
+                    seen.setdefault((bi, name), []).append(got)
+    finally:
+        _lib.load().gvl_set_debug_flags(-1)
+    assert len(seen) == 6 and all(len(v) == 2 and np.array_equal(v[0].view(np.uint32), v[1].view(np.uint32)) for v in seen.values())
 
 
 @pytest.fixture(params=[0, -1, 134217728, 67108864, 33554432],

@@ -1,4 +1,4 @@
-"""bench.py's `secondary.spliced` leg on its own.  python tools/spliced_bench.py"""
+"""bench.py's `secondary.spliced` leg on its own.  python tools/spliced_bench.py [pairs per batch] [longest exon] [exonic keep mask 0/1]"""
 import json
 import sys
 from pathlib import Path
@@ -9,6 +9,8 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import bench  # noqa: E402
 
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-d = bench.secondary_spliced(torch, pairs=pairs)
+max_exon = int(sys.argv[2]) if len(sys.argv) > 2 else 9000
+exonic = bool(int(sys.argv[3])) if len(sys.argv) > 3 else True
+d = bench.secondary_spliced(torch, pairs=pairs, max_exon=max_exon, exonic=exonic)
 d.pop('how')
 print(json.dumps(d, indent=1))
