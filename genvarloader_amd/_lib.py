@@ -69,6 +69,7 @@ SYMBOLS = (
 
 ABI_VERSION = 11         # include/gvl_hip.h: GVL_ABI_VERSION
 TUNE_PIPE_ROWS_X100, TUNE_PIPE_MIN_ROWS, TUNE_LEAN_SUB, TUNE_TRACK_PLAN_MAX_MB, TUNE_RAGGED_SIZING, TUNE_HAP_PLAN_MAX_MB = 0, 1, 2, 3, 4, 5     # GVL_TUNE_*
+TUNE_MIXED_MIN_ROWS = 6
 GVL_ONEHOT_LC = 0
 GVL_ONEHOT_CL = 1
 

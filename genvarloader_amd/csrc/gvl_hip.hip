@@ -789,7 +789,9 @@ static bool lean_rag_eligible(const gvl_static *st, const gvl_batch *bt, const g
         // ... and the batch is large: a wave writes its long rows chunk by chunk at its end, which a launch of a few thousand rows has
         // nothing to hide behind (4 420 exon rows with 4 long ones: 27 us against the all-purpose kernel's 15; 17 372 rows: 34 against 40;
         // 69 586 rows: 89 against 152 -- tools/spliced_bench.py)
-        if (bt->total_len_hint <= 0 || bt->total_len_hint / n_rows > (i64)PIPE_RAG_MAXT * TRIP / 2 || ml > 65536 || n_rows < 16384) return false;
+        const i64 mixed_t = tune(GVL_TUNE_MIXED_MIN_ROWS);
+        const i64 mixed_min = mixed_t > 0 ? mixed_t : 16384;
+        if (bt->total_len_hint <= 0 || bt->total_len_hint / n_rows > (i64)PIPE_RAG_MAXT * TRIP / 2 || ml > 65536 || n_rows < mixed_min) return false;
     }
     if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;
     return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 268435456 | 536870912 | 1073741824)) == 0;

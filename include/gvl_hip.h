@@ -196,9 +196,11 @@ int gvl_set_debug_flags(int flags);
  *   GVL_TUNE_RAGGED_SIZING       1: the native loader sizes ragged rows once per group of batches (round 4's way), not once per epoch.
  *   GVL_TUNE_HAP_PLAN_MAX_MB     haplotype chunk plans of an epoch larger than this are not made (built in: 64 -- they pay while they
  *                                stay in the 256 MB Infinity Cache next to the epoch's other inputs, and cost more than the walks
- *                                they save beyond it: profiles/r05_cfg4_plans_vs_size.txt). */
+ *                                they save beyond it: profiles/r05_cfg4_plans_vs_size.txt).
+ *   GVL_TUNE_MIXED_MIN_ROWS      ragged batches of mostly short rows with a few beyond 2560 bases (gvl_batch.total_len_hint): with fewer
+ *                                rows than this the all-purpose kernel keeps them (built in: see lean_rag_eligible, gvl_hip.hip). */
 enum { GVL_TUNE_PIPE_ROWS_X100 = 0, GVL_TUNE_PIPE_MIN_ROWS = 1, GVL_TUNE_LEAN_SUB = 2, GVL_TUNE_TRACK_PLAN_MAX_MB = 3, GVL_TUNE_RAGGED_SIZING = 4,
-       GVL_TUNE_HAP_PLAN_MAX_MB = 5, GVL_TUNE_COUNT = 6 };
+       GVL_TUNE_HAP_PLAN_MAX_MB = 5, GVL_TUNE_MIXED_MIN_ROWS = 6, GVL_TUNE_COUNT = 7 };
 int gvl_set_tuning(int32_t key, int64_t value);
 const char *gvl_last_error(void);
 /* (The flag behind gvl_async_error is PROCESS-global: it says that some launch of this process met the

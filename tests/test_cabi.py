@@ -50,10 +50,10 @@ def test_header_enums_match_the_python_mirror(lib):
     enums = {k: int(v) for k, v in re.findall(r"\b(GVL_[A-Z0-9_]+)\s*=\s*(-?\d+)", txt)}
     defines = {k: int(v) for k, v in re.findall(r"#define\s+(GVL_[A-Z0-9_]+)\s+(-?\d+)\b", txt)}
     both = {**defines, **enums}
-    for name in ("PIPE_ROWS_X100", "PIPE_MIN_ROWS", "LEAN_SUB", "TRACK_PLAN_MAX_MB", "RAGGED_SIZING", "HAP_PLAN_MAX_MB"):
+    for name in ("PIPE_ROWS_X100", "PIPE_MIN_ROWS", "LEAN_SUB", "TRACK_PLAN_MAX_MB", "RAGGED_SIZING", "HAP_PLAN_MAX_MB", "MIXED_MIN_ROWS"):
         assert both["GVL_TUNE_" + name] == getattr(_lib, "TUNE_" + name), name
     n_keys = both["GVL_TUNE_COUNT"]
-    assert n_keys == 6
+    assert n_keys == 7
     assert lib.gvl_set_tuning(n_keys - 1, 0) == 0 and lib.gvl_set_tuning(n_keys, 0) != 0 and lib.gvl_set_tuning(-1, 0) != 0
     assert both["GVL_LOADER_TABLE_PARTS"] == _lib.LOADER_TABLE_PARTS
     assert both["GVL_ONEHOT_LC"] == _lib.GVL_ONEHOT_LC and both["GVL_ONEHOT_CL"] == _lib.GVL_ONEHOT_CL
