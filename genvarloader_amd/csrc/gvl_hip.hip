@@ -349,7 +349,6 @@ int pick_chunk(i64 max_len, int *chunks, int *chunk_len) {
 //   128  no speculative reference reads in front of the plan
 //  1024  painter ignores the per-list bucket index (exact 64-ary searches per chunk)
 //  2048  length deltas (get_diffs_sparse, ragged sizing) always one wave per row
-//  4096  gvl_tracks_batch sizes its scratch tracks in a launch of its own (not inside the first track's row-plan launch)
 //  8192  painter always paints an LDS image (no start-bitmap lookup for non-overlapping candidates)
 // 16384  no lean kernel (the all-purpose kernel over every row, as before round 3)
 // 32768  the lean kernel hands EVERY row to its solo general path (per-wave scans from the byte reference)
@@ -794,7 +793,7 @@ static bool lean_rag_eligible(const gvl_static *st, const gvl_batch *bt, const g
         if (bt->total_len_hint <= 0 || bt->total_len_hint / n_rows > (i64)PIPE_RAG_MAXT * TRIP / 2 || ml > 65536 || n_rows < mixed_min) return false;
     }
     if (st->alt_len >= (1ll << 32) || st->ref_len >= (1ll << 32) - 8192) return false;
-    return (debug_flags() & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 268435456 | 536870912 | 1073741824)) == 0;
+    return (debug_flags() & ~(2 | 4 | 256 | 32768 | 65536 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 268435456 | 536870912 | 1073741824)) == 0;
 }
 static bool lean_pipe_wanted(i64 total_rows, int n_batches = 1) {
     if (debug_flags() & 67108864) return false;

@@ -170,8 +170,7 @@ int gvl_paint_tracks(const gvl_track_set *ts, const int64_t *offset_idxs, const 
 static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const float *tracks,
                                const int64_t *track_offsets, const double *params, int64_t strategy_id,
                                uint64_t base_seed, const u64 *seed_ptr, float *out, void *stream, const PaintSrcArgs *ps = nullptr,
-                               int2 *plan_hdr = nullptr, i32x4 *plan_ent = nullptr, bool plan_make = false, int to_shift = 0,
-                               const DiffArgs *mk_D = nullptr, i64 *mk_lengths = nullptr, i64 *mk_out_offsets = nullptr);
+                               int2 *plan_hdr = nullptr, i32x4 *plan_ent = nullptr, bool plan_make = false, int to_shift = 0);
 int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *tracks,
                        const int64_t *track_offsets, const double *params, int64_t strategy_id,
                        uint64_t base_seed, float *out, void *stream) {
@@ -180,8 +179,7 @@ int gvl_realign_tracks(const gvl_static *st, const gvl_batch *bt, const float *t
 static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const float *tracks,
                                const int64_t *track_offsets, const double *params, int64_t strategy_id,
                                uint64_t base_seed, const u64 *seed_ptr, float *out, void *stream, const PaintSrcArgs *ps,
-                               int2 *plan_hdr, i32x4 *plan_ent, bool plan_make, int to_shift,
-                               const DiffArgs *mk_D, i64 *mk_lengths, i64 *mk_out_offsets) {
+                               int2 *plan_hdr, i32x4 *plan_ent, bool plan_make, int to_shift) {
     if (!st || !bt) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: NULL struct");
     if (bt->batch < 0 || bt->ploidy <= 0) return fail(GVL_ERR_INVALID, "%s", "gvl_realign_tracks: bad batch/ploidy");
     if (bt->batch == 0) return GVL_OK;
@@ -217,19 +215,12 @@ static int realign_tracks_impl(const gvl_static *st, const gvl_batch *bt, const 
     // (int2 per (row, chunk) + PLAN_MAXE entries per row: the caller has made sure both fit)
     if (plan_hdr && plan_ent && chunks > 1 && !(A.dbg & (8 | 268435456))) {
         if (plan_make) {
-            // (mk_lengths: the plan kernel sizes the batch too -- scratch-track lengths as pairs + the fixed-length rows' offsets)
-            if (mk_D && mk_lengths && mk_out_offsets)
-                track_plan_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(A, plan_hdr, plan_ent, chunks, bt->max_row_len, 0,
-                                                                                              *mk_D, mk_lengths, mk_out_offsets);
-            else
-                track_plan_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(A, plan_hdr, plan_ent, chunks, -1, 0, DiffArgs(),
-                                                                                              nullptr, nullptr);
+            track_plan_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(A, plan_hdr, plan_ent, chunks, -1, 0);
             const int rc = check_launch("gvl_realign_tracks(row plans)");
             if (rc) return rc;
         }
         A.plan_hdr = plan_hdr; A.plan_ent = plan_ent;
     }
-    if (mk_lengths && !A.plan_hdr) return fail(GVL_ERR_INVALID, "%s", "gvl_tracks_batch: the batch was to be sized by the row-plan launch, which did not run");
     // tracks straight from the intervals with the rows' plans at hand: the fast kernel (chunks it does not take call the general body;
     // GVL_DBG & 1073741824: the general kernel for every chunk, as in round 4)
     if (ps && A.plan_hdr && A.plan_ent && A.out_offsets && !(A.dbg & (1073741824 | GVL_ABL(8388608) | GVL_ABL(16777216) | 2097152)))
@@ -314,17 +305,9 @@ int gvli::tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const int
         all_fused = T.tile_complete != 0 && T.bkt_offsets && T.bkt_base && T.bkt_lo && T.bkt_hi && !(debug_flags() & 1024) && T.itv_pmax_ends;
     }
     int to_shift = 0;
-    // (the sizing folded into the first track's row-plan launch: every track straight from its intervals, rows of several chunks with
-    // room for their plans, ploidy 1 / 2 / 4 -- the haplotypes of a query then share a workgroup of the plan kernel; GVL_DBG & 4096:
-    // a sizing launch of its own, as before)
-    bool fold = false;
     if (pre_track_offsets && pre_out_offsets) {
         track_offsets = const_cast<i64 *>(pre_track_offsets);
         out_offsets = const_cast<i64 *>(pre_out_offsets);
-    } else if (all_fused && !plan_made && plan_hdr && plan_ent && (P == 1 || P == 2 || P == 4) &&
-               !(debug_flags() & (8 | 4096 | 268435456 | 1073741824 | GVL_ABL(8388608) | GVL_ABL(16777216) | 2097152))) {
-        fold = true;
-        to_shift = 1;
     } else {
         const bool per_hap = P == 1 || P == 2 || P == 4;      // a wave per (query, haplotype), 4 / P queries per workgroup
         const i64 grid = per_hap ? (B * P + 3) / 4 : (B * WAVE + 255) / 256;
@@ -362,8 +345,7 @@ int gvli::tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const int
             PaintSrcArgs ps{(const i64 *)offset_idxs, T.list_div > 1 ? T.list_div : 1, T.itv_starts, T.itv_ends, T.itv_values,
                             (const i64 *)T.itv_offsets, T.itv_pmax_ends, X};
             rc = realign_tracks_impl(st, &rb, nullptr, (const int64_t *)track_offsets, T.has_fill ? t_par : params, t_strategy, base_seed,
-                                     seed_ptr, out + (i64)t * out_track_stride, stream, &ps, plan_hdr, plan_ent, !plan_made, to_shift,
-                                     fold && !plan_made ? &D : nullptr, track_offsets, out_offsets);
+                                     seed_ptr, out + (i64)t * out_track_stride, stream, &ps, plan_hdr, plan_ent, !plan_made, to_shift);
             if (rc) return rc;
             plan_made = true;
             continue;
@@ -383,8 +365,7 @@ int gvli::tracks_batch_impl(const gvl_static *st, const gvl_batch *bt, const int
 
 int gvli::launch_track_plan(const TrackArgs &TA, int2 *hdr, i32x4 *ent, int chunks, i64 fixed_len, i64 rows_per_batch_q, void *stream) {
     const i64 wgrid = (TA.n_rows + 3) / 4;
-    track_plan_kernel<<<dim3((unsigned)wgrid), dim3(256), 0, (hipStream_t)stream>>>(TA, hdr, ent, chunks, fixed_len, rows_per_batch_q, DiffArgs(),
-                                                                                    nullptr, nullptr);
+    track_plan_kernel<<<dim3((unsigned)wgrid), dim3(256), 0, (hipStream_t)stream>>>(TA, hdr, ent, chunks, fixed_len, rows_per_batch_q);
     return check_launch("gvl_loader_start_epoch(row plans)");
 }
 

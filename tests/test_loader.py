@@ -491,8 +491,7 @@ def test_tracks_batch_long_rows_jitter_and_dense_lists(oracle, dbg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dbg", [0, 268435456, 1073741824, 4096],
-                         ids=["row-plans", "every-chunk-walks", "row-plans-general-track-kernel", "sizing-launch-of-its-own"])
+@pytest.mark.parametrize("dbg", [0, 268435456, 1073741824], ids=["row-plans", "every-chunk-walks", "row-plans-general-track-kernel"])
 @pytest.mark.parametrize("python_loop", [False, True], ids=["epoch-table-plans", "per-call-plans"])
 @pytest.mark.parametrize("strategy,param", [(0, 0.0), (4, 3.0)], ids=["repeat5p", "interpolate"])
 def test_tracks_row_plans_rows_of_many_trips(oracle, dbg, python_loop, strategy, param):
@@ -548,10 +547,10 @@ def test_tracks_row_plans_rows_of_many_trips(oracle, dbg, python_loop, strategy,
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("P", [1, 2, 3, 4])
-def test_tracks_batch_sized_inside_the_row_plan_launch(oracle, P):
-    """A stand-alone gvl_tracks_batch (the Python submit loop's call) on rows of several chunks sizes its scratch tracks inside the
-    first track's row-plan launch (ploidy 1 / 2 / 4: a query's haplotypes share a workgroup; 3: a sizing launch of its own, like
-    GVL_DBG 4096): two tracks, batches that do not fill their last workgroup -- both ways against the oracle, and bit-equal."""
+def test_tracks_batch_standalone_any_ploidy(oracle, P):
+    """A stand-alone gvl_tracks_batch (the Python submit loop's call) on rows of several chunks: its sizing launch takes a wave per
+    (query, haplotype) for ploidy 1 / 2 / 4 (the haplotypes of a query meet in LDS) and a wave per query otherwise (3); two tracks,
+    batches that do not fill their last workgroup -- against the oracle, with the rows' plans and without (GVL_DBG 268435456)."""
     from genvarloader_amd import HapsDevice, _lib
     from genvarloader_amd.loader import DeviceHapsTracksDataset
 
@@ -574,7 +573,7 @@ def test_tracks_batch_sized_inside_the_row_plan_launch(oracle, P):
                      pad_char=st.pad_char)
     seen = {}
     try:
-        for dbg in (0, 4096):
+        for dbg in (0, 268435456):
             _lib.load().gvl_set_debug_flags(dbg)
             ds = DeviceHapsTracksDataset(dev, full_regions, S, P, tracks=tracks, strategy_id=4, param=2.0, output_length=L,
                                          jitter=21, onehot=False, haps=True, seed=3)

@@ -1,13 +1,11 @@
 #!/bin/bash
-# one GPU call: the new tests, gvl_tracks_batch A/B, spliced batches with and without the front workgroups
+# rows per wave for batches of short ragged rows (spliced exons): GVL_TUNE_PIPE_ROWS_X100 sweep
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 O=gpurun_out/r06; mkdir -p $O
-python -m pytest tests/test_loader.py -q -x -k "sized_inside or row_plans_rows" > $O/t_tracks.log 2>&1; tail -3 $O/t_tracks.log
-python -m pytest tests/test_gpu_parity.py -q -x -k "few_long_ones" > $O/t_mixed.log 2>&1; tail -3 $O/t_mixed.log
-python -m pytest tests/test_gpu_svar2.py -q -x -k "consensus" > $O/t_cons.log 2>&1; tail -3 $O/t_cons.log
-python tools/tracks_batch_ab.py > $O/tracks_ab.txt 2>&1; tail -4 $O/tracks_ab.txt
-: > $O/spliced_ab.txt
-for cfg in "4096 9000 1" "4096 2500 1" "4096 9000 0" "1024 9000 1 1" "256 9000 1 1" "256 9000 1"; do
-  for d in 0 256; do echo "== $cfg GVL_DBG=$d" >> $O/spliced_ab.txt; GVL_DBG=$d python tools/spliced_bench.py $cfg 2>&1 | grep -E "workload|kernel_ms|routing_kernel_ms|ms_per_step" >> $O/spliced_ab.txt; done
+: > $O/spliced_rows.txt
+for x in 100 150 200 300 400 600 800 1200 1600; do
+  for cfg in "4096 9000 1 1" "4096 2500 1 1" "4096 2500 0 1" "1024 9000 1 1"; do
+    echo "== $cfg x100=$x" >> $O/spliced_rows.txt; python tools/spliced_bench.py $cfg $x 2>&1 | grep -E "\"kernel_ms|routing_kernel_ms" >> $O/spliced_rows.txt
+  done
 done
-cat $O/spliced_ab.txt
+cat $O/spliced_rows.txt

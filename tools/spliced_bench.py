@@ -1,4 +1,4 @@
-"""bench.py's `secondary.spliced` leg on its own.  python tools/spliced_bench.py [pairs per batch] [longest exon] [exonic keep mask 0/1] [GVL_TUNE_MIXED_MIN_ROWS]"""
+"""bench.py's `secondary.spliced` leg on its own.  python tools/spliced_bench.py [pairs per batch] [longest exon] [exonic keep mask 0/1] [GVL_TUNE_MIXED_MIN_ROWS] [GVL_TUNE_PIPE_ROWS_X100]"""
 import json
 import sys
 from pathlib import Path
@@ -12,6 +12,8 @@ from genvarloader_amd import _lib  # noqa: E402
 
 if len(sys.argv) > 4:
     _lib.set_tuning(_lib.TUNE_MIXED_MIN_ROWS, int(sys.argv[4]))
+if len(sys.argv) > 5:
+    _lib.set_tuning(_lib.TUNE_PIPE_ROWS_X100, int(sys.argv[5]))
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 max_exon = int(sys.argv[2]) if len(sys.argv) > 2 else 9000
 exonic = bool(int(sys.argv[3])) if len(sys.argv) > 3 else True
