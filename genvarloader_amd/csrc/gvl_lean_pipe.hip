@@ -61,6 +61,11 @@ int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks) 
     // above that "two rows per wave", which is 1.5 on average: the first half of the waves take two rows (w, w + W), the second
     // half -- dispatched last -- one, so the grid drains in short waves (125 / 175 measure like 150; exactly 2, or 3, are slower).
     // gvl_set_tuning(GVL_TUNE_PIPE_ROWS_X100) overrides (200 = exactly two rows for every wave, 300 = three, ...).
+    //
+    // SHORT rows (round 6; tools/short_rows.py, tools/stamps_pipe.py, profiles/r06_short_rows*.txt, r06_stamps_pipe*.txt): a launch of
+    // 65 536 rows takes 52-56 us whether its rows have 128 or 1024 bases -- a SIMD gets through ~1.4 rows per us whatever the schedule
+    // (8 waves of 1.5 rows, 7 of 9, 4 of 16: a row is ~900 instructions of every kind, and a wave alone needs ~3 us for them) -- so more
+    // rows per wave buy nothing there either: one generation of waves with total / waves rows each measured 61 us against 53.
     i64 x100 = tune(GVL_TUNE_PIPE_ROWS_X100);
     if (x100 < 100) x100 = total >= 49152 ? 150 : 100;
     if (x100 > 100 * (i64)PIPE_MAX_ROWS) x100 = 100 * (i64)PIPE_MAX_ROWS;      // (a wave's deferred-rows mask has a bit per row)

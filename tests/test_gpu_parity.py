@@ -1271,3 +1271,46 @@ def test_ragged_batch_of_short_rows_with_a_few_long_ones(gpu, oracle, mode, crew
         assert n_long >= 12 and by_crews == n_long and 0 < deferred + 1 < 2000, (n_long, deferred, by_crews)
     else:
         assert n_long >= 12 and by_crews == 0 and n_long <= deferred < 2000, (n_long, deferred)
+
+
+@pytest.mark.parametrize("mode", ["fixed-oh", "fixed-oh-bytes", "ragged", "ragged-keep", "fixed-annotated", "fixed-cl"])
+@pytest.mark.parametrize("q,L", [(8200, 190), (20000, 300), (9000, 1000)], ids=["16400x190", "40000x300", "18000x1000"])
+def test_launches_of_short_rows_many_rows_per_wave(gpu, oracle, mode, q, L):
+    """Launches of >= 16 384 SHORT rows (a spliced batch's exons; tools/short_rows.py measures them), at the built-in 1 - 1.5 rows per
+    wave and at 9 rows per wave (GVL_TUNE_PIPE_ROWS_X100 = 900: every wave pipelines over many rows) == the oracle in every output mode."""
+    from genvarloader_amd import _lib
+
+    ragged = mode.startswith("ragged")
+    st, bt = _synth(900 + L, (3_000_000,), q, L, indel_frac=0.3, density=1 / 90, rc_frac=0.5, slack=12,
+                    **({"output_length": -1} if ragged else {}))
+    if mode == "ragged-keep":
+        _with_keep(np.random.default_rng(1), bt, 0.6)
+    dev = make_dev(gpu, st, bt)
+    kw = dict(haps=mode != "fixed-oh" and mode != "fixed-cl", onehot=mode != "fixed-annotated", annotate=mode == "fixed-annotated",
+              layout="cl" if mode == "fixed-cl" else "lc")
+    got = []
+    for x100 in (0, 900):
+        _lib.set_tuning(_lib.TUNE_PIPE_ROWS_X100, x100)
+        try:
+            out = dev.reconstruct(bt.regions, bt.shifts, bt.geno_offset_idx, bt.output_length, bt.keep, bt.keep_offsets, bt.to_rc, **kw)
+            gpu.torch.cuda.synchronize()
+        finally:
+            _lib.set_tuning(_lib.TUNE_PIPE_ROWS_X100, 0)
+        _lib.check_async()
+        got.append(out)
+    if mode == "fixed-annotated":
+        exp, av, ap, exp_off = oracle_fused(oracle, st, bt, annotate=True)
+        for out in got:
+            np.testing.assert_array_equal(out.annot_v_idxs.cpu().numpy().ravel(), av)
+            np.testing.assert_array_equal(out.annot_ref_pos.cpu().numpy().ravel(), ap)
+            np.testing.assert_array_equal(out.haps.cpu().numpy().ravel(), exp)
+        return
+    exp, exp_off, exp_oh = oracle_fused(oracle, st, bt, onehot=True)
+    if mode == "fixed-cl":
+        exp_oh = np.ascontiguousarray(exp_oh.reshape(-1, L, 4).transpose(0, 2, 1))
+    for out in got:
+        np.testing.assert_array_equal(out.onehot.cpu().numpy().ravel(), exp_oh.ravel())
+        if kw["haps"]:
+            np.testing.assert_array_equal(out.haps.cpu().numpy().ravel(), exp)
+        if ragged:
+            np.testing.assert_array_equal(out.out_offsets.cpu().numpy(), exp_off)
