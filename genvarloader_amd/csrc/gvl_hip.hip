@@ -850,9 +850,9 @@ int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_o
     }
     if (all_one_chunk_lean && (lean_pipe_wanted(total, n) || any_cl) && lean_pipe_compatible(A, n)) return launch_lean_rows(A, n, stream, 1);
     if (all_rag && lean_pipe_compatible(A, n)) {
-        int min_chunks = chunks[0];             // (the launch reports a row longer than the smallest bound any of its batches gave)
-        for (int i = 1; i < n; ++i) min_chunks = chunks[i] < min_chunks ? chunks[i] : min_chunks;
-        return launch_lean_rows(A, n, stream, min_chunks);
+        int min_chunks = chunks[0], max_chunks = chunks[0];   // (the launch reports a row longer than the smallest bound any of its batches gave)
+        for (int i = 1; i < n; ++i) { min_chunks = chunks[i] < min_chunks ? chunks[i] : min_chunks; max_chunks = chunks[i] > max_chunks ? chunks[i] : max_chunks; }
+        return launch_lean_rows(A, n, stream, min_chunks, max_chunks);
     }
     for (int i = 0; i < n; ++i) {
         int rc;

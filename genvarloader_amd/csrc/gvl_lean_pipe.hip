@@ -27,7 +27,7 @@ bool lean_pipe_compatible(const ReconArgs *RAs, int n) {
     }
     return total <= 0x7FFFFFF0ll && F.regions_stride <= 0x7FFFFFFFll;
 }
-int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks) {
+int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks, int rag_chunks_max) {
     const ReconArgs &RA = RAs[0];
     LeanArgs A;
     LeanMany M;
@@ -77,7 +77,9 @@ int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks) 
     }
     // ragged rows beyond the streaming loop's trips (the caller's bound says there may be some): one front workgroup per 256 rows finds
     // them and runs their chunks in parallel (lean_solo_rows' crews); GVL_DBG & 256: by the wave that meets them, as before
-    if (RA.out_offsets && A.max_row_len > PIPE_RAG_MAXT * TRIP && !(debug_flags() & 256)) A.front = (int)((total + LEAN_THREADS - 1) / LEAN_THREADS);
+    // (several batches: the LARGEST bound any of them gave decides -- max_row_len above is the smallest, what a row is reported against)
+    const i64 longest = (i64)RA.chunk_len * (rag_chunks_max > rag_chunks ? rag_chunks_max : rag_chunks);
+    if (RA.out_offsets && longest > PIPE_RAG_MAXT * TRIP && !(debug_flags() & 256)) A.front = (int)((total + LEAN_THREADS - 1) / LEAN_THREADS);
     const unsigned grid = (unsigned)((waves + LEAN_WAVES - 1) / LEAN_WAVES) + (unsigned)A.front;
     const dim3 g(grid), b(LEAN_THREADS);
     hipStream_t s = (hipStream_t)stream;

@@ -1314,3 +1314,56 @@ def test_launches_of_short_rows_many_rows_per_wave(gpu, oracle, mode, q, L):
             np.testing.assert_array_equal(out.haps.cpu().numpy().ravel(), exp)
         if ragged:
             np.testing.assert_array_equal(out.out_offsets.cpu().numpy(), exp_off)
+
+
+def test_many_ragged_batches_with_a_few_long_rows(gpu, oracle):
+    """gvl_reconstruct_many over three ragged batches of short rows with a handful of long ones each (the same bound on the longest row for
+    all of them, as a loader gives): ONE grid, whose front workgroups find the long rows of every batch -- a workgroup's 256 rows may
+    straddle two batches -- and run them chunk by chunk; every batch == the oracle, and the crews took exactly the long rows."""
+    import ctypes as C
+
+    from genvarloader_amd import _lib, synth
+
+    rng = np.random.default_rng(72)
+    st = synth.make_static(rng, (600_000,), indel_frac=0.3)
+    P, per = 2, 2830                                   # 5660 rows per batch: not a multiple of 256
+    full = synth.make_batch(rng, st, 3 * per, P, 280, rc_frac=0.5, output_length=-1, slack=10)
+    long_q = rng.choice(3 * per, 11, replace=False)
+    full.regions[long_q, 2] = np.minimum(full.regions[long_q, 1] + rng.integers(2600, 7000, 11).astype(np.int32), 599_000)
+    dev = make_dev(gpu, st, full)
+    lib = _lib.load()
+    _lib.set_tuning(_lib.TUNE_MIXED_MIN_ROWS, 1000)
+    stamps = gpu.torch.zeros(64, dtype=gpu.torch.int64, device="cuda")
+    try:
+        prep, mx = [], 0
+        for i in range(3):
+            a, b = i * per, (i + 1) * per
+            b0 = dev.prepare_batch(full.regions[a:b], full.shifts[a:b], full.geno_offset_idx[a:b], -1, to_rc=full.to_rc[a * P:b * P])
+            oo, tm, _ = dev.hap_offsets(b0)
+            tot, m = (int(x) for x in tm.cpu())
+            mx = max(mx, m)
+            prep.append((a, b, oo, tot))
+        bts, outs, keep = [], [], []
+        for a, b, oo, tot in prep:
+            dbt = dev.prepare_batch(full.regions[a:b], full.shifts[a:b], full.geno_offset_idx[a:b], -1, None, None, full.to_rc[a * P:b * P],
+                                    oo, max_row_len=mx, total_len=tot)
+            o, oc = dev.alloc_output(dbt, tot, haps=True, onehot=True)
+            bts.append(dbt); outs.append(oc); keep.append(o)
+        lib.gvl_diag_set_stamps(C.c_void_p(stamps.data_ptr()))
+        dev.launch_many(dev.pack_many(bts, outs))
+        gpu.torch.cuda.synchronize()
+    finally:
+        lib.gvl_diag_set_stamps(None)
+        _lib.set_tuning(_lib.TUNE_MIXED_MIN_ROWS, 0)
+    _lib.check_async()
+    n_long = 0
+    for i, (a, b, oo, tot) in enumerate(prep):
+        exp, exp_off, exp_oh = oracle.reconstruct_haplotypes_fused(
+            full.regions[a:b], full.shifts[a:b], full.geno_offset_idx[a:b], full.geno_offsets, full.geno_v_idxs, st.v_starts,
+            st.ilens, st.alt_alleles, st.alt_offsets, st.ref, st.ref_offsets, st.pad_char, -1, None, None, full.to_rc[a * P:b * P], True,
+            onehot=True, n_threads=4)
+        np.testing.assert_array_equal(oo.cpu().numpy(), exp_off, err_msg=f"batch {i}")
+        np.testing.assert_array_equal(keep[i].haps.cpu().numpy(), exp, err_msg=f"batch {i}")
+        np.testing.assert_array_equal(keep[i].onehot.cpu().numpy(), exp_oh, err_msg=f"batch {i}")
+        n_long += int((np.diff(exp_off) > 2560).sum())
+    assert n_long >= 15 and int(stamps[15]) == n_long, (n_long, int(stamps[15]))
