@@ -700,6 +700,7 @@ static int fill_recon_args(const gvl_static *st, const gvl_batch *bt, const gvl_
     if (ragged_rows && bt->output_length > ml) ml = bt->output_length;
     if (ml < 0) ml = 0;
     if (pick_chunk(ml, chunks, &A.chunk_len)) return fail(GVL_ERR_INVALID, "%s", "gvl_reconstruct: too many chunks");
+    A.row_chunks = *chunks;
     A.ref_only = 0;
     A.dbg = debug_flags();
     A.pad = st->pad_char;
@@ -850,9 +851,9 @@ int gvl_reconstruct_many(const gvl_static *st, const gvl_batch *bts, const gvl_o
     }
     if (all_one_chunk_lean && (lean_pipe_wanted(total, n) || any_cl) && lean_pipe_compatible(A, n)) return launch_lean_rows(A, n, stream, 1);
     if (all_rag && lean_pipe_compatible(A, n)) {
-        int min_chunks = chunks[0], max_chunks = chunks[0];   // (the launch reports a row longer than the smallest bound any of its batches gave)
-        for (int i = 1; i < n; ++i) { min_chunks = chunks[i] < min_chunks ? chunks[i] : min_chunks; max_chunks = chunks[i] > max_chunks ? chunks[i] : max_chunks; }
-        return launch_lean_rows(A, n, stream, min_chunks, max_chunks);
+        int min_chunks = chunks[0];             // (LeanArgs.max_row_len: the smallest bound; a row is reported against its own batch's, ReconArgs.row_chunks)
+        for (int i = 1; i < n; ++i) min_chunks = chunks[i] < min_chunks ? chunks[i] : min_chunks;
+        return launch_lean_rows(A, n, stream, min_chunks);
     }
     for (int i = 0; i < n; ++i) {
         int rc;
@@ -918,6 +919,7 @@ int gvl_get_reference(const gvl_static *st, const int32_t *regions, int64_t regi
     A.n_rows = n_rows; A.ploidy = 1; A.ploidy_shift = 0;
     int chunks = 1;
     if (pick_chunk(max_row_len, &chunks, &A.chunk_len)) return fail(GVL_ERR_INVALID, "%s", "gvl_get_reference: too many chunks");
+    A.row_chunks = chunks;
     A.ref_only = 1;
     A.pad = st->pad_char;
     A.haps = out; A.onehot = onehot;
@@ -976,6 +978,7 @@ int gvl_get_reference_many(const gvl_static *st, const gvl_ref_batch *bs, int32_
         R.n_rows = b.n_rows; R.ploidy = 1; R.ploidy_shift = 0;
         int chunks = 1;
         if (pick_chunk(b.max_row_len, &chunks, &R.chunk_len)) { grouped = false; break; }
+        R.row_chunks = chunks;
         min_chunks = chunks < min_chunks ? chunks : min_chunks;
         R.ref_only = 1; R.pad = st->pad_char; R.haps = b.out; R.onehot = b.onehot;
         R.dbg = debug_flags(); R.async_err = async_err_word();

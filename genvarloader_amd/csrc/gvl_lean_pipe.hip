@@ -27,7 +27,7 @@ bool lean_pipe_compatible(const ReconArgs *RAs, int n) {
     }
     return total <= 0x7FFFFFF0ll && F.regions_stride <= 0x7FFFFFFFll;
 }
-int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks, int rag_chunks_max) {
+int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks) {
     const ReconArgs &RA = RAs[0];
     LeanArgs A;
     LeanMany M;
@@ -45,7 +45,7 @@ int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks, 
     A.slot_vidx = RA.slot_vidx;
     A.rows_per_batch = (int)RA.n_rows; A.n_batches = n;
     A.max_row_len = (int)((i64)RA.chunk_len * (RA.out_offsets ? rag_chunks : 1));
-    i64 total = 0;
+    i64 total = 0, longest = 0;
     for (int i = 0; i < n; ++i) {
         LeanBatch &b = M.b[i];
         b.regions = RAs[i].regions; b.shifts = RAs[i].shifts; b.geno_offset_idx = RAs[i].geno_offset_idx; b.to_rc = RAs[i].to_rc;
@@ -53,6 +53,10 @@ int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks, 
         b.out_offsets = RAs[i].out_offsets;
         b.keep = RAs[i].keep; b.keep_offsets = RAs[i].keep_offsets;
         b.av = RAs[i].av; b.ap = RAs[i].ap;
+        // (a batch's own bound: its chunks where the caller's call said so -- gvl_reconstruct(_many) --, the launch's otherwise)
+        const int own_chunks = RAs[i].row_chunks > 0 ? RAs[i].row_chunks : rag_chunks;
+        b.max_row_len = (i64)RAs[i].chunk_len * (RAs[i].out_offsets ? own_chunks : 1);
+        longest = b.max_row_len > longest ? b.max_row_len : longest;
         total += RAs[i].n_rows;
     }
     A.n_rows = (int)total;
@@ -77,8 +81,7 @@ int launch_lean_rows(const ReconArgs *RAs, int n, void *stream, int rag_chunks, 
     }
     // ragged rows beyond the streaming loop's trips (the caller's bound says there may be some): one front workgroup per 256 rows finds
     // them and runs their chunks in parallel (lean_solo_rows' crews); GVL_DBG & 256: by the wave that meets them, as before
-    // (several batches: the LARGEST bound any of them gave decides -- max_row_len above is the smallest, what a row is reported against)
-    const i64 longest = (i64)RA.chunk_len * (rag_chunks_max > rag_chunks ? rag_chunks_max : rag_chunks);
+    // (several batches: the LARGEST bound any of them gave decides)
     if (RA.out_offsets && longest > PIPE_RAG_MAXT * TRIP && !(debug_flags() & 256)) A.front = (int)((total + LEAN_THREADS - 1) / LEAN_THREADS);
     const unsigned grid = (unsigned)((waves + LEAN_WAVES - 1) / LEAN_WAVES) + (unsigned)A.front;
     const dim3 g(grid), b(LEAN_THREADS);

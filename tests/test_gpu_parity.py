@@ -1367,3 +1367,54 @@ def test_many_ragged_batches_with_a_few_long_rows(gpu, oracle):
         np.testing.assert_array_equal(keep[i].onehot.cpu().numpy(), exp_oh, err_msg=f"batch {i}")
         n_long += int((np.diff(exp_off) > 2560).sum())
     assert n_long >= 15 and int(stamps[15]) == n_long, (n_long, int(stamps[15]))
+
+
+def test_many_ragged_batches_each_reported_against_its_own_bound(gpu, oracle):
+    """Two ragged batches in one grid whose callers gave DIFFERENT bounds on the longest row (1 chunk / 2 chunks): a row the pipelined
+    kernel hands to its solo path is reported as "longer than max_row_len" against ITS batch's bound (LeanBatch.max_row_len), not the
+    group's smallest -- with GVL_DBG 32768 every row goes that way: no report, both batches == the oracle; a bound that IS too small is
+    reported."""
+    from genvarloader_amd import _lib, synth
+
+    rng = np.random.default_rng(73)
+    st = synth.make_static(rng, (900_000,), indel_frac=0.3)
+    P, per = 2, 40
+    lib = _lib.load()
+    fulls = [synth.make_batch(rng, st, per, P, L, rc_frac=0.5, output_length=-1, slack=10) for L in (1700, 2350)]
+    # ONE genotype table for both batches: the second batch's offsets behind the first's
+    g0, g1 = fulls
+    off = int(g0.geno_v_idxs.size)
+    geno_offsets = np.concatenate([g0.geno_offsets, g1.geno_offsets + off], axis=1)
+    geno_v_idxs = np.concatenate([g0.geno_v_idxs, g1.geno_v_idxs])
+    g1.geno_offset_idx = g1.geno_offset_idx + g0.geno_offsets.shape[1]
+    dev = gpu.device.HapsDevice(ref=st.ref, ref_offsets=st.ref_offsets, v_starts=st.v_starts, ilens=st.ilens, alt_alleles=st.alt_alleles,
+                                alt_offsets=st.alt_offsets, geno_offsets=geno_offsets, geno_v_idxs=geno_v_idxs, pad_char=st.pad_char)
+    for shrink in (False, True):
+        lib.gvl_set_debug_flags(32768)
+        try:
+            bts, outs, keep, offs = [], [], [], []
+            for bt in fulls:
+                b0 = dev.prepare_batch(bt.regions, bt.shifts, bt.geno_offset_idx, -1, to_rc=bt.to_rc)
+                oo, tm, _ = dev.hap_offsets(b0)
+                tot, m = (int(x) for x in tm.cpu())
+                bound = 2048 if (shrink and bt is g1) else m                   # (2048: one chunk -- the second batch's rows are longer)
+                dbt = dev.prepare_batch(bt.regions, bt.shifts, bt.geno_offset_idx, -1, None, None, bt.to_rc, oo, max_row_len=bound, total_len=tot)
+                o, oc = dev.alloc_output(dbt, tot, haps=True, onehot=True)
+                bts.append(dbt); outs.append(oc); keep.append(o); offs.append(oo)
+            dev.launch_many(dev.pack_many(bts, outs))
+            gpu.torch.cuda.synchronize()
+        finally:
+            lib.gvl_set_debug_flags(-1)
+        if shrink:
+            with pytest.raises(Exception, match="max_row_len"):
+                _lib.check_async()
+            continue
+        _lib.check_async()
+        for i, bt in enumerate(fulls):
+            exp, exp_off, exp_oh = oracle.reconstruct_haplotypes_fused(
+                bt.regions, bt.shifts, bt.geno_offset_idx, geno_offsets, geno_v_idxs, st.v_starts, st.ilens, st.alt_alleles, st.alt_offsets,
+                st.ref, st.ref_offsets, st.pad_char, -1, None, None, bt.to_rc, True, onehot=True, n_threads=4)
+            assert (np.diff(exp_off).max() > 2048) == (i == 1)
+            np.testing.assert_array_equal(offs[i].cpu().numpy(), exp_off)
+            np.testing.assert_array_equal(keep[i].haps.cpu().numpy(), exp)
+            np.testing.assert_array_equal(keep[i].onehot.cpu().numpy(), exp_oh)
