@@ -593,14 +593,20 @@ def secondary_spliced(torch, n_tx: int = 1500, S: int = 8, pairs: int = 256, n: 
             lib.gvl_set_debug_flags(-1)
 
     k_ms, k5_ms = kern(-1), kern(1073741824)
-    return {"workload": f"spliced haplotypes under the exonic keep mask: {pairs} (transcript, sample) pairs per batch = {len(lens)} exon rows "
+    n_long = int((lens > 2560).sum())
+    k_solo = kern(256) if n_long and len(lens) >= 16384 else None      # (the pipelined kernel with its long rows at the waves' ends, as before the front workgroups)
+    extra = {} if k_solo is None else {"long_rows_at_the_waves_ends_kernel_ms": k_solo,
+                                       "long_rows": "by the launch's front workgroups, chunks in parallel (GVL_DBG 256: by the wave that meets them, chunk after chunk)"}
+    return {**extra, "workload": f"spliced haplotypes under the exonic keep mask: {pairs} (transcript, sample) pairs per batch = {len(lens)} exon rows "
                         f"(mean {lens.mean():.0f} bases, {int((lens > 2560).sum())} longer than 2560, longest {int(lens.max())}), one-hot + bytes",
             "ms_per_step": ms, "rows_per_s": len(lens) / (ms * 1e-3), "algorithmic_bytes_per_step": ab,
             "step_frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "kernel_ms": k_ms, "kernel_frac": ab / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "r05_routing_kernel_ms": k5_ms, "r05_routing_kernel_frac": ab / (k5_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "kernel": "a batch of a few thousand short rows + a few long ones: the all-purpose kernel (launch-latency-bound: 7 MB of work); from 16 384 "
-                      "rows on recon_lean_rows_kernel<onehot, haps, ragged, keep mask> with the long rows by its solo path (tools/spliced_bench.py 4096)",
+            "kernel": ("recon_lean_rows_kernel<onehot, haps, ragged, keep mask>; rows of a few hundred bases are bound by the scalar unit (1 250 rows/us "
+                       "whatever their length, DESIGN 4.1), not by bytes" if len(lens) >= 16384 else
+                       "a batch of a few thousand short rows + a few long ones: the all-purpose kernel (launch-latency-bound: 7 MB of work); from 16 384 "
+                       "rows on recon_lean_rows_kernel<onehot, haps, ragged, keep mask> (the `spliced_large` leg)"),
             "how": "ms_per_step: batches through DeviceSplicedHapsDataset.to_dataloader (a Python submit loop with two host reads per batch: "
                    "the keep mask's and the output's sizes), host clock; kernel_ms: the batch's one gvl_reconstruct launch, HIP events"}
 
@@ -1249,6 +1255,7 @@ def main() -> None:
             secondary["annotated_long"] = {"error": repr(exc)}
         secondary["long_modes_s"] = round(time.perf_counter() - t_l, 2)
         leg("spliced", lambda: secondary_spliced(torch))
+        leg("spliced_large", lambda: secondary_spliced(torch, pairs=4096, n=6))
 
     lean = (dev.ref4 is not None and dev.slot_rec is not None and L <= 2048 and L % 4 == 0
             and (int(os.environ.get("GVL_DBG", "0")) & ~(2 | 4 | 32768 | 65536 | 262144 | 524288 | 33554432 | 67108864)) == 0)

@@ -1,4 +1,5 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 O=gpurun_out/r06; mkdir -p $O
-python -m pytest tests/test_gpu_parity.py -q -x -k "many or few_long or ragged" > $O/t_new.log 2>&1; tail -n 15 $O/t_new.log
+tools/wbench.bin > $O/wbench.txt 2>&1; cat $O/wbench.txt
+python bench.py > $O/bench_default2.json 2> $O/bench_default2.err; tail -c 1500 $O/bench_default2.json; tail -n 3 $O/bench_default2.err
