@@ -66,6 +66,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 HBM_COPY_GBS = 6290.0      # measured float4-copy ceiling (same guide)
+HBM_STORE_GBS = 5650.0     # what the pool's boxes sustain store-only for outputs beyond the Infinity Cache (tools/wbench.hip: 5.4-5.8 TB/s,
+                           # profiles/r06_wbench.txt): the ceiling of a kernel that mostly writes -- a one-hot is 4 bytes out per half byte read
 
 
 def algorithmic_bytes_per_window(L: int, mean_variants: float, haps: bool, onehot: bool) -> float:
@@ -1327,6 +1329,9 @@ def main() -> None:
                 # would be a units mismatch
                 "frac_of_copy_ceiling": (traffic if traffic is not None else lbytes) / (kern_ms * 1e-3) / 1e9 / HBM_COPY_GBS,
                 "copy_ceiling_bytes": "moved (profiles/traffic.json)" if traffic is not None else "algorithmic",
+                "frac_of_store_ceiling": (traffic if traffic is not None else lbytes) / (kern_ms * 1e-3) / 1e9 / HBM_STORE_GBS,
+                "store_ceiling": "%.0f GB/s: store-only kernels over outputs of 134 MB - 1 GB sustain 5.4-5.8 TB/s on this pool (tools/wbench.hip, "
+                                 "profiles/r06_wbench.txt); nine tenths of this launch's traffic are stores" % HBM_STORE_GBS,
                 "kernel": (("recon_lean_rows_kernel<onehot, haps=%s> (ONE grid over the launch's %d batches; a wave takes rows w, w + W, ... "
                             "-- one or two rows per wave -- and fetches a row's window + slot line by LDS-DMA; nibble-packed reference)"
                             % ("true" if args.haps else "false", G)) if piped else
