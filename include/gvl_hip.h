@@ -159,8 +159,8 @@ typedef struct gvl_batch {
                                       (the PyO3 layer checks it on the host: src/ffi/mod.rs:101-139). */
     int64_t total_len_hint;        /* rows at out_offsets (ABI 11): the SUM of the rows' lengths when the caller knows it (it sized the
                                       output: out_offsets[-1]), else 0.  Tells a batch of mostly short rows with a few long ones -- a
-                                      spliced batch's exons: the pipelined kernel takes it, rows longer than its 2560 bases by its
-                                      solo path -- from a batch of long rows (the chunked kernel).  Without it every batch whose
+                                      spliced batch's exons: the pipelined kernel takes it, rows longer than its 2560 bases by the
+                                      launch's front workgroups, chunks in parallel -- from a batch of long rows (the chunked kernel).  Without it every batch whose
                                       max_row_len exceeds 2560 takes the chunked kernel.  Results never depend on it. */
     const int64_t *query_seed;     /* tracks only (ABI 11), nullable: i64 (batch): the GLOBAL batch row of local query q -- the `query`
                                       component of the FlankSample fill's per-position seed (src/tracks/mod.rs:744-760: callers that
