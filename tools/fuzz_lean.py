@@ -10,7 +10,10 @@ FUZZ_MANY=1: what bench.py and the native loader launch -- 4-16 batches of 1 500
 DEFAULT flags = ONE multi-workgroup grid of recon_lean_rows_kernel, every batch of every launch compared with the oracle; the rows per
 wave drawn per case (the built-in policy, 1.5, exactly 2, 3, 8: a wave's second and later rows are the DMA prefetch a row ahead, the
 counted vmcnt and the (batch, row) arithmetic of rows w + W, w + 2 W ...).  With FUZZ_RAGGED=1: the ragged form, offsets from
-gvl_hap_offsets per batch."""
+gvl_hap_offsets per batch.
+FUZZ_MIXED=1 (round 6): ragged batches of MOSTLY short rows with a few of 2 600 ... 20 000 bases (a spliced batch's exons), the route forced
+at any batch size (GVL_TUNE_MIXED_MIN_ROWS = 1): the pipelined kernel's ragged form whose FRONT workgroups run the long rows chunk by
+chunk in parallel -- with keep masks, annotations, ploidy 1-3, rows that straddle contig edges; GVL_DBG 256: long rows at the waves' ends."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -20,7 +23,8 @@ from oracle import oracle
 
 LONG = bool(int(os.environ.get("FUZZ_LONG", "0")))
 MANY = bool(int(os.environ.get("FUZZ_MANY", "0")))
-RAGGED = bool(int(os.environ.get("FUZZ_RAGGED", "0")))     # output_length = -1: rows at out_offsets (with FUZZ_LONG: the chunked kernel's ragged form)
+MIXED = bool(int(os.environ.get("FUZZ_MIXED", "0")))
+RAGGED = bool(int(os.environ.get("FUZZ_RAGGED", "0"))) or MIXED     # output_length = -1: rows at out_offsets (with FUZZ_LONG: the chunked kernel's ragged form)
 
 
 def one_case(rng):
@@ -61,6 +65,32 @@ def one_case(rng):
         bt.regions[:, 2] += rng.integers(0, 7, len(bt.regions)).astype(bt.regions.dtype)      # (lengths of every residue mod 4)
         bt.output_length = -1
     if not LONG and rng.random() < 0.3:            # a keep mask (rows of one chunk: the pipelined kernel reads it with the slot line)
+        idx = bt.geno_offset_idx.ravel()
+        n_per = bt.geno_offsets[1, idx] - bt.geno_offsets[0, idx]
+        bt.keep_offsets = np.concatenate([[0], np.cumsum(n_per)]).astype(np.int64)
+        bt.keep = rng.random(int(bt.keep_offsets[-1])) < float(rng.choice([0.2, 0.7, 0.95]))
+    return st, bt
+
+
+def mixed_case(rng):
+    contigs = tuple(int(x) for x in rng.integers(60_000, 400_000, int(rng.integers(1, 3))))
+    st = synth.make_static(rng, contigs, density=float(rng.choice([1 / 400, 1 / 100, 1 / 30])), indel_frac=float(rng.choice([0.0, 0.2, 0.6])),
+                           af_beta=(float(rng.choice([0.3, 0.6, 2.0])), float(rng.choice([0.9, 2.5]))), max_indel=int(rng.choice([3, 30, 200])),
+                           n_frac=float(rng.choice([0.0, 0.01])))
+    ploidy = int(rng.choice([1, 2, 2, 3]))
+    q = int(rng.integers(40, 700))
+    L = int(rng.choice([60, 150, 250, 400, 900]))
+    bt = synth.make_batch(rng, st, q, ploidy, L, slack=int(rng.choice([0, 8, 40])), rc_frac=float(rng.choice([0.0, 0.5, 1.0])),
+                          random_shifts=False, lookback=int(rng.choice([40, 300])), edge_frac=float(rng.choice([0.0, 0.0, 0.05])),
+                          permute_csr=bool(rng.random() < 0.5), output_length=-1)
+    bt.regions = bt.regions.copy()
+    bt.regions[:, 2] += rng.integers(0, 7, len(bt.regions)).astype(bt.regions.dtype)
+    n_long = int(rng.integers(1, 9))
+    lq = rng.choice(q, min(n_long, q), replace=False)
+    ends = bt.regions[lq, 1].astype(np.int64) + rng.integers(2600, 20_000, len(lq))
+    lim = np.array([st.ref_offsets[c + 1] - st.ref_offsets[c] for c in bt.regions[lq, 0]], np.int64) + int(rng.choice([0, 0, 300]))   # (some over the contig's end)
+    bt.regions[lq, 2] = np.minimum(ends, np.maximum(lim, bt.regions[lq, 1] + 2600)).astype(bt.regions.dtype)
+    if rng.random() < 0.5:
         idx = bt.geno_offset_idx.ravel()
         n_per = bt.geno_offsets[1, idx] - bt.geno_offsets[0, idx]
         bt.keep_offsets = np.concatenate([[0], np.cumsum(n_per)]).astype(np.int64)
@@ -178,6 +208,10 @@ if __name__ == "__main__":
         from genvarloader_amd import _lib
 
         _lib.set_tuning(_lib.TUNE_LEAN_SUB, int(os.environ["FUZZ_SUB"]))
+    if MIXED:
+        from genvarloader_amd import _lib
+
+        _lib.set_tuning(_lib.TUNE_MIXED_MIN_ROWS, 1)
     if MANY:
         bad, t0, rows = 0, time.time(), 0
         for ci in range(n_cases):
@@ -195,7 +229,7 @@ if __name__ == "__main__":
     t0 = time.time()
     for ci in range(n_cases):
         rng = np.random.default_rng(seed0 * 100003 + ci)
-        st, bt = one_case(rng)
+        st, bt = mixed_case(rng) if MIXED else one_case(rng)
         want = ((True, False), (True, True), (False, True))[ci % 3]         # one-hot only / one-hot + bytes / bytes only
         # (fixed-length rows of one chunk: every fourth case channel-major -- the pipelined kernel's form, also on launches of one small batch)
         layout = "cl" if (want[0] and not RAGGED and ci % 4 == 1) else "lc"          # (long rows: the chunked kernel's channel-major form)

@@ -12,6 +12,8 @@ echo "== fuzz_lean.py FUZZ_RAGGED=1 (output_length -1: the pipelined kernel's ra
 for d in 0 33554432 67108864; do run tools/fuzz_lean.py $d "FUZZ_RAGGED=1" $N 4010; done
 for d in 0 32768 65536 1048576; do run tools/fuzz_lean.py $d "FUZZ_LONG=1 FUZZ_RAGGED=1" $((N / 8)) 4011; done
 run tools/fuzz_lean.py 0 "FUZZ_LONG=1 FUZZ_RAGGED=1 FUZZ_SUB=1" $((N / 8)) 4012
+echo "== fuzz_lean.py FUZZ_MIXED=1 (round 6: ragged batches of short rows with a few long ones on the pipelined kernel: front workgroups / long rows at the waves' ends)"
+for d in 0 256 33554432; do run tools/fuzz_lean.py $d "FUZZ_MIXED=1" $((N / 4)) 4015; done
 echo "== fuzz_lean.py FUZZ_MANY=1 (4-16 batches of 1 500-6 000 queries in one grid, default flags; rows per wave 1 / 1.5 / 2 / 3 / 8; channel-major, annotated)"
 run tools/fuzz_lean.py 0 "FUZZ_MANY=1" $((N / 40)) 4020; run tools/fuzz_lean.py 0 "FUZZ_MANY=1 FUZZ_RAGGED=1" $((N / 40)) 4021
 run tools/fuzz_lean.py 1073741824 "FUZZ_MANY=1" $((N / 80)) 4022
