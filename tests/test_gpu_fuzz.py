@@ -126,6 +126,13 @@ def test_fuzz_lean_kernel_many_batches_one_grid(ragged):
     _run("fuzz_lean.py", 24, 250 + ragged, FUZZ_MANY=1, FUZZ_RAGGED=ragged)
 
 
+@pytest.mark.parametrize("dbg", [0, 256], ids=["front-workgroups", "solo-at-the-waves-ends"])
+def test_fuzz_lean_kernel_mixed_ragged_batches(dbg):
+    """FUZZ_MIXED=1: ragged batches of mostly short rows with a few of 2 600 ... 20 000 bases on the pipelined kernel (round 6): the long
+    rows by the launch's front workgroups, chunks in parallel / by the wave that meets them."""
+    _run("fuzz_lean.py", 200, 260 + (dbg >> 8), dbg=dbg, FUZZ_MIXED=1)
+
+
 def test_fuzz_svar2_provider():
     """tools/fuzz_svar2.py: random two-source batches (windows across the packed form's 16 entries and the general form's 64-entry
     tiles, filter_exonic, ragged / fixed, shifts, RC) -- gvl_svar2_merge + the kernels over the merged table vs the oracle's provider."""
