@@ -1,6 +1,10 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 O=gpurun_out/r06; mkdir -p $O
-python -m pytest tests -m gpu -q -x > $O/gpu_suite_final.log 2>&1; tail -n 4 $O/gpu_suite_final.log
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -n 2
-GVL_DBG=262144 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok under GVL_DBG=262144')" 2>&1 | tail -n 1
+python bench.py --workload cfg4 --steps 20 --warmup 3 2>$O/cfg4_err.txt | python -c "
+import sys, json
+d = json.loads(sys.stdin.readlines()[-1]); k = d['kernels']
+print('step %.1f us' % (d['ms_per_step'] * 1e3))
+for n, v in k.items():
+    if isinstance(v, dict): print('  ', n[:70], {a: (round(b * 1e3, 1) if 'ms' in a else round(b, 3)) for a, b in v.items() if a != 'algorithmic_bytes'})"
+tail -n 3 $O/cfg4_err.txt
