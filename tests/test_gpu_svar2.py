@@ -452,3 +452,33 @@ def test_reference_consensus_vectors(gpu, sv2, kpath):
         got, off = sv2.reconstruct_haplotypes_from_svar2(*_consensus_args(c))
         np.testing.assert_array_equal(off, c["expected_offsets"], err_msg=f"case {i}")
         np.testing.assert_array_equal(got, c["expected"], err_msg=f"case {i}")
+
+
+@pytest.mark.parametrize("strategy", [0, 3, 4])
+def test_tracks_on_the_reference_tests_del_only_records(gpu, sv2, oracle, strategy):
+    """The records of the reference's own end-to-end track test (tests/test_svar2_realign_tracks.py: POS 4 GTA>G, POS 10 GGG>G = pure DELs
+    at 3 and 9; S0 1|0 0|1, S1 1|1 1|0), everything in var_key and everything dense: the HIP SVAR2 track driver == the SVAR1 realign of
+    the oracle (the reference's assertion) == the oracle's SVAR2 driver, f32 bit patterns."""
+    haps = [[0], [1], [0, 1], [0]]
+    v_starts, ilens = np.array([3, 9], np.int32), np.array([-2, -2], np.int32)
+    regions = np.array([[0, 0, 40], [0, 0, 40]], np.int32)
+    go = np.concatenate([[0], np.cumsum([len(h) for h in haps])]).astype(np.int64)
+    gv = np.concatenate(haps).astype(np.int32)
+    tracks = np.random.default_rng(3).random(80).astype(np.float32)
+    toff = np.array([0, 40, 80], np.int64)
+    shifts = np.zeros((2, 2), np.int32)
+    d1 = oracle.get_diffs_sparse(np.arange(4).reshape(2, 2), gv, go, ilens, None, None, regions[:, 1].copy(), regions[:, 2].copy(), v_starts)
+    ooff = np.concatenate([[0], np.cumsum((40 + d1).reshape(-1))]).astype(np.int64)
+    exp = np.zeros(int(ooff[-1]), np.float32)
+    oracle.shift_and_realign_tracks_sparse(exp, ooff, regions, shifts, np.arange(4).reshape(2, 2), gv, go, v_starts, ilens, tracks, toff,
+                                           [2.0], None, None, strategy, 11)
+    for dense in (False, True):
+        if dense:
+            args = (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(5, np.int64), v_starts, ilens, np.array([[0, 2], [0, 2]], np.int64),
+                    np.packbits(np.array([1, 0, 0, 1, 1, 1, 1, 0], bool), bitorder="little"), np.array([0, 2, 4, 6, 8], np.int64))
+        else:
+            args = (v_starts[gv], ilens[gv], go, np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((2, 2), np.int64), np.zeros(0, np.uint8),
+                    np.zeros(5, np.int64))
+        got, off = sv2.shift_and_realign_tracks_from_svar2(regions, shifts, *args, tracks, toff, [2.0], strategy, 11)
+        np.testing.assert_array_equal(off, ooff)
+        np.testing.assert_array_equal(np.asarray(got).view(np.uint32), exp.view(np.uint32), err_msg=f"dense {dense}")
