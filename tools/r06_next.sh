@@ -1,3 +1,3 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-python -m pytest tests/test_gpu_svar2.py -q -x -k "del_only" 2>&1 | tail -n 8
+python tools/slice_exp.py 2>&1 | grep -v amdgpu.ids
