@@ -1,5 +1,3 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-O=gpurun_out/r06; mkdir -p $O
-for i in 1 2; do python -m pytest tests -m gpu -q -x > $O/gpu_suite_rep$i.log 2>&1; tail -n 1 $O/gpu_suite_rep$i.log; done
-timeout 600 python tools/loader_stress.py > $O/loader_stress.txt 2>&1; tail -n 3 $O/loader_stress.txt
+for p in 1536 2048 3072; do for d in 0 256 0 256; do echo -n "pairs $p GVL_DBG=$d: "; GVL_DBG=$d python tools/spliced_bench.py $p 2>&1 | grep -E "\"kernel_ms|exon rows" | tr '\n' ' ' | sed 's/"workload": "spliced haplotypes under the exonic keep mask: //' | cut -c1-200; echo; done; done
