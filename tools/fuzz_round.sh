@@ -2,7 +2,8 @@
 # tools/fuzz_round.sh: the round's fuzz campaign on the current build -> stdout (profiles/rNN_fuzz.txt)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 N=${N:-20000}
-run() { echo -n "$1 GVL_DBG=${2:-0} ${3}: "; env GVL_DBG=${2:-0} $3 python $1 ${4:-$N} ${5:-4001} 2>&1 | tail -1; }
+SEED_OFFSET=${SEED_OFFSET:-0}      # (another campaign over other cases: SEED_OFFSET=1000 ...)
+run() { echo -n "$1 GVL_DBG=${2:-0} ${3}: "; env GVL_DBG=${2:-0} $3 python $1 ${4:-$N} $(( ${5:-4001} + SEED_OFFSET )) 2>&1 | tail -1; }
 echo "== fuzz_lean.py (rows of one chunk; one-hot / one-hot + bytes / bytes)"
 for d in 0 65536 32768 33554432 33619968 33587200 67108864 1073741824; do run tools/fuzz_lean.py $d "" $N 4001; done
 echo "== fuzz_lean.py FUZZ_LONG=1 (rows of 2 052 ... 40 000 bases: the chunked form)"
