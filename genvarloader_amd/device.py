@@ -272,9 +272,10 @@ class HapsDevice:
                                                      C.c_int64(1), _ptr(diffs), _stream_ptr()))
         return diffs
 
-    def choose_exonic_variants(self, starts, ends, geno_offset_idx):
+    def choose_exonic_variants(self, starts, ends, geno_offset_idx, max_per_row=None):
         """choose_exonic_variants (src/genotypes/mod.rs:127-176) -> (keep u8[total], keep_offsets i64[K+1])
-        device tensors; one host sync for the exactly-sized mask."""
+        device tensors; one host sync for the exactly-sized mask -- or none when the caller knows a bound on a row's variants
+        (``max_per_row``: the mask is then allocated for rows x that; only its first keep_offsets[-1] bytes mean anything)."""
         d = self.device
         goi = _dev(geno_offset_idx, torch.int64, d)
         st_, en_ = _dev(starts, torch.int32, d), _dev(ends, torch.int32, d)
@@ -284,7 +285,10 @@ class HapsDevice:
         with torch.cuda.device(d):
             _lib.check(self.lib.gvl_keep_offsets(C.byref(self.c), _ptr(goi), C.c_int64(B), C.c_int64(P), _ptr(ko), _ptr(tm),
                                                  _stream_ptr()))
-            total = int(tm[0].item()) if B * P else 0
+            if max_per_row is not None:
+                total = B * P * max(0, int(max_per_row))
+            else:
+                total = int(tm[0].item()) if B * P else 0
             keep = torch.empty(total, dtype=torch.uint8, device=d)
             if total:
                 _lib.check(self.lib.gvl_choose_exonic_variants(C.byref(self.c), _ptr(st_), _ptr(en_), _ptr(goi), C.c_int64(B),

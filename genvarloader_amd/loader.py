@@ -557,7 +557,7 @@ class DeviceSplicedHapsDataset(DeviceHapsDataset):
     element where it belongs in its spliced haplotype (``reconstruct_haplotypes_spliced_fused``,
     ``ffi/mod.rs:1981-2076``); negative-strand elements are reverse-complemented in place when
     ``rc_neg``.  Like the reference: ragged only, deterministic, no jitter (``_query.py:225-226``).
-    One host read per batch (the total size, for the exactly-sized allocation)."""
+    One host read per batch (the output's total size, for the exactly-sized allocation); the keep mask is sized by a bound."""
 
     def __init__(self, dev, regions, n_samples, ploidy, *, splice_offsets, splice_region_idx, rc_neg: bool = True,
                  onehot: bool = False, haps: bool = True, annotate: bool = False, exonic: bool = False):
@@ -581,6 +581,13 @@ class DeviceSplicedHapsDataset(DeviceHapsDataset):
 
     def __len__(self):
         return self.n_rows * self.n_samples
+
+    def _max_slot_variants(self) -> int:
+        """The most variants any genotype slot of the dataset holds (one device reduction + host read, once per dataset)."""
+        if getattr(self, "_max_nv", None) is None:
+            go = self.dev.geno_offsets
+            self._max_nv = int((go[1] - go[0]).max().item()) if go[0].numel() else 0
+        return self._max_nv
 
     def __getitem__(self, pairs) -> SplicedBatch:
         d, P, S = self.dev.device, self.ploidy, self.n_samples
@@ -614,7 +621,10 @@ class DeviceSplicedHapsDataset(DeviceHapsDataset):
         to_rc_p = None if to_rc is None else to_rc.index_select(0, perm).contiguous()
         keep = keep_offsets = None
         if self.exonic and B:
-            keep, keep_offsets = self.dev.choose_exonic_variants(regions_p[:, 1].contiguous(), regions_p[:, 2].contiguous(), goi_p)
+            # (no host read for the mask's size: a row has at most the dataset's largest genotype slot's variants)
+            mx = self._max_slot_variants()             # (... unless an outlier slot makes that bound absurd: then the exact size, one read)
+            keep, keep_offsets = self.dev.choose_exonic_variants(regions_p[:, 1].contiguous(), regions_p[:, 2].contiguous(), goi_p,
+                                                                 max_per_row=mx if B * P * mx <= (64 << 20) else None)
         out = self.dev.reconstruct(regions_p, shifts_p, goi_p, -1, keep, keep_offsets, to_rc=to_rc_p, haps=self.haps,
                                    onehot=self.onehot, annotate=self.annotate)
         cells = torch.zeros(n_pairs * P + 1, dtype=torch.int64, device=d)
