@@ -610,7 +610,7 @@ def secondary_spliced(torch, n_tx: int = 1500, S: int = 8, pairs: int = 256, n: 
                        "a batch of a few thousand short rows + a few long ones: the all-purpose kernel (launch-latency-bound: 7 MB of work); from 16 384 "
                        "rows on recon_lean_rows_kernel<onehot, haps, ragged, keep mask> (the `spliced_large` leg)"),
             "how": "ms_per_step: batches through DeviceSplicedHapsDataset.to_dataloader (a Python submit loop with one host read per batch: "
-                   "the output's size; ~60 small device launches), host clock; kernel_ms: the batch's one gvl_reconstruct launch, HIP events"}
+                   "the output's size; ~30 small device launches), host clock; kernel_ms: the batch's one gvl_reconstruct launch, HIP events"}
 
 
 
