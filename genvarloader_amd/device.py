@@ -55,9 +55,19 @@ def _ptr(t: torch.Tensor | None):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_CUR_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream_ptr(stream=None):
-    s = torch.cuda.current_stream() if stream is None else stream
-    return C.c_void_p(s.cuda_stream)
+    """The HIP stream a launch goes to: `stream`, else the current device's current torch stream (read through torch's raw
+    accessor where it has one: `torch.cuda.current_stream()` builds a Stream object per call, several microseconds of a
+    launch that costs the device ten)."""
+    if stream is not None:
+        return C.c_void_p(stream.cuda_stream)
+    if _RAW_STREAM is not None and _CUR_DEVICE is not None:
+        return C.c_void_p(_RAW_STREAM(_CUR_DEVICE()))
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def _starts_stops(geno_offsets):

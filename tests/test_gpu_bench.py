@@ -130,3 +130,20 @@ def test_bench_starts_its_own_ranks():
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["gather_ms"] > 0 and d["scaling"] == "weak"
     assert abs(d["value"] - 8192 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+def test_stream_ptr_is_torchs_current_stream():
+    """device._stream_ptr reads the current stream through torch's raw accessor: the same handle as torch.cuda.current_stream()'s, on
+    the default stream and inside a `with torch.cuda.stream(...)`."""
+    import torch
+
+    from genvarloader_amd import device as gdev
+
+    assert gdev._stream_ptr().value in (None, 0) or gdev._stream_ptr().value == torch.cuda.current_stream().cuda_stream
+    assert (gdev._stream_ptr().value or 0) == torch.cuda.current_stream().cuda_stream
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        assert (gdev._stream_ptr().value or 0) == s.cuda_stream
+        assert (gdev._stream_ptr(s).value or 0) == s.cuda_stream
+    assert (gdev._stream_ptr().value or 0) == torch.cuda.current_stream().cuda_stream
