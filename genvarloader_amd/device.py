@@ -55,6 +55,28 @@ def _ptr(t: torch.Tensor | None):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+class _on_device:
+    """`with _on_device(d)` without its constructor's `_get_device_index` (availability probe, environment lookups: ~8 us a time,
+    a dozen times per batch of the Python submit loops): the same two calls torch's own context manager makes."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, d):
+        i = d if isinstance(d, int) else getattr(d, "index", None)
+        self.idx = -1 if i is None else int(i)             # (-1: no-op, as for torch.cuda.device(None))
+        self.prev = -1
+
+    def __enter__(self):
+        self.prev = torch.cuda._exchange_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        torch.cuda._maybe_exchange_device(self.prev)
+        return False
+
+
+if not (hasattr(torch.cuda, "_exchange_device") and hasattr(torch.cuda, "_maybe_exchange_device")):
+    _on_device = torch.cuda.device          # (a torch without those: its own context manager)     # noqa: F811
+
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _CUR_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
 
@@ -136,7 +158,7 @@ class HapsDevice:
             raise ValueError("variant table arrays disagree on n_variants")
         # 16-byte packed records (gvl_pack_variants) -- built once per dataset
         self.vrec = torch.empty((max(n_var, 1), 4), dtype=torch.int32, device=d)
-        with torch.cuda.device(d):
+        with _on_device(d):
             _lib.check(self.lib.gvl_pack_variants(
                 _ptr(self.v_starts), _ptr(self.ilens), _ptr(self.alt_offsets), _ptr(self.alt_alleles),
                 C.c_int64(n_var), _ptr(self.vrec), _stream_ptr()))
@@ -159,7 +181,7 @@ class HapsDevice:
         if inline_genotypes is None:
             inline_genotypes = n_geno > 0 and n_var > 0 and 16 * n_geno <= torch.cuda.mem_get_info(d)[0] // 4
         if inline_genotypes and n_geno > 0 and n_var > 0:
-            with torch.cuda.device(d):
+            with _on_device(d):
                 self.geno_rec = torch.empty((n_geno, 4), dtype=torch.int32, device=d)
                 _lib.check(self.lib.gvl_pack_genotypes(C.byref(self.c), _ptr(self.geno_rec), _stream_ptr()))
             self.c.geno_rec = self.geno_rec.data_ptr()
@@ -172,12 +194,12 @@ class HapsDevice:
             slot_records = (n_go > 0 and n_var > 0 and int(self.alt_alleles.numel()) < (1 << 32)
                             and 128 * n_go <= torch.cuda.mem_get_info(d)[0] // 4)
         if slot_records and n_go > 0 and n_var > 0:
-            with torch.cuda.device(d):
+            with _on_device(d):
                 self.slot_rec = torch.empty((n_go * 8, 4), dtype=torch.int32, device=d)
                 _lib.check(self.lib.gvl_pack_slots(C.byref(self.c), _ptr(self.slot_rec), _stream_ptr()))
             self.c.slot_rec = self.slot_rec.data_ptr()
             # ... and the records' variant indices (32 B per slot): what annotated haplotypes need next to the slot line
-            with torch.cuda.device(d):
+            with _on_device(d):
                 self.slot_vidx = torch.empty((n_go * 8,), dtype=torch.int32, device=d)
                 _lib.check(self.lib.gvl_pack_slot_vidx(C.byref(self.c), _ptr(self.slot_vidx), _stream_ptr()))
             self.c.slot_vidx = self.slot_vidx.data_ptr()
@@ -188,7 +210,7 @@ class HapsDevice:
         if packed_reference is None:      # (also for a reference-only static: gvl_get_reference's lean route reads it)
             packed_reference = n_ref > 0 and n_ref // 2 <= torch.cuda.mem_get_info(d)[0] // 4
         if packed_reference and n_ref > 0:
-            with torch.cuda.device(d):
+            with _on_device(d):
                 self.ref4 = torch.empty(int(self.lib.gvl_ref4_bytes(n_ref)), dtype=torch.uint8, device=d)
                 _lib.check(self.lib.gvl_pack_reference(_ptr(self.ref), C.c_int64(n_ref), _ptr(self.ref4), _stream_ptr()))
             self.c.ref4 = self.ref4.data_ptr()
@@ -250,7 +272,7 @@ class HapsDevice:
         if n <= 0:
             return None
         plan = torch.empty(n, dtype=torch.uint8, device=self.device)
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             _lib.check(self.lib.gvl_hap_plan(C.byref(self.c), C.byref(bt.c), _ptr(plan), _stream_ptr()))
         plan._gvl_plan_of = (bt.n_rows, bt.output_length)      # (checked by prepare_batch)
         return plan
@@ -262,7 +284,7 @@ class HapsDevice:
         oo = torch.empty(n + 1, dtype=torch.int64, device=self.device)
         tm = torch.empty(2, dtype=torch.int64, device=self.device)
         diffs = torch.empty(tuple(bt.geno_offset_idx.shape), dtype=torch.int32, device=self.device) if want_diffs else None
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             _lib.check(self.lib.gvl_hap_offsets(C.byref(self.c), C.byref(bt.c), _ptr(diffs), _ptr(oo),
                                                 _ptr(tm), _stream_ptr()))
         return oo, tm, diffs
@@ -277,7 +299,7 @@ class HapsDevice:
                      keep=None if kp is None else kp.data_ptr(),
                      keep_offsets=None if ko is None else ko.data_ptr())
         diffs = torch.empty(tuple(goi.shape), dtype=torch.int32, device=d)
-        with torch.cuda.device(d):
+        with _on_device(d):
             _lib.check(self.lib.gvl_get_diffs_sparse(C.byref(self.c), C.byref(c), _ptr(qs), _ptr(qe),
                                                      C.c_int64(1), _ptr(diffs), _stream_ptr()))
         return diffs
@@ -292,7 +314,7 @@ class HapsDevice:
         B, P = int(goi.shape[0]), int(goi.shape[1])
         ko = torch.empty(B * P + 1, dtype=torch.int64, device=d)
         tm = torch.zeros(2, dtype=torch.int64, device=d)
-        with torch.cuda.device(d):
+        with _on_device(d):
             _lib.check(self.lib.gvl_keep_offsets(C.byref(self.c), _ptr(goi), C.c_int64(B), C.c_int64(P), _ptr(ko), _ptr(tm),
                                                  _stream_ptr()))
             if max_per_row is not None:
@@ -356,7 +378,7 @@ class HapsDevice:
         Fixed length: one launch, no host sync.  Ragged (output_length < 0): sizes on
         the device, then one host read of {total, max} to allocate (the reference
         returns an exactly-sized buffer, ffi/mod.rs:814-815)."""
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             bt = self.prepare_batch(regions, shifts, geno_offset_idx, output_length, keep, keep_offsets,
                                     to_rc, out_offsets)
             n = bt.n_rows
@@ -386,7 +408,7 @@ class HapsDevice:
     def get_reference(self, regions, out_offsets, to_rc=None, *, onehot=False, max_row_len=None):
         """get_reference (ffi/mod.rs:2401-2429) -> u8[total] (and (total, 4) one-hot)."""
         d = self.device
-        with torch.cuda.device(d):
+        with _on_device(d):
             reg = _dev(regions, torch.int32, d)
             oo = _dev(out_offsets, torch.int64, d)
             rc = _dev(to_rc, torch.uint8, d)
@@ -414,7 +436,7 @@ def _get_reference_many(self, batches, *, onehot=False, haps=True):
     n = len(batches)
     arr = (_lib.GvlRefBatch * n)()
     outs, keep = [], []
-    with torch.cuda.device(d):
+    with _on_device(d):
         for i, (regions, out_offsets, to_rc, total, max_row_len) in enumerate(batches):
             reg = _dev(regions, torch.int32, d)
             oo = _dev(out_offsets, torch.int64, d)
@@ -442,7 +464,7 @@ def rc_flat_rows_inplace(data: torch.Tensor, offsets, to_rc) -> None:
     assert data.dtype == torch.uint8 and data.is_contiguous()
     if data.numel() == 0 or rc.numel() == 0:
         return
-    with torch.cuda.device(d):
+    with _on_device(d):
         _lib.check(lib.gvl_rc_rows(_ptr(data), _ptr(oo), _ptr(rc), C.c_int64(rc.numel()), _stream_ptr()))
 
 
@@ -454,7 +476,7 @@ def rc_bounded_rows_inplace(data: torch.Tensor, bounds, to_rc) -> None:
     assert data.dtype == torch.uint8 and data.is_contiguous() and bd.dim() == 2 and bd.shape[1] == 2
     if data.numel() == 0 or rc.numel() == 0:
         return
-    with torch.cuda.device(d):
+    with _on_device(d):
         _lib.check(lib.gvl_rc_bounded_rows(_ptr(data), _ptr(bd), _ptr(rc), C.c_int64(rc.numel()), _stream_ptr()))
 
 
@@ -466,7 +488,7 @@ def reverse_flat_rows_inplace(data: torch.Tensor, offsets, to_rc) -> None:
     assert data.element_size() == 4 and data.is_contiguous()
     if data.numel() == 0 or rc.numel() == 0:
         return
-    with torch.cuda.device(d):
+    with _on_device(d):
         _lib.check(lib.gvl_reverse_rows_4(_ptr(data), _ptr(oo), _ptr(rc), C.c_int64(rc.numel()), _stream_ptr()))
 
 
@@ -476,7 +498,7 @@ def onehot(x: torch.Tensor) -> torch.Tensor:
     assert x.dtype == torch.uint8 and x.is_cuda
     x = x.contiguous()
     out = torch.empty(tuple(x.shape) + (4,), dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         _lib.check(lib.gvl_onehot(_ptr(x), C.c_int64(x.numel()), _ptr(out), _stream_ptr()))
     return out
 
@@ -488,7 +510,7 @@ def intervals_prefix_max(itv_ends, itv_offsets, device="cuda") -> torch.Tensor:
     d = torch.device(device)
     b, io = _dev(itv_ends, torch.int32, d), _dev(itv_offsets, torch.int64, d)
     pm = torch.empty_like(b)
-    with torch.cuda.device(d):
+    with _on_device(d):
         _lib.check(lib.gvl_intervals_prefix_max(_ptr(b), _ptr(io), C.c_int64(int(io.numel()) - 1), _ptr(pm), _stream_ptr()))
     return pm
 
@@ -503,7 +525,7 @@ def intervals_bucket_index(itv_starts, itv_pmax_ends, itv_offsets, device="cuda"
     bo = torch.empty(n_lists + 1, dtype=torch.int64, device=d)
     base = torch.empty(max(n_lists, 1), dtype=torch.int32, device=d)
     tot = torch.zeros(2, dtype=torch.int64, device=d)
-    with torch.cuda.device(d):
+    with _on_device(d):
         _lib.check(lib.gvl_intervals_bucket_counts(_ptr(a), _ptr(io), C.c_int64(n_lists), _ptr(bo), _ptr(base), _ptr(tot),
                                                    _stream_ptr()))
         n_b = int(tot[0].item())
@@ -549,11 +571,11 @@ def intervals_to_tracks(offset_idxs, starts, itv_starts, itv_ends, itv_values, i
     if max_row_len is None:
         max_row_len = int((oo[1:] - oo[:-1]).max().item())
     if track_set is not None:
-        with torch.cuda.device(d):
+        with _on_device(d):
             _lib.check(lib.gvl_paint_tracks(C.byref(track_set), _ptr(oi), _ptr(st), C.c_int64(starts_stride), C.c_int64(n), _ptr(out),
                                             _ptr(oo), C.c_int64(max_row_len), _stream_ptr()))
         return out
-    with torch.cuda.device(d):
+    with _on_device(d):
         pm = _dev(itv_pmax_ends, torch.int32, d)
         _lib.check(lib.gvl_intervals_to_tracks(_ptr(oi), _ptr(st), C.c_int64(starts_stride), C.c_int64(n), _ptr(a),
                                                _ptr(b), _ptr(v), _ptr(io), C.c_int64(int(a.numel())), _ptr(pm),
@@ -566,7 +588,7 @@ def realign_tracks(dev: "HapsDevice", regions, shifts, geno_offset_idx, out_offs
     """shift_and_realign_tracks_sparse (src/tracks/mod.rs:495-667) + the reversal of negative-strand
     rows (src/ffi/mod.rs:2657-2668) -> f32[out_offsets[-1]] device tensor."""
     d = dev.device
-    with torch.cuda.device(d):
+    with _on_device(d):
         bt = dev.prepare_batch(regions, shifts, geno_offset_idx, -1, keep, keep_offsets, to_rc, out_offsets)
         qs = _dev(query_seed, torch.int64, d)        # (src/tracks/mod.rs:754-760: the FlankSample seed's query component, per local query)
         if qs is not None:

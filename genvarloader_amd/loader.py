@@ -27,6 +27,7 @@ import os
 import numpy as np
 import torch
 
+from .device import _on_device
 from .sharding import epoch_order
 
 
@@ -173,7 +174,7 @@ class DeviceHapsDataset:
         to_rc = torch.empty(b * P, dtype=torch.uint8, device=d)
         shifts = torch.empty((b, P), dtype=torch.int32, device=d)
         d_seed, d_counter = self._draw_key()
-        with torch.cuda.device(d):
+        with _on_device(d):
             _lib.check(self.dev.lib.gvl_prepare_request(
                 C.byref(self.dev.c), _ptr(idx), C.c_int64(b), _ptr(self.full_regions), C.c_int64(self.n_regions),
                 C.c_int64(self.n_samples), C.c_int64(P), C.c_int64(self.jitter), C.c_int32(int(self.rc_neg)),
@@ -228,7 +229,7 @@ class DeviceHapsDataset:
         d_seed, d_counter = self._draw_key()
         lib = self.dev.lib
         stream = C.c_void_p(torch.cuda.current_stream(d).cuda_stream)
-        with torch.cuda.device(d):
+        with _on_device(d):
             _lib.check(lib.gvl_prepare_request(
                 C.byref(self.dev.c), C.c_void_p(idx.data_ptr()), C.c_int64(b), C.c_void_p(self.full_regions.data_ptr()),
                 C.c_int64(self.n_regions), C.c_int64(self.n_samples), C.c_int64(P), C.c_int64(self.jitter),
@@ -479,7 +480,7 @@ class DeviceHapsTracksDataset(DeviceHapsDataset):
                       to_rc=None if base.to_rc is None else base.to_rc.data_ptr(), output_length=L, out_offsets=None,
                       max_row_len=L)
         par = (C.c_double * 1)(self.param)
-        with torch.cuda.device(d):
+        with _on_device(d):
             _lib.check(lib.gvl_tracks_batch(
                 C.byref(dev.c), C.byref(bt), C.c_void_p(base.idx.data_ptr()), self._track_sets, C.c_int32(T), par,
                 C.c_int64(self.strategy_id), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_void_p(arena.data_ptr()),
@@ -729,7 +730,7 @@ class DeviceLoader:
         ptrs = (C.c_void_p * n_slots)(*[a.data_ptr() for a in arenas])
         cfg.slot_arenas = C.cast(ptrs, C.POINTER(C.c_void_p))
         handle = C.c_void_p()
-        with torch.cuda.device(d):
+        with _on_device(d):
             _lib.check(lib.gvl_loader_create(C.byref(ds.dev.c), C.byref(cfg), C.byref(handle)))
         self._native = dict(handle=handle, arenas=arenas, parts=[int(x) for x in parts], cfg=cfg, ptrs=ptrs,
                             out=GvlLoaderBatch(), views={})
@@ -843,7 +844,7 @@ class DeviceLoader:
             self._native_setup()
         nat, ds, d = self._native, self.ds, self.ds.dev.device
         lib, handle, out = ds.dev.lib, nat["handle"], nat["out"]
-        with torch.cuda.device(d):
+        with _on_device(d):
             cur = torch.cuda.current_stream(d)
             g = self.generator
 

@@ -33,7 +33,7 @@ import torch
 from . import _lib
 from . import device as _device
 from ._lib import GvlBatch, GvlStatic, GvlSvar2Batch
-from .device import HapsDevice, _dev, _ptr, _stream_ptr
+from .device import HapsDevice, _dev, _on_device, _ptr, _stream_ptr
 
 
 class Svar2Channels:
@@ -98,7 +98,7 @@ class Svar2Merged(HapsDevice):
         self._ws_off = (-base) % 256
         self.c = GvlStatic()
         goi = C.c_void_p()
-        with torch.cuda.device(d):
+        with _on_device(d):
             _lib.check(self.lib.gvl_svar2_merge(C.byref(ref_dev.c), C.byref(ch.c), _ptr(reg), C.c_int64(reg.shape[1]),
                                                 C.c_int64(batch), C.c_int64(ploidy), C.c_void_p(base + self._ws_off),
                                                 C.c_int64(nbytes), C.byref(self.c), C.byref(goi), _stream_ptr()))
@@ -235,7 +235,7 @@ def reconstruct_haplotypes_from_svar2_into(
     d = m.device
     if ob.shape[0] != m.geno_offset_idx.numel():
         raise ValueError("out_bounds must have one row per (query, hap)")
-    with torch.cuda.device(d):
+    with _on_device(d):
         buf = torch.from_numpy(out).to(d) if out.size else torch.empty(0, dtype=torch.uint8, device=d)
         obd = _dev(ob, torch.int64, d)
         sh = _dev(shifts, torch.int32, d)
@@ -290,7 +290,7 @@ def shift_and_realign_tracks_from_svar2(
     reg0 = regions.copy()
     reg0[:, 0] = 0
     m = merge(dev, ch, reg0, shifts.shape[1])
-    with torch.cuda.device(m.device):
+    with _on_device(m.device):
         bt = m.prepare_batch(m.regions, shifts, m.geno_offset_idx, -1)
         oo, tm, _ = m.hap_offsets(bt)
     res = _device.realign_tracks(m, m.regions, shifts, m.geno_offset_idx, oo, tracks, track_offsets, params, strategy_id, base_seed)
