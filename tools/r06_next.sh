@@ -1,5 +1,6 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-python -m pytest tests/test_gpu_bench.py tests/test_splice.py tests/test_loader.py tests/test_gpu_svar2.py -q -x 2>&1 | tail -n 3
-python tools/spliced_bench.py 256 2>&1 | grep -E "ms_per_step"
-python tools/ffi_bench.py 2>&1 | grep -v amdgpu.ids | tail -n 4
+O=gpurun_out/r06; mkdir -p $O
+python -m pytest tests -m gpu -q -x > $O/gpu_suite_final2.log 2>&1; tail -n 2 $O/gpu_suite_final2.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -n 1
+python bench.py > $O/bench_default4.json 2> $O/bench_default4.err; tail -c 200 $O/bench_default4.json
