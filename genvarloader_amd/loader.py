@@ -575,6 +575,7 @@ class DeviceSplicedHapsDataset(DeviceHapsDataset):
         d = dev.device
         self._so, self._sr = torch.as_tensor(so).to(d), torch.as_tensor(sr).to(d)
         self.exonic = bool(exonic)
+        self.host_index_max = 8192          # batches of up to this many elements: index arithmetic on the host (see __getitem__)
 
     @property
     def shape(self):
@@ -601,26 +602,39 @@ class DeviceSplicedHapsDataset(DeviceHapsDataset):
             raise IndexError("pair index out of range")
         # The batch's index arithmetic -- element dataset indices, the splice plan's permutation (``build_splice_plan``,
         # ``_dataset/_splice.py:82-88``: element i of pair p, ploid e goes to P * start[p] + e * len[p] + i; it depends on the pairs' element
-        # counts only, not on any length), the cells' bounds -- is done on the HOST in numpy (a few thousand elements: tens of
-        # microseconds) and uploaded in ONE copy: as torch device ops it was twenty launches of a few hundred threads each, a quarter of
-        # the batch's 0.7 ms (round 6).
+        # counts only, not on any length), the cells' bounds.  Batches of up to 8192 elements: numpy on the HOST (tens of microseconds) and
+        # ONE upload -- as torch device ops it is twenty launches of a few hundred threads each, a quarter of a 256-pair batch's 0.7 ms
+        # (round 6); larger batches: the device ops (a 4 096-pair batch: 1.05 against 1.33 ms).
         row_h, smp_h = pairs_h // S, pairs_h % S
         n_pairs = int(pairs_h.size)
         pair_len_h = self._len_host[row_h].astype(np.int64)
-        B = int(pair_len_h.sum())                           # elements of the batch
-        start_h = np.cumsum(pair_len_h) - pair_len_h
-        pair_of_q = np.repeat(np.arange(n_pairs, dtype=np.int64), pair_len_h)
-        i_local = np.arange(B, dtype=np.int64) - start_h[pair_of_q]
-        r_idx_h = self._sr_host[self._so_host[row_h[pair_of_q]] + i_local] if B else np.zeros(0, np.int64)
-        ds_idx_h = r_idx_h * S + smp_h[pair_of_q]
-        dest = (P * start_h[pair_of_q] + i_local)[:, None] + np.arange(P, dtype=np.int64)[None, :] * pair_len_h[pair_of_q][:, None]
-        perm_h = np.empty(B * P, np.int64)
-        perm_h[dest.reshape(-1)] = np.arange(B * P, dtype=np.int64)
-        cells_h = np.zeros(n_pairs * P + 1, np.int64)
-        np.cumsum(np.repeat(pair_len_h, P), out=cells_h[1:])
-        packed = torch.from_numpy(np.concatenate([pairs_h, ds_idx_h, perm_h, perm_h // P, cells_h])).to(d)
-        o1, o2, o3, o4 = n_pairs, n_pairs + B, n_pairs + B + B * P, n_pairs + B + 2 * B * P
-        pairs_d, ds_idx, perm, q_of, cells_idx = packed[:o1], packed[o1:o2], packed[o2:o3], packed[o3:o4], packed[o4:]
+        B = int(pair_len_h.sum())                           # elements of the batch: known on the host, no sync
+        if B <= self.host_index_max:
+            start_h = np.cumsum(pair_len_h) - pair_len_h
+            pair_of_q = np.repeat(np.arange(n_pairs, dtype=np.int64), pair_len_h)
+            i_local = np.arange(B, dtype=np.int64) - start_h[pair_of_q]
+            r_idx_h = self._sr_host[self._so_host[row_h[pair_of_q]] + i_local] if B else np.zeros(0, np.int64)
+            ds_idx_h = r_idx_h * S + smp_h[pair_of_q]
+            dest = (P * start_h[pair_of_q] + i_local)[:, None] + np.arange(P, dtype=np.int64)[None, :] * pair_len_h[pair_of_q][:, None]
+            perm_h = np.empty(B * P, np.int64)
+            perm_h[dest.reshape(-1)] = np.arange(B * P, dtype=np.int64)
+            cells_h = np.zeros(n_pairs * P + 1, np.int64)
+            np.cumsum(np.repeat(pair_len_h, P), out=cells_h[1:])
+            packed = torch.from_numpy(np.concatenate([pairs_h, ds_idx_h, perm_h, perm_h // P, cells_h])).to(d)
+            o1, o2, o3, o4 = n_pairs, n_pairs + B, n_pairs + B + B * P, n_pairs + B + 2 * B * P
+            pairs_d, ds_idx, perm, q_of, cells_idx = packed[:o1], packed[o1:o2], packed[o2:o3], packed[o3:o4], packed[o4:]
+        else:
+            pairs_d = torch.as_tensor(pairs_h).to(d)
+            row, smp = pairs_d // S, pairs_d % S
+            pair_len = (self._so[row + 1] - self._so[row])
+            start = torch.cumsum(pair_len, 0) - pair_len
+            pair_of_q = torch.repeat_interleave(torch.arange(n_pairs, device=d), pair_len, output_size=B)
+            i_local = torch.arange(B, device=d) - start[pair_of_q]
+            ds_idx = self._sr[self._so[row[pair_of_q]] + i_local] * S + smp[pair_of_q]
+            perm, _, _ = splice_plan_device(torch.zeros((B, P), dtype=torch.int32, device=d), pair_len)
+            q_of = torch.div(perm, P, rounding_mode="floor")
+            cells_idx = torch.zeros(n_pairs * P + 1, dtype=torch.int64, device=d)
+            torch.cumsum(pair_len.repeat_interleave(P), 0, out=cells_idx[1:])
         _, regions, shifts, goi, to_rc = self.request(ds_idx)
         # per-element lengths -> plan.  The lengths come out of the ragged sizing of the permuted launch
         # itself (region length + length delta, under the keep mask when exonic), so the plan only needs

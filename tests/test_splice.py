@@ -82,7 +82,8 @@ def test_torch_splice_plan_matches_reference_vectors():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("exonic", [False, True], ids=["all-variants", "exonic-keep-mask"])
-def test_spliced_dataset_matches_oracle(oracle, exonic):
+@pytest.mark.parametrize("index_on", ["host", "device"])
+def test_spliced_dataset_matches_oracle(oracle, exonic, index_on):
     """(splice row, sample) pairs -> one spliced haplotype per ploid: against the oracle's plan over the
     oracle's per-element lengths and its ploidy-1 reconstruction at the plan's offsets
     (_query.py:207-313, _haps.py:876-931, _haps.py:1058-1112)."""
@@ -102,6 +103,8 @@ def test_spliced_dataset_matches_oracle(oracle, exonic):
     ds = DeviceSplicedHapsDataset(dev, full_regions, S, P, splice_offsets=so, splice_region_idx=sr, onehot=True, haps=True,
                                   annotate=True, exonic=exonic)
     assert len(ds) == n_rows * S
+    if index_on == "device":
+        ds.host_index_max = -1              # (large batches' way: the index arithmetic as torch device ops)
     seen = 0
     for batch in ds.to_dataloader(batch_size=6, shuffle=True, seed=2):
         pairs = batch.pairs.cpu().numpy()
